@@ -1,0 +1,171 @@
+/* meld_hip.h -- C-ABI of libmeld_hip.so: the MI355X (gfx950) hot path of MELD.fit_transform.
+ *
+ * The reference (KrishnaswamyLab/MELD v1.0.2) is pure Python and has no FFI; its hot path is the
+ * arithmetic that graphtools and pygsp perform under
+ *     meld/meld.py:273   self.fit(X)            -> graphtools.Graph(...)   (kNN + alpha-decay kernel)
+ *     meld/meld.py:235   filter.filter(...)     -> meld/filter.py:39,56,59 (lmax + Chebyshev filter)
+ * Each entry point below names the reference interface (file:line, or the [UPSTREAM] library
+ * routine called from that line) whose work it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream;
+ *   - no hidden allocation, no global state besides the last-error string (thread local);
+ *   - return value: 0 = ok, <0 = error (MELD_ERR_*), message via meld_last_error();
+ *   - N, nnz counts are int64_t; column indices int32 (N < 2^31); values are IEEE fp64 wherever
+ *     the reference computes in fp64.  fp32 appears only in the candidate search, whose result
+ *     is re-evaluated exactly in fp64 before it is used.
+ */
+#ifndef MELD_HIP_H
+#define MELD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MELD_OK 0
+#define MELD_ERR_INVALID (-1)     /* bad argument */
+#define MELD_ERR_UNSUPPORTED (-2) /* size outside what the kernels are instantiated for */
+#define MELD_ERR_HIP (-3)         /* a HIP runtime call failed */
+
+typedef void* meld_stream_t;
+
+/* ---- library info ------------------------------------------------------------------------- */
+int meld_abi_version(void);
+const char* meld_last_error(void);
+/* hipGetDeviceCount-style probe: number of visible devices, or <0 */
+int meld_device_count(void);
+
+/* ---- kNN candidate search (replaces [UPSTREAM graphtools kNNGraph.build_kernel_to_data ->
+ *      sklearn NearestNeighbors.kneighbors], reached from meld/meld.py:273) ------------------ */
+
+/* Geometry of the search kernel, so that the caller can size its buffers. */
+int meld_knn_padded_dim(int d);     /* KP: augmented (d+2) dimension rounded up to an instantiated size; <0 if d unsupported */
+int meld_knn_tile_refs(void);       /* TS: reference points per LDS tile (reference array is padded to a multiple) */
+int meld_knn_block_queries(void);   /* BQ: queries per workgroup (query arrays are padded to a multiple) */
+int meld_knn_row_capacity(int ksel);/* CAP: row stride of the candidate buffers for a given ksel; <0 if unsupported */
+
+/* column sums of X[N,d] (fp64) -> sums[d] (zeroed by the call).  Used for centring. */
+int meld_col_sums_f64(const double* X, int64_t N, int d, double* sums, meld_stream_t stream);
+
+/* Build the fp32 operands of the distance GEMM from fp64 data (centred by `mean[d]`):
+ *   refs:    tile-major augmented reference form  Rt[n_tiles][KP/2][TS][2]  of  [-2x, 1, |x|^2, 0..]
+ *            rows >= N are filled so that their distance is huge; norm2[N] = |x|^2 (fp32),
+ *            norm2_max[1] = max_i norm2[i] (atomic max; must be zeroed by the caller);
+ *   queries: row-major augmented query form  Q[q_pad][KP]  of  [x, |x|^2, 1, 0..]  for rows
+ *            q_begin .. q_begin+q_count (rows beyond q_count replicate the last valid row). */
+int meld_knn_prepare_refs(const double* X, int64_t N, int d, const double* mean, int KP, float* Rt,
+                          float* norm2, float* norm2_max, meld_stream_t stream);
+int meld_knn_prepare_queries(const double* X, int64_t N, int d, const double* mean, int KP,
+                             int64_t q_begin, int64_t q_count, float* Q, meld_stream_t stream);
+
+/* Brute-force search on the matrix cores: for each of the q_count queries in Q, the ksel
+ * references with the smallest fp32 squared distance (self included).  Output rows have stride
+ * CAP = meld_knn_row_capacity(ksel); the first min(cand_cnt, ksel) entries of a row are valid and
+ * sorted by (d2, idx) ascending.  Buffers must hold q_pad = roundup(q_count, BQ) rows. */
+int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_t q_count, int ksel,
+                  int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
+
+/* ---- exact re-evaluation + alpha-decay kernel (replaces [UPSTREAM graphtools
+ *      kNNGraph.build_kernel_to_data, "affinities" block]) ---------------------------------- */
+
+/* For each query row: exact fp64 distances to its candidates, bandwidth bw = (knn+1)-th smallest
+ * (self counted), kernel value v = exp(-(d/bw)^decay), kept iff v >= thresh.  A row whose candidate
+ * list cannot be proven to contain every reference with v >= thresh ("completeness")
+ * is appended to flag_rows (its keep_cnt is set to 0) and must go through meld_knn_radius_exact.
+ *   cand_val[q_count][ksel] : kernel value or 0
+ *   keep_cnt[q_count]       : number of kept OFF-DIAGONAL entries (0 for flagged rows)
+ *   n_flag[1]               : atomic counter, zeroed by the caller */
+int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
+                    const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
+                    int knn, double decay, double thresh, const float* norm2_max, double* bw,
+                    double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
+                    meld_stream_t stream);
+
+/* Exact fp64 radius search for the flagged rows (the analogue of graphtools' re-search /
+ * radius_neighbors fallback).  mode 0: fb_cnt[f] = number of off-diagonal references with
+ * v >= thresh, and err_flag[0] |= 1 if the row's bandwidth cannot be confirmed;
+ * mode 1: write (column, value) at fb_off[f] + running cursor (fb_cursor[f], zeroed by caller). */
+int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, const int32_t* flag_rows,
+                          int32_t n_flag, const double* bw, int knn, double decay, double thresh,
+                          int mode, int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor,
+                          int32_t* fb_col, double* fb_val, int32_t* err_flag, meld_stream_t stream);
+
+/* ---- symmetrise / anisotropy / Laplacian pieces (replaces [UPSTREAM graphtools
+ *      BaseGraph.symmetrize_kernel, apply_anisotropy, PyGSPGraph._build_weight_from_kernel;
+ *      pygsp Graph.compute_laplacian]) ------------------------------------------------------- */
+
+/* exclusive prefix sum int32 -> int64 (out has n+1 entries; out[n] = total) */
+size_t meld_scan_temp_bytes(int64_t n);
+int meld_exclusive_scan_i32_i64(const int32_t* in, int64_t* out, int64_t n, void* temp, size_t temp_bytes,
+                                meld_stream_t stream);
+
+/* Emit the directed off-diagonal kernel entries as COO, twice: (i,j,v/2) into slot e and the
+ * transposed (j,i,v/2) into slot M + e, keys = (row << 32) | col.  keep_off = exclusive scan of
+ * keep_cnt; flagged rows take their entries from the fallback arrays at fb_base + fb_off[f]. */
+int meld_coo_emit(int64_t q_begin, int64_t q_count, const int32_t* cand_idx, const double* cand_val,
+                  const int32_t* cand_cnt, int ksel, const int64_t* keep_off, const int32_t* flag_rows,
+                  int32_t n_flag, const int64_t* fb_off, const int32_t* fb_col, const double* fb_val,
+                  int64_t fb_base, int64_t M, uint64_t* keys, double* vals, meld_stream_t stream);
+
+/* radix sort of (u64 key, f64 value) pairs on bits [0, end_bit) */
+size_t meld_sort_temp_bytes(int64_t n);
+int meld_sort_pairs_u64_f64(const uint64_t* keys_in, uint64_t* keys_out, const double* vals_in,
+                            double* vals_out, int64_t n, int end_bit, void* temp, size_t temp_bytes,
+                            meld_stream_t stream);
+
+/* Sum runs of equal keys (K + K^T): unique keys/values and their count. */
+size_t meld_merge_temp_bytes(int64_t n);
+int meld_coo_merge(const uint64_t* keys_sorted, const double* vals_sorted, int64_t n, uint64_t* ukeys,
+                   double* uvals, int64_t* n_unique, void* temp, size_t temp_bytes, meld_stream_t stream);
+
+/* keys of rows [row_begin, row_begin + n_rows) -> CSR: rowptr[n_rows+1] (int64), col[nnz] int32 */
+int meld_csr_from_keys(const uint64_t* ukeys, int64_t nnz, int64_t row_begin, int64_t n_rows,
+                       int64_t* rowptr, int32_t* col, meld_stream_t stream);
+
+/* ksum[i] = diag + sum_j val[i,j]   (row sums of the symmetrised kernel; diag = K_ii = 1) */
+int meld_csr_row_sums(const int64_t* rowptr, const double* val, int64_t n_rows, double diag,
+                      double* out, meld_stream_t stream);
+/* W_ij = K_ij / (ksum_i * ksum_j)^anisotropy, in place; ksum_all is indexed by global column,
+ * ksum_row_offset = global index of local row 0. */
+int meld_csr_anisotropy(const int64_t* rowptr, const int32_t* col, double* val, int64_t n_rows,
+                        const double* ksum_all, int64_t ksum_row_offset, double anisotropy,
+                        meld_stream_t stream);
+
+/* ---- Laplacian operator: lmax and the Chebyshev recurrence (replaces [UPSTREAM pygsp
+ *      Graph.estimate_lmax] at meld/filter.py:39 and [UPSTREAM pygsp
+ *      filters.approximations.cheby_op] at meld/filter.py:59) ------------------------------- */
+
+/* One step of the three-term recurrence on local rows [0, n_rows) of L = diag(dw) - W:
+ *     y      = alpha * (dw .* x_loc - W x_full) + beta * x_loc + gamma * z
+ *     r     += coef * y                      (if r != NULL)
+ *     dots   = per-slot partial sums of [ <y, x_loc>, <y, y> ]   (if dots != NULL; p == 1 only;
+ *              dots has 2 * meld_spmm_dot_slots() entries: slot-major per quantity; the caller
+ *              sums the slots.  Used by the Lanczos lmax estimate.)
+ * x_full is the full-length gathered vector ([n_cols, p] row-major), x_loc = x_full + x_row_offset*p,
+ * z, y, r are local ([n_rows, p]); y may alias z.  z may be NULL when gamma == 0.
+ * nnz_hint (total nonzeros of the local rows, or 0) only sizes the LDS staging area.
+ *   T1 = (L s - a2 s)/a1          : alpha = 1/a1, beta = -a2/a1, gamma = 0
+ *   Tk = (2/a1)(L - a2) T - Told  : alpha = 2/a1, beta = -2 a2/a1, gamma = -1  */
+int meld_spmm_dot_slots(void);
+int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw,
+                    int64_t n_rows, int64_t nnz_hint, int p, const double* x_full, int64_t x_row_offset,
+                    const double* z, double* y, double* r, double alpha, double beta, double gamma,
+                    double coef, double* dots, meld_stream_t stream);
+
+/* r = a * x  (n doubles) -- initialises r = c0/2 * T0 */
+int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream);
+/* y = a * x + b * y  (n doubles) -- Lanczos vector update */
+int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, meld_stream_t stream);
+
+/* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
+/* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */
+int meld_normalize_rows_l1(const double* in, double* out, int64_t n_rows, int p, meld_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELD_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmeld_hip.so (the C-ABI declared in include/meld_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or fails to load,
+``get_lib()`` raises and every graph / filter operation fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmeld_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+_i32, _i64, _f64, _sz, _ptr = C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/meld_hip.h one to one
+SIGNATURES = {
+    "meld_abi_version": (_i32, []),
+    "meld_last_error": (C.c_char_p, []),
+    "meld_device_count": (_i32, []),
+    "meld_knn_padded_dim": (_i32, [_i32]),
+    "meld_knn_tile_refs": (_i32, []),
+    "meld_knn_block_queries": (_i32, []),
+    "meld_knn_row_capacity": (_i32, [_i32]),
+    "meld_col_sums_f64": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),
+    "meld_knn_prepare_refs": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn_prepare_queries": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _i64, _i64, _ptr, _ptr]),
+    "meld_knn_topk": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn_refine": (
+        _i32,
+        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _f64, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    ),
+    "meld_knn_radius_exact": (
+        _i32,
+        [_ptr, _i64, _i32, _i64, _ptr, _i32, _ptr, _i32, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    ),
+    "meld_scan_temp_bytes": (_sz, [_i64]),
+    "meld_exclusive_scan_i32_i64": (_i32, [_ptr, _ptr, _i64, _ptr, _sz, _ptr]),
+    "meld_coo_emit": (
+        _i32,
+        [_i64, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+    ),
+    "meld_sort_temp_bytes": (_sz, [_i64]),
+    "meld_sort_pairs_u64_f64": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _ptr, _sz, _ptr]),
+    "meld_merge_temp_bytes": (_sz, [_i64]),
+    "meld_coo_merge": (_i32, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "meld_csr_from_keys": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
+    "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),
+    "meld_csr_anisotropy": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr]),
+    "meld_spmm_dot_slots": (_i32, []),
+    "meld_cheby_step": (
+        _i32,
+        [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr],
+    ),
+    "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
+    "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr]),
+    "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
+}
+
+_lib = None
+
+
+class MeldHipError(RuntimeError):
+    """A libmeld_hip.so entry point returned a non-zero status."""
+
+
+def get_lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "meld_amd: {} not found. The MI355X HIP extension is mandatory (there is no CPU "
+            "fallback); build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python -m meld_amd.build`.".format(LIB_PATH)
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = get_lib().meld_last_error()
+        raise MeldHipError("{} failed with status {}: {}".format(what or "libmeld_hip call", status, (msg or b"").decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,57 @@
+// common.hpp -- shared helpers for libmeld_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/meld_hip.h"
+
+namespace meld {
+
+// thread-local last-error string, reported through meld_last_error()
+char* err_buf();
+void set_err(const char* fmt, ...);
+
+static inline hipStream_t S(meld_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// wave = 64 lanes on CDNA4; hard-coded on purpose (cdna_hip_programming.md section 1)
+constexpr int WAVE = 64;
+
+#define MELD_CHECK_ARG(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      meld::set_err(__VA_ARGS__);        \
+      return MELD_ERR_INVALID;           \
+    }                                    \
+  } while (0)
+
+#define MELD_LAUNCH_CHECK(name)                                               \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      meld::set_err("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+      return MELD_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+
+#define MELD_HIP_CALL(expr)                                                   \
+  do {                                                                        \
+    hipError_t e__ = (expr);                                                  \
+    if (e__ != hipSuccess) {                                                  \
+      meld::set_err("%s failed: %s", #expr, hipGetErrorString(e__));          \
+      return MELD_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace meld

@@ -1,0 +1,242 @@
+// refine.hip -- exact fp64 re-evaluation of the kNN candidates and the alpha-decay kernel.
+//
+// Replaces the "Calculating affinities" block of graphtools
+// ([UPSTREAM kNNGraph.build_kernel_to_data]: bandwidth = distances[:, knn], radius = bandwidth *
+// (-log thresh)^(1/decay), re-search of rows whose farthest neighbour is inside the radius,
+// K = exp(-(d/bw)^decay), K < thresh dropped), reached from reference meld/meld.py:273.
+//
+// Net semantics reproduced here (see oracle/meld_oracle.py::semantic_kernel_dense):
+//   bw_i  = (knn+1)-th smallest euclidean distance of row i, self counted, clipped to eps
+//   K_ij  = exp(-(d_ij / bw_i)^decay)  for every j with K_ij >= thresh
+//
+// Completeness proof per row (why a fixed-size candidate list is enough).  Let tau be the fp32
+// squared distance of the ksel-th (last) candidate and E a bound on |d2_fp32 - d2_exact| (fp32
+// FMA-chain bound, E = KP * 2^-21 * max_i |x~_i|^2).  Every reference that is NOT a candidate
+// has d2_fp32 >= tau, hence exact d2 >= tau - E.  If radius^2 + E <= tau, no reference inside
+// the radius (and therefore none of the knn+1 nearest, since radius >= bw) was missed, so bw
+// and the row of K computed from the candidates are exact.  Rows that fail the test are
+// flagged and recomputed by the exact fp64 sweep below -- graphtools' re-search fallback.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace meld {
+
+constexpr int RB_FALL = 8;  // flagged rows per workgroup in the exact sweep
+
+__device__ __forceinline__ double decay_kernel(double dist, double bw, double decay) {
+  double v = exp(-pow(dist / bw, decay));
+  if (v != v) v = 1.0;  // graphtools: NaN -> 1
+  return v;
+}
+
+// one wave per query row; lane c owns candidates c and c + 64
+__global__ __launch_bounds__(256) void refine_kernel(
+    const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
+    const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, int ksel, int cap, int knn,
+    double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
+    double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
+    int* __restrict__ flag_rows, int* __restrict__ n_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= q_count) return;
+  const int64_t gi = q_begin + q;
+  const int n = min(cand_cnt[q], ksel);
+  const double* xi = X + gi * d;
+  const size_t ro = (size_t)q * cap;
+
+  double dist[2];
+  int idx[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = lane + 64 * e;
+    if (c < n) {
+      idx[e] = cand_idx[ro + c];
+      const double* xj = X + (int64_t)idx[e] * d;
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double t = xi[k] - xj[k];
+        s = fma(t, t, s);
+      }
+      dist[e] = sqrt(s);
+    } else {
+      idx[e] = 0x7fffffff;
+      dist[e] = INFINITY;
+    }
+  }
+
+  // rank of each candidate by (dist, idx); the entry with rank == knn is the bandwidth
+  int rk[2] = {0, 0};
+  const int ne = (n > 64) ? 2 : 1;
+  for (int e2 = 0; e2 < ne; ++e2) {
+    const int lim = min(64, n - 64 * e2);
+    for (int l2 = 0; l2 < lim; ++l2) {
+      const double de = __shfl(dist[e2], l2, 64);
+      const int ie = __shfl(idx[e2], l2, 64);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) rk[e] += (de < dist[e] || (de == dist[e] && ie < idx[e])) ? 1 : 0;
+    }
+  }
+  double bw = 0.0;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned long long b = __ballot((lane + 64 * e) < n && rk[e] == knn);
+    if (b) bw = __shfl(dist[e], __ffsll((long long)b) - 1, 64);
+  }
+  bw = fmax(bw, DBL_EPSILON);
+
+  // completeness test in squared-distance space
+  const double radius = bw * radius_factor;
+  const double E = err_coef * (double)norm2_max[0];
+  bool complete = true;
+  if (cand_cnt[q] >= ksel) {
+    const double tau = (double)cand_d2[ro + ksel - 1];
+    complete = (radius * radius + E <= tau);
+  }
+  if (n <= knn) complete = false;  // cannot even define the bandwidth from this list
+
+  int kept = 0;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int c = lane + 64 * e;
+    double v = 0.0;
+    if (c < n && complete) {
+      v = decay_kernel(dist[e], bw, decay);
+      if (v < thresh || (int64_t)idx[e] == gi) v = 0.0;  // diagonal handled analytically (K_ii = 1)
+    }
+    if (c < ksel) cand_val[(size_t)q * ksel + c] = v;
+    kept += __popcll(__ballot(v > 0.0));
+  }
+  if (lane == 0) {
+    bw_out[q] = bw;
+    keep_cnt[q] = complete ? kept : 0;
+    if (!complete) {
+      const int pos = atomicAdd(n_flag, 1);
+      flag_rows[pos] = (int)q;
+    }
+  }
+}
+
+// Exact fp64 sweep for flagged rows: RB_FALL rows per workgroup, every thread walks a strided
+// subset of all N references.  mode 0 counts, mode 1 fills.
+__global__ __launch_bounds__(256) void radius_exact_kernel(
+    const double* __restrict__ X, int64_t N, int d, int64_t q_begin, const int* __restrict__ flag_rows,
+    int n_flag, const double* __restrict__ bw_all, int knn, double decay, double thresh, int mode,
+    int* __restrict__ fb_cnt, const int64_t* __restrict__ fb_off, int* __restrict__ fb_cursor,
+    int* __restrict__ fb_col, double* __restrict__ fb_val, int* __restrict__ err_flag) {
+  extern __shared__ double xq[];  // [RB_FALL][d]
+  __shared__ int s_cnt[RB_FALL];
+  __shared__ int s_lt[RB_FALL];
+  const int f0 = blockIdx.x * RB_FALL;
+  const int nf = min(RB_FALL, n_flag - f0);
+  int64_t gi[RB_FALL];
+  double bw[RB_FALL];
+#pragma unroll
+  for (int f = 0; f < RB_FALL; ++f) {
+    const int q = flag_rows[f0 + (f < nf ? f : 0)];
+    gi[f] = q_begin + q;
+    bw[f] = bw_all[q];
+  }
+  for (int u = threadIdx.x; u < RB_FALL * d; u += blockDim.x) {
+    const int f = u / d, k = u % d;
+    xq[u] = X[gi[f] * d + k];
+  }
+  if (threadIdx.x < RB_FALL) {
+    s_cnt[threadIdx.x] = 0;
+    s_lt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+
+  int cnt[RB_FALL], lt[RB_FALL];
+#pragma unroll
+  for (int f = 0; f < RB_FALL; ++f) cnt[f] = lt[f] = 0;
+
+  for (int64_t ref = threadIdx.x; ref < N; ref += blockDim.x) {
+    const double* xr = X + ref * d;
+    double s[RB_FALL];
+#pragma unroll
+    for (int f = 0; f < RB_FALL; ++f) s[f] = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double xv = xr[k];
+#pragma unroll
+      for (int f = 0; f < RB_FALL; ++f) {
+        const double t = xq[f * d + k] - xv;
+        s[f] = fma(t, t, s[f]);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < RB_FALL; ++f) {
+      if (f < nf) {
+        const double dist = sqrt(s[f]);
+        if (dist < bw[f]) lt[f]++;
+        const double v = decay_kernel(dist, bw[f], decay);
+        if (v >= thresh && ref != gi[f]) {
+          if (mode == 0) {
+            cnt[f]++;
+          } else {
+            const int pos = atomicAdd(&fb_cursor[f0 + f], 1);
+            fb_col[fb_off[f0 + f] + pos] = (int)ref;
+            fb_val[fb_off[f0 + f] + pos] = v;
+          }
+        }
+      }
+    }
+  }
+  if (mode == 0) {
+#pragma unroll
+    for (int f = 0; f < RB_FALL; ++f) {
+      if (cnt[f]) atomicAdd(&s_cnt[f], cnt[f]);
+      if (lt[f]) atomicAdd(&s_lt[f], lt[f]);
+    }
+    __syncthreads();
+    if (threadIdx.x < nf) {
+      fb_cnt[f0 + threadIdx.x] = s_cnt[threadIdx.x];
+      // bw is the (knn+1)-th smallest distance iff at most knn references are strictly closer
+      if (s_lt[threadIdx.x] > knn) atomicOr(err_flag, 1);
+    }
+  }
+}
+
+}  // namespace meld
+
+using namespace meld;
+
+extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
+                               const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
+                               int knn, double decay, double thresh, const float* norm2_max, double* bw,
+                               double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
+                               meld_stream_t stream) {
+  MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
+                 "meld_knn_refine: null pointer");
+  MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N && d > 0, "meld_knn_refine: bad sizes");
+  MELD_CHECK_ARG(ksel >= 1 && ksel <= 128, "meld_knn_refine: ksel=%d outside [1,128]", ksel);
+  MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
+  const int cap = meld_knn_row_capacity(ksel);
+  if (cap < 0) return cap;
+  const int KP = meld_knn_padded_dim(d);
+  if (KP < 0) return KP;
+  const double radius_factor = pow(-log(thresh), 1.0 / decay);
+  const double err_coef = (double)KP * ldexp(1.0, -21);
+  hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
+                     q_count, cand_idx, cand_d2, cand_cnt, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
+                     err_coef, bw, cand_val, keep_cnt, flag_rows, n_flag);
+  MELD_LAUNCH_CHECK("refine_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, const int32_t* flag_rows,
+                                     int32_t n_flag, const double* bw, int knn, double decay, double thresh, int mode,
+                                     int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor, int32_t* fb_col,
+                                     double* fb_val, int32_t* err_flag, meld_stream_t stream) {
+  if (n_flag == 0) return MELD_OK;
+  MELD_CHECK_ARG(X && flag_rows && bw && n_flag > 0 && N > 0 && d > 0, "meld_knn_radius_exact: bad arguments");
+  MELD_CHECK_ARG(mode == 0 ? (fb_cnt && err_flag) : (fb_off && fb_cursor && fb_col && fb_val),
+                 "meld_knn_radius_exact: missing output for mode %d", mode);
+  const size_t lds = sizeof(double) * RB_FALL * d;
+  hipLaunchKernelGGL(radius_exact_kernel, dim3((unsigned)ceil_div(n_flag, RB_FALL)), dim3(256), lds, S(stream), X, N,
+                     d, q_begin, flag_rows, n_flag, bw, knn, decay, thresh, mode, fb_cnt, fb_off, fb_cursor, fb_col,
+                     fb_val, err_flag);
+  MELD_LAUNCH_CHECK("radius_exact_kernel");
+  return MELD_OK;
+}

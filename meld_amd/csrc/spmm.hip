@@ -1,0 +1,275 @@
+// spmm.hip -- the graph-Laplacian operator: Chebyshev three-term recurrence step and helpers.
+//
+// Replaces [UPSTREAM pygsp filters.approximations.cheby_op] (called from reference
+// meld/filter.py:59) and supplies the matrix-vector product for the lmax estimate
+// ([UPSTREAM pygsp Graph.estimate_lmax], reference meld/filter.py:39).
+//
+// pygsp materialises factor = (2/a1)(L - a2 I) and runs  T_k = factor T_{k-1} - T_{k-2};
+// r += c_k T_k  as separate scipy passes (SpMM, subtract, scale, add: >= 5 vector passes plus a
+// second sparse matrix).  Here one kernel does
+//     y = alpha * (dw .* x - W x) + beta * x + gamma * z ;   r += coef * y
+// reading W (fp64 values + int32 columns) exactly once per step and never forming L or factor.
+//
+// Kernel shape ("CSR-stream"): a workgroup owns RB consecutive rows = one contiguous span of
+// the CSR value/column arrays.  All 256 threads stream that span with fully coalesced loads,
+// gather x[col] (16 B per nonzero for p = 2), and stage the products in LDS; then TPR = 256/RB
+// lanes per row sum the row's LDS segment and a 2-step shuffle finishes the row.  Rows of any
+// length work: the span is processed in LDS-sized chunks with the row accumulators kept in
+// registers.  HBM-bound: 12 B/nonzero streamed + vector traffic (roofline section).
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace meld {
+
+constexpr int DOT_SLOTS = 64;
+
+template <int P>
+struct Vec {
+  double v[P];
+};
+
+template <int P>
+__device__ __forceinline__ Vec<P> load_row(const double* __restrict__ base, int64_t row, int ld, int colofs) {
+  Vec<P> out;
+  const double* p = base + row * ld + colofs;
+  if constexpr (P == 1) {
+    out.v[0] = p[0];
+  } else {
+#pragma unroll
+    for (int c = 0; c < P; c += 2) {
+      const double2 t = *reinterpret_cast<const double2*>(p + c);
+      out.v[c] = t.x;
+      out.v[c + 1] = t.y;
+    }
+  }
+  return out;
+}
+
+template <int P>
+__device__ __forceinline__ void store_row(double* __restrict__ base, int64_t row, int ld, int colofs,
+                                          const Vec<P>& val) {
+  double* p = base + row * ld + colofs;
+  if constexpr (P == 1) {
+    p[0] = val.v[0];
+  } else {
+#pragma unroll
+    for (int c = 0; c < P; c += 2) *reinterpret_cast<double2*>(p + c) = make_double2(val.v[c], val.v[c + 1]);
+  }
+}
+
+template <int P, int RB>
+__global__ __launch_bounds__(256) void cheby_step_kernel(
+    const int64_t* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+    const double* __restrict__ dw, int64_t n_rows, int ld, int colofs, const double* __restrict__ x_full,
+    int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
+    double coef, double* __restrict__ dots, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) double prod[];  // [chunk][P]
+  __shared__ int64_t s_rowptr[RB + 1];
+  __shared__ double s_dot[2][4];
+  constexpr int TPR = 256 / RB;
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  if (tid <= RB) s_rowptr[tid] = rowptr[min(row0 + tid, n_rows)];
+
+  const int rr = tid / TPR;
+  const int sub = tid % TPR;
+  const int64_t row = row0 + rr;
+  const bool own = (row < n_rows) && (sub == 0);
+
+  // epilogue operands: issue the loads now, consume them after the reduction
+  Vec<P> xl, zl, rl;
+  double dwi = 0.0;
+#pragma unroll
+  for (int c = 0; c < P; ++c) xl.v[c] = zl.v[c] = rl.v[c] = 0.0;
+  if (own) {
+    xl = load_row<P>(x_full, x_row_offset + row, ld, colofs);
+    dwi = dw[row];
+    if (gamma != 0.0) zl = load_row<P>(z, row, ld, colofs);
+    if (r != nullptr) rl = load_row<P>(r, row, ld, colofs);
+  }
+  __syncthreads();
+
+  const int64_t e0 = s_rowptr[0];
+  const int64_t e1 = s_rowptr[RB];
+  const int64_t rs = s_rowptr[rr];
+  const int64_t re = s_rowptr[rr + 1];
+  Vec<P> acc;
+#pragma unroll
+  for (int c = 0; c < P; ++c) acc.v[c] = 0.0;
+
+  for (int64_t cs = e0; cs < e1; cs += chunk) {
+    const int64_t ce = min(cs + (int64_t)chunk, e1);
+    // stream the span: 4 independent (value, column, gather) chains per thread per trip
+    for (int64_t eb = cs + tid; eb < ce; eb += 4 * 256) {
+      double v[4];
+      int j[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t e = eb + u * 256;
+        const bool ok = e < ce;
+        v[u] = ok ? val[e] : 0.0;
+        j[u] = ok ? col[e] : 0;
+      }
+      Vec<P> xj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xj[u] = load_row<P>(x_full, j[u], ld, colofs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t e = eb + u * 256;
+        if (e < ce) {
+          Vec<P> pr;
+#pragma unroll
+          for (int c = 0; c < P; ++c) pr.v[c] = v[u] * xj[u].v[c];
+          store_row<P>(prod, e - cs, P, 0, pr);
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t lo = max(rs, cs), hi = min(re, ce);
+    for (int64_t e = lo + sub; e < hi; e += TPR) {
+      const Vec<P> t = load_row<P>(prod, e - cs, P, 0);
+#pragma unroll
+      for (int c = 0; c < P; ++c) acc.v[c] += t.v[c];
+    }
+    if (ce < e1) __syncthreads();
+  }
+
+#pragma unroll
+  for (int off = 1; off < TPR; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < P; ++c) acc.v[c] += __shfl_xor(acc.v[c], off, 64);
+  }
+
+  double d_yx = 0.0, d_yy = 0.0;
+  if (own) {
+    Vec<P> yv;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const double lx = dwi * xl.v[c] - acc.v[c];  // (L x)_i
+      yv.v[c] = alpha * lx + beta * xl.v[c] + gamma * zl.v[c];
+      rl.v[c] += coef * yv.v[c];
+      d_yx += yv.v[c] * xl.v[c];
+      d_yy += yv.v[c] * yv.v[c];
+    }
+    store_row<P>(y, row, ld, colofs, yv);
+    if (r != nullptr) store_row<P>(r, row, ld, colofs, rl);
+  }
+  if (dots != nullptr) {
+    d_yx = wave_sum(d_yx);
+    d_yy = wave_sum(d_yy);
+    if ((tid & 63) == 0) {
+      s_dot[0][tid >> 6] = d_yx;
+      s_dot[1][tid >> 6] = d_yy;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      const double s = s_dot[tid][0] + s_dot[tid][1] + s_dot[tid][2] + s_dot[tid][3];
+      atomicAdd(&dots[tid * DOT_SLOTS + (blockIdx.x % DOT_SLOTS)], s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ x, double a, double* __restrict__ r,
+                                                    int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    r[i] = a * x[i];
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
+                                                    double* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(256) void normalize_rows_l1_kernel(const double* __restrict__ in,
+                                                                double* __restrict__ out, int64_t n_rows, int p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  double s = 0.0;
+  for (int c = 0; c < p; ++c) s += fabs(in[i * p + c]);
+  if (s == 0.0) s = 1.0;
+  for (int c = 0; c < p; ++c) out[i * p + c] = in[i * p + c] / s;
+}
+
+template <int P, int RB>
+static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows,
+                        int ld, int colofs, const double* x_full, int64_t x_row_offset, const double* z, double* y,
+                        double* r, double alpha, double beta, double gamma, double coef, double* dots, int chunk,
+                        hipStream_t st) {
+  const unsigned grid = (unsigned)ceil_div(n_rows, RB);
+  const size_t lds = sizeof(double) * (size_t)chunk * P;
+  hipLaunchKernelGGL((cheby_step_kernel<P, RB>), dim3(grid), dim3(256), lds, st, rowptr, col, val, dw, n_rows, ld,
+                     colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma, coef, dots, chunk);
+  return 0;
+}
+
+}  // namespace meld
+
+using namespace meld;
+
+extern "C" int meld_spmm_dot_slots(void) { return DOT_SLOTS; }
+
+extern "C" int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw,
+                               int64_t n_rows, int64_t nnz_hint, int p, const double* x_full, int64_t x_row_offset,
+                               const double* z, double* y, double* r, double alpha, double beta, double gamma,
+                               double coef, double* dots, meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && dw && x_full && y && n_rows > 0 && p >= 1, "meld_cheby_step: bad arguments");
+  MELD_CHECK_ARG(gamma == 0.0 || z != nullptr, "meld_cheby_step: z is required when gamma != 0");
+  MELD_CHECK_ARG(dots == nullptr || p == 1, "meld_cheby_step: dots are only produced for p == 1");
+  hipStream_t st = S(stream);
+  if (dots) MELD_HIP_CALL(hipMemsetAsync(dots, 0, sizeof(double) * 2 * DOT_SLOTS, st));
+  constexpr int RB = 32;
+  // LDS chunk: ~1.3x the mean span of RB rows, multiple of 256, within [512, 3072] entries
+  const double mean_span = (nnz_hint > 0) ? (double)nnz_hint / (double)n_rows * RB : 1024.0;
+  auto pick_chunk = [&](int P) {
+    int64_t c = (int64_t)(mean_span * 1.3) / 256 * 256 + 256;
+    const int64_t cmax = (48 * 1024) / (8 * P) / 256 * 256;
+    return (int)std::max<int64_t>(512, std::min<int64_t>(c, cmax));
+  };
+  int colofs = 0;
+  if (p % 2 == 0) {
+    while (colofs + 4 <= p) {
+      launch_cheby<4, RB>(rowptr, col, val, dw, n_rows, p, colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma,
+                          coef, nullptr, pick_chunk(4), st);
+      colofs += 4;
+    }
+    if (colofs + 2 <= p) {
+      launch_cheby<2, RB>(rowptr, col, val, dw, n_rows, p, colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma,
+                          coef, nullptr, pick_chunk(2), st);
+      colofs += 2;
+    }
+  } else {
+    for (; colofs < p; ++colofs)
+      launch_cheby<1, RB>(rowptr, col, val, dw, n_rows, p, colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma,
+                          coef, dots, pick_chunk(1), st);
+  }
+  MELD_LAUNCH_CHECK("cheby_step_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream) {
+  MELD_CHECK_ARG(x && r && n >= 0, "meld_scale_f64: bad arguments");
+  if (n == 0) return MELD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(n, 256));
+  hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(256), 0, S(stream), x, a, r, n);
+  MELD_LAUNCH_CHECK("scale_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, meld_stream_t stream) {
+  MELD_CHECK_ARG(x && y && n >= 0, "meld_axpby_f64: bad arguments");
+  if (n == 0) return MELD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(n, 256));
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), a, x, b, y, n);
+  MELD_LAUNCH_CHECK("axpby_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_normalize_rows_l1(const double* in, double* out, int64_t n_rows, int p, meld_stream_t stream) {
+  MELD_CHECK_ARG(in && out && n_rows > 0 && p > 0, "meld_normalize_rows_l1: bad arguments");
+  hipLaunchKernelGGL(normalize_rows_l1_kernel, dim3((unsigned)ceil_div(n_rows, 256)), dim3(256), 0, S(stream), in, out,
+                     n_rows, p);
+  MELD_LAUNCH_CHECK("normalize_rows_l1_kernel");
+  return MELD_OK;
+}

@@ -1,0 +1,177 @@
+"""Validated-attribute estimator base: the slice of ``graphtools.estimator.GraphEstimator`` that
+``meld.MELD`` inherits (reference ``meld/meld.py:9,13,42-92,117-118``; [UPSTREAM graphtools 1.5.x
+``estimator.attribute`` / ``GraphEstimator``]), re-stated for a device-resident graph.
+
+Behaviour kept:
+  * ``attribute(name, default, on_set=validators)`` properties that validate on assignment and
+    raise ``ValueError`` with graphtools' messages (pinned by reference ``test/test_meld.py:100-105``);
+  * graph parameters ``knn=5, decay=40, n_pca=100, thresh=1e-4, distance="euclidean", n_jobs,
+    random_state, verbose`` with their defaults;
+  * ``fit(X)`` adopts a prebuilt graph or builds one; refitting on different data rebuilds;
+  * ``set_params`` of a graph parameter drops the graph (reference ``test/test_meld.py:90-93``).
+"""
+from __future__ import annotations
+
+import numbers
+from functools import partial
+
+import numpy as np
+
+__all__ = ["attribute", "GraphEstimator", "check_positive", "check_int", "check_in", "check_if_not"]
+
+
+def check_positive(**params):
+    for p in params:
+        if not isinstance(params[p], numbers.Number) or params[p] <= 0:
+            raise ValueError("Expected {} > 0, got {}".format(p, params[p]))
+
+
+def check_int(**params):
+    for p in params:
+        if not isinstance(params[p], numbers.Integral):
+            raise ValueError("Expected {} integer, got {}".format(p, params[p]))
+
+
+def check_in(choices, **params):
+    for p in params:
+        if params[p] not in choices:
+            raise ValueError("{} value {} not recognized. Choose from {}".format(p, params[p], choices))
+
+
+def check_if_not(x, *checks, **params):
+    for p in params:
+        if params[p] is not x and params[p] != x:
+            for chk in checks:
+                chk(**{p: params[p]})
+
+
+def attribute(attr, default=None, doc=None, on_set=None):
+    """Property stored as ``_<attr>`` whose setter runs the ``on_set`` validators."""
+    validators = [] if on_set is None else ([on_set] if callable(on_set) else list(on_set))
+
+    def fget(self):
+        return getattr(self, "_" + attr, default)
+
+    def fset(self, value):
+        for fn in validators:
+            fn(**{attr: value})
+        setattr(self, "_" + attr, value)
+
+    return property(fget=fget, fset=fset, doc=doc)
+
+
+_GRAPH_PARAMS = ("knn", "decay", "n_pca", "thresh", "distance", "anisotropy", "n_landmark")
+_PASSIVE_PARAMS = ("n_jobs", "random_state", "verbose")
+
+
+class GraphEstimator(object):
+    """Estimator that owns a graph built from data."""
+
+    X = attribute("X", doc="Stored input data")
+    n_pca = attribute("n_pca", default=100, on_set=partial(check_if_not, None, check_positive, check_int))
+    random_state = attribute("random_state")
+    knn = attribute("knn", default=5, on_set=[check_positive, check_int])
+    decay = attribute("decay", default=40, on_set=partial(check_if_not, None, check_positive))
+    distance = attribute("distance", default="euclidean", on_set=partial(check_in, ["euclidean"]))
+    n_jobs = attribute("n_jobs", default=1, on_set=check_int)
+    verbose = attribute("verbose", default=0)
+    thresh = attribute("thresh", default=1e-4, on_set=partial(check_if_not, 0, check_positive))
+    n_landmark = attribute("n_landmark", on_set=partial(check_if_not, None, check_positive, check_int))
+
+    def __init__(
+        self,
+        knn=5,
+        decay=40,
+        n_pca=100,
+        n_landmark=None,
+        random_state=None,
+        verbose=0,
+        n_jobs=1,
+        distance="euclidean",
+        thresh=1e-4,
+        anisotropy=0,
+        **kwargs
+    ):
+        if verbose is True:
+            verbose = 1
+        elif verbose is False:
+            verbose = 0
+        self.n_pca = n_pca
+        self.n_landmark = n_landmark
+        self.random_state = random_state
+        self.knn = knn
+        self.decay = decay
+        self.distance = distance
+        self.n_jobs = n_jobs
+        self.verbose = verbose
+        self.thresh = thresh
+        self.anisotropy = anisotropy
+        self.kwargs = kwargs
+        self._graph = None
+
+    # graph property: dropping the graph resets everything derived from it
+    @property
+    def graph(self):
+        return getattr(self, "_graph", None)
+
+    @graph.setter
+    def graph(self, G):
+        self._graph = G
+        if G is None:
+            self._reset_graph()
+
+    def _reset_graph(self):  # overridden by subclasses
+        pass
+
+    def set_params(self, **params):
+        for p, v in params.items():
+            if p in _GRAPH_PARAMS:
+                if getattr(self, p) != v:
+                    setattr(self, p, v)
+                    self.graph = None
+            elif p in _PASSIVE_PARAMS:
+                setattr(self, p, v)
+            elif p in self.kwargs or p in ("ksel",):
+                if self.kwargs.get(p) != v:
+                    self.kwargs[p] = v
+                    self.graph = None
+            else:
+                raise ValueError("Invalid parameter {} for estimator {}".format(p, type(self).__name__))
+        return self
+
+    def _log(self, msg):
+        if self.verbose:
+            print(msg, flush=True)
+
+    def fit(self, X, **kwargs):
+        """Build (or adopt) the graph.  ``X``: array-like [n_samples, n_features] (ndarray,
+        DataFrame, anything with ``.X`` like AnnData) or an already built ``DeviceGraph``."""
+        from . import graph as _graph
+
+        if isinstance(X, _graph.DeviceGraph):
+            self._log("Using precomputed graph and diffusion operator...")
+            self.X = None
+            self.graph = X
+            return self
+        if hasattr(X, "X") and not isinstance(X, np.ndarray):  # AnnData-like
+            X = X.X
+        if hasattr(X, "sparse") and hasattr(X.sparse, "to_dense"):
+            X = X.sparse.to_dense()
+        data = np.asarray(getattr(X, "values", X))
+        if hasattr(data, "toarray"):
+            data = data.toarray()
+        if data.ndim != 2:
+            raise ValueError("Expected a 2D data matrix, got shape {}".format(data.shape))
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if not np.all(np.isfinite(data)):
+            raise ValueError("Input data contains NaN or infinity")
+        if self.X is not None and (self.X.shape != data.shape or not np.array_equal(self.X, data)):
+            self.graph = None  # new data: rebuild
+        self.X = data
+        if self.graph is None:
+            self._log("Building graph on {} samples and {} features.".format(data.shape[0], data.shape[1]))
+            self.graph = self._build_graph(data, **kwargs)
+        return self
+
+    def _build_graph(self, data, **kwargs):
+        raise NotImplementedError

@@ -1,0 +1,327 @@
+"""Device-resident alpha-decay kNN graph: the MI355X replacement of ``graphtools.Graph``.
+
+The reference builds its graph with ``graphtools.Graph(X, knn, decay, thresh, anisotropy=1,
+use_pygsp=True, ...)`` (reference ``meld/meld.py:117-118,273``) and hands a PyGSP graph to
+``meld/filter.py``.  ``DeviceGraph`` offers the attributes that path touches -- ``N``
+(``meld/meld.py:209``), ``estimate_lmax()`` / ``lmax`` (``meld/filter.py:39,45``) -- plus host
+exports (``W``, ``K``, ``L``, ``dw``) for inspection and tests.  All arithmetic is done by the HIP
+kernels of ``libmeld_hip.so``; torch only owns the device memory and the stream.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+
+from ._lib import check, get_lib, ptr
+
+__all__ = ["DeviceGraph", "build_knn_graph", "default_ksel"]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def default_ksel(knn):
+    """Candidate-list length of the search kernel: ~4x the (knn+1) nearest, in [32, 128].
+    (graphtools searches 6*(knn+1) first [UPSTREAM search_multiplier]; rows that need more go
+    through the exact radius sweep exactly as graphtools re-searches them.)"""
+    k = 4 * (knn + 1)
+    k = ((k + 31) // 32) * 32
+    return int(min(128, max(32, k)))
+
+
+class _Timer:
+    """Per-stage wall times (host clock around a device sync); only active when asked for."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+        self.t = {}
+        self._t0 = None
+
+    def start(self):
+        if self.enabled:
+            torch.cuda.synchronize()
+            self._t0 = time.perf_counter()
+
+    def stop(self, name):
+        if self.enabled:
+            torch.cuda.synchronize()
+            self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - self._t0
+            self._t0 = time.perf_counter()
+
+
+class DeviceGraph:
+    """Symmetric weight matrix W (CSR, fp64 values, int32 columns, no diagonal) and degrees
+    ``dw = W 1`` resident in HBM; ``L = diag(dw) - W`` is applied on the fly, never stored.
+
+    Attributes mirror what callers of the PyGSP graph use: ``N``, ``lmax``, ``estimate_lmax()``,
+    and (host-side, lazily copied) ``W``, ``K``, ``L``, ``dw``.
+    """
+
+    def __init__(self, rowptr, col, val, dw, ksum=None, anisotropy=1.0, row_begin=0, n_total=None, info=None):
+        self.rowptr = rowptr  # int64 [n_rows + 1]
+        self.col = col  # int32 [nnz]
+        self.val = val  # fp64  [nnz]
+        self.dw_dev = dw  # fp64  [n_rows]
+        self.ksum = ksum  # fp64  [N] row sums of the symmetrised kernel (diag included)
+        self.anisotropy = float(anisotropy)
+        self.n_rows = int(rowptr.shape[0] - 1)
+        self.row_begin = int(row_begin)
+        self.N = int(n_total if n_total is not None else self.n_rows)
+        self.nnz = int(col.shape[0])
+        self.info = info or {}
+        self._lmax = None
+        self.lmax_info = {}
+
+    @classmethod
+    def from_scipy(cls, W, device="cuda"):
+        """Upload a symmetric, zero-diagonal scipy.sparse weight matrix (e.g. ``G.W`` of a graph
+        built elsewhere) -- the counterpart of handing a prebuilt graph to ``MELD.fit``
+        (reference ``meld/benchmark.py:194-195``)."""
+        from scipy import sparse
+
+        W = sparse.csr_matrix(W).astype(np.float64)
+        W.sort_indices()
+        if W.shape[0] != W.shape[1]:
+            raise ValueError("W must be square")
+        rowptr = torch.from_numpy(W.indptr.astype(np.int64)).to(device)
+        col = torch.from_numpy(W.indices.astype(np.int32)).to(device)
+        val = torch.from_numpy(W.data.astype(np.float64)).to(device)
+        dw = torch.from_numpy(np.ravel(W.sum(1)).astype(np.float64)).to(device)
+        return cls(rowptr, col, val, dw, ksum=None, anisotropy=0.0)
+
+    # -- pygsp-like surface -------------------------------------------------------------------
+    @property
+    def lmax(self):
+        if self._lmax is None:
+            self.estimate_lmax()
+        return self._lmax
+
+    @lmax.setter
+    def lmax(self, value):
+        self._lmax = None if value is None else float(value)
+
+    def estimate_lmax(self, recompute=False, tol=1e-7, max_iter=300):
+        """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
+        ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
+        tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos
+        recurrence on the device SpMV is run to ``tol``.  No-op when a value is already set
+        (same as pygsp), which is how parity tests inject a common lmax."""
+        if self._lmax is not None and not recompute:
+            return self._lmax
+        from .filter import lanczos_lmax
+
+        lam, info = lanczos_lmax(self, tol=tol, max_iter=max_iter)
+        self._lmax = 1.01 * lam
+        self.lmax_info = info
+        return self._lmax
+
+    # -- host exports (tests / inspection; not used by the hot path) -----------------------------
+    def _scipy(self, vals):
+        from scipy import sparse
+
+        return sparse.csr_matrix(
+            (vals, self.col.cpu().numpy(), self.rowptr.cpu().numpy()), shape=(self.n_rows, self.N)
+        )
+
+    @property
+    def W(self):
+        return self._scipy(self.val.cpu().numpy())
+
+    @property
+    def dw(self):
+        return self.dw_dev.cpu().numpy()
+
+    @property
+    def L(self):
+        from scipy import sparse
+
+        if self.n_rows != self.N:
+            raise ValueError("L is only defined for an unsharded graph")
+        return (sparse.diags(self.dw, 0) - self.W).tocsr()
+
+    @property
+    def K(self):
+        """Symmetrised, anisotropy-normalised kernel including its diagonal (graphtools' ``G.K``)."""
+        from scipy import sparse
+
+        if self.n_rows != self.N:
+            raise ValueError("K is only defined for an unsharded graph")
+        ks = self.ksum.cpu().numpy()
+        diag = 1.0 / (ks * ks) ** self.anisotropy
+        return (self.W + sparse.diags(diag, 0)).tocsr()
+
+
+def _scan_i32(lib, x, st):
+    n = x.shape[0]
+    out = torch.empty(n + 1, dtype=torch.int64, device=x.device)
+    tb = lib.meld_scan_temp_bytes(n)
+    tmp = torch.empty(tb, dtype=torch.uint8, device=x.device)
+    check(lib.meld_exclusive_scan_i32_i64(ptr(x), ptr(out), n, ptr(tmp), tb, st), "meld_exclusive_scan_i32_i64")
+    return out
+
+
+def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False):
+    """Data [N, d] -> DeviceGraph.  Rows A2-A5 of SURVEY.md section 8(a).
+
+    ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
+    distance GEMM with fused top-ksel, exact fp64 refinement + alpha-decay kernel, exact sweep for
+    rows whose candidate list is provably incomplete, COO emit + radix sort + merge = (K + K^T)/2,
+    anisotropy, degrees.
+    """
+    lib = get_lib()
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float64 and X.dim() == 2):
+        raise TypeError("build_knn_graph expects a CUDA float64 tensor [N, d]")
+    X = X.contiguous()
+    N, d = int(X.shape[0]), int(X.shape[1])
+    dev = X.device
+    st = _stream()
+    tm = _Timer(profile)
+
+    if N < 3:
+        raise ValueError("need at least 3 points to build a kNN graph, got {}".format(N))
+    if knn > N - 2:  # [UPSTREAM graphtools kNNGraph.__init__] clips (with a warning)
+        knn = N - 2
+    thresh = float(max(thresh, np.finfo(float).eps))  # [UPSTREAM] thresh floor
+    if ksel is None:
+        ksel = default_ksel(knn)
+    if ksel < knn + 2:
+        raise NotImplementedError(
+            "knn={} needs a candidate list of at least knn+2 entries but the search kernel holds at most 128".format(knn)
+        )
+    KP = lib.meld_knn_padded_dim(d)
+    if KP < 0:
+        check(KP, "meld_knn_padded_dim")
+    TS = lib.meld_knn_tile_refs()
+    BQ = lib.meld_knn_block_queries()
+    cap = lib.meld_knn_row_capacity(ksel)
+    if cap < 0:
+        check(cap, "meld_knn_row_capacity")
+
+    # ---- operands of the distance GEMM ---------------------------------------------------------
+    tm.start()
+    sums = torch.empty(d, dtype=torch.float64, device=dev)
+    check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
+    mean = sums / N
+    n_tiles = (N + TS - 1) // TS
+    Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
+    norm2 = torch.empty(N, dtype=torch.float32, device=dev)
+    nmax = torch.zeros(1, dtype=torch.float32, device=dev)
+    check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
+    q_pad = ((N + BQ - 1) // BQ) * BQ
+    Q = torch.empty(q_pad * KP, dtype=torch.float32, device=dev)
+    check(lib.meld_knn_prepare_queries(ptr(X), N, d, ptr(mean), KP, 0, N, ptr(Q), st), "meld_knn_prepare_queries")
+    tm.stop("prepare")
+
+    # ---- candidate search on the matrix cores -----------------------------------------------------
+    cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
+    cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
+    cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+    check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, N, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
+    tm.stop("knn_topk")
+    del Q, Rt
+
+    # ---- exact refinement + alpha-decay kernel ----------------------------------------------------
+    bw = torch.empty(N, dtype=torch.float64, device=dev)
+    cand_val = torch.empty(N * ksel, dtype=torch.float64, device=dev)
+    keep_cnt = torch.empty(N, dtype=torch.int32, device=dev)
+    flag_rows = torch.empty(N, dtype=torch.int32, device=dev)
+    n_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    nmax_used = nmax
+    if force_fallback:  # test hook: an infinite error bound flags every row
+        nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
+    check(
+        lib.meld_knn_refine(
+            ptr(X), N, d, 0, N, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, knn, float(decay), thresh,
+            ptr(nmax_used), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
+        ),
+        "meld_knn_refine",
+    )
+    keep_off = _scan_i32(lib, keep_cnt, st)
+    n_flag_h = int(n_flag.item())
+    m_main = int(keep_off[N].item())
+    tm.stop("refine")
+
+    # ---- exact sweep for rows the candidate list could not certify --------------------------------
+    fb_total = 0
+    fb_off = fb_col = fb_val = None
+    if n_flag_h > 0:
+        flag_rows = torch.sort(flag_rows[:n_flag_h]).values.contiguous()  # deterministic order
+        fb_cnt = torch.empty(n_flag_h, dtype=torch.int32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(
+            lib.meld_knn_radius_exact(
+                ptr(X), N, d, 0, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), thresh, 0,
+                ptr(fb_cnt), None, None, None, None, ptr(err), st,
+            ),
+            "meld_knn_radius_exact(count)",
+        )
+        fb_off = _scan_i32(lib, fb_cnt, st)
+        fb_total = int(fb_off[n_flag_h].item())
+        if int(err.item()) != 0:
+            raise NotImplementedError(
+                "degenerate neighbourhoods (more than {} references tie below the bandwidth of a row); "
+                "this data needs the dense exact graph".format(ksel)
+            )
+        fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
+        fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
+        cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)
+        check(
+            lib.meld_knn_radius_exact(
+                ptr(X), N, d, 0, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), thresh, 1,
+                None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,
+            ),
+            "meld_knn_radius_exact(fill)",
+        )
+    tm.stop("radius_exact")
+
+    # ---- (K + K^T)/2 as sorted CSR ---------------------------------------------------------------
+    M = m_main + fb_total
+    if M == 0:
+        raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
+    keys = torch.empty(2 * M, dtype=torch.int64, device=dev)
+    vals = torch.empty(2 * M, dtype=torch.float64, device=dev)
+    check(
+        lib.meld_coo_emit(
+            0, N, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, ptr(keep_off), ptr(flag_rows), n_flag_h,
+            ptr(fb_off), ptr(fb_col), ptr(fb_val), m_main, M, ptr(keys), ptr(vals), st,
+        ),
+        "meld_coo_emit",
+    )
+    del cand_idx, cand_d2, cand_val
+    keys2 = torch.empty_like(keys)
+    vals2 = torch.empty_like(vals)
+    tb = lib.meld_sort_temp_bytes(2 * M)
+    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    end_bit = 32 + max(1, int(N - 1).bit_length())
+    check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(keys2), ptr(vals), ptr(vals2), 2 * M, end_bit, ptr(tmp), tb, st), "meld_sort_pairs_u64_f64")
+    tb = lib.meld_merge_temp_bytes(2 * M)
+    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib.meld_coo_merge(ptr(keys2), ptr(vals2), 2 * M, ptr(keys), ptr(vals), ptr(n_unique), ptr(tmp), tb, st), "meld_coo_merge")
+    nnz = int(n_unique.item())
+    rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    check(lib.meld_csr_from_keys(ptr(keys), nnz, 0, N, ptr(rowptr), ptr(col), st), "meld_csr_from_keys")
+    val = vals[:nnz].clone()
+    del keys, keys2, vals, vals2, tmp
+    tm.stop("symmetrize")
+
+    # ---- anisotropy + degrees ---------------------------------------------------------------------
+    ksum = torch.empty(N, dtype=torch.float64, device=dev)
+    check(lib.meld_csr_row_sums(ptr(rowptr), ptr(val), N, 1.0, ptr(ksum), st), "meld_csr_row_sums")
+    check(lib.meld_csr_anisotropy(ptr(rowptr), ptr(col), ptr(val), N, ptr(ksum), 0, float(anisotropy), st), "meld_csr_anisotropy")
+    dw = torch.empty(N, dtype=torch.float64, device=dev)
+    check(lib.meld_csr_row_sums(ptr(rowptr), ptr(val), N, 0.0, ptr(dw), st), "meld_csr_row_sums")
+    tm.stop("anisotropy_degree")
+
+    info = dict(
+        N=N, d=d, knn=int(knn), ksel=int(ksel), KP=int(KP), n_flagged_rows=n_flag_h, nnz_directed=M, nnz=nnz,
+        mean_degree=nnz / N, stage_seconds=dict(tm.t),
+    )
+    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=info)
+    G.bandwidth = bw
+    return G

@@ -1,0 +1,209 @@
+"""``MELD`` estimator -- MI355X drop-in for ``meld.MELD`` (reference ``meld/meld.py:13-274``).
+
+Same constructor signature, defaults, validation messages, ``fit`` / ``transform`` /
+``fit_transform`` / ``set_params`` behaviour, attributes (``graph``, ``samples``,
+``sample_indicators``, ``sample_densities``, ``sample_labels_``) and output layout (DataFrame
+``[N, p]``, index = labels' index, columns = sorted unique labels).  The two hot loops run on the
+GPU: graph construction (``meld_amd.graph.build_knn_graph``) and the Chebyshev filter
+(``meld_amd.filter.filter``).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import numpy as np
+import pandas as pd
+
+from . import filter as _filter
+from . import utils
+from .estimator import GraphEstimator, attribute, check_in, check_int, check_positive
+
+__all__ = ["MELD"]
+
+_FILTER_PARAMS = ("beta", "offset", "order", "solver", "chebyshev_order", "lap_type", "filter")
+
+
+class MELD(GraphEstimator):
+    """MELD operator for filtering signals over a graph.
+
+    Parameters (reference ``meld/meld.py:16-40``)
+    ----------
+    beta : int, default 60 -- amount of smoothing
+    offset : float, default 0 -- shift of the filter in the (normalised) spectrum, in [0, 1]
+    order : int, default 1 -- falloff / squareness of the filter
+    filter : {'heat', 'laplacian'}, default 'heat'
+    solver : {'chebyshev', 'exact'}, default 'chebyshev'
+    chebyshev_order : int, default 50
+    lap_type : {'combinatorial', 'normalized'}, default 'combinatorial' (validated and stored;
+        like the reference it is never forwarded, the Laplacian is always combinatorial)
+    sample_normalize : bool, default True -- indicator columns are scaled to sum to 1
+    anisotropy : default 1;  n_landmark : default None (landmarking is not implemented)
+    **kwargs : graph parameters -- knn=5, decay=40, n_pca=100, thresh=1e-4,
+        distance='euclidean', n_jobs, random_state, verbose; ``ksel`` (candidate list length of the
+        GPU search) and ``lmax`` (inject the Laplacian's spectral bound) are extensions.
+    """
+
+    # class-level defaults differ from the __init__ defaults exactly as in reference meld/meld.py:42-92
+    beta = attribute("beta", default=40, on_set=check_positive, doc="Amount of smoothing to apply.")
+    offset = attribute("offset", default=0, doc="Shift of the filter in the eigenvalue spectrum, in [0, 1].")
+    order = attribute("order", default=1, doc="Falloff and smoothness of the filter.")
+    filter = attribute("filter", default="heat", on_set=partial(check_in, ["heat", "laplacian"]),
+                       doc="Filter type to use. Should be in ['heat', 'laplacian']")
+    solver = attribute("solver", default="chebyshev", on_set=partial(check_in, ["chebyshev", "exact"]),
+                       doc="'chebyshev' polynomial approximation or 'exact' eigen-solution.")
+    chebyshev_order = attribute("chebyshev_order", default=30, on_set=[check_int, check_positive],
+                                doc="Order of chebyshev approximation to use.")
+    lap_type = attribute("lap_type", default="combinatorial",
+                         on_set=partial(check_in, ["combinatorial", "normalized"]),
+                         doc="The kind of Laplacian to calculate")
+    sample_densities = attribute("sample_densities", doc="Density associated with each sample")
+
+    def __init__(
+        self,
+        beta=60,
+        offset=0,
+        order=1,
+        filter="heat",  # noqa: A002
+        solver="chebyshev",
+        chebyshev_order=50,
+        lap_type="combinatorial",
+        sample_normalize=True,
+        anisotropy=1,
+        n_landmark=None,
+        **kwargs
+    ):
+        self.beta = beta
+        self.offset = offset
+        self.order = order
+        self.solver = solver
+        self.chebyshev_order = chebyshev_order
+        self.lap_type = lap_type
+        self.filter = filter
+        self.sample_normalize = sample_normalize
+        self._lmax_override = kwargs.pop("lmax", None)
+        kwargs.pop("use_pygsp", None)  # the reference forces use_pygsp=True; nothing to choose here
+        super().__init__(anisotropy=anisotropy, n_landmark=n_landmark, **kwargs)
+
+    # -- state resets (reference meld/meld.py:120-141) -------------------------------------------
+    def _reset_graph(self):
+        self._reset_filter()
+
+    def _reset_filter(self):
+        self.filt = None
+        self.sample_densities = None
+
+    def set_params(self, **params):
+        params = dict(params)
+        for name in _FILTER_PARAMS:
+            if name in params:
+                value = params.pop(name)
+                if value != getattr(self, name):
+                    self._reset_filter()
+                    setattr(self, name, value)
+        if "lmax" in params:
+            self._lmax_override = params.pop("lmax")
+            self._reset_filter()
+        return super().set_params(**params)
+
+    # -- graph construction (replaces graphtools.Graph(...), reference meld/meld.py:117-118,273) ----
+    def _build_graph(self, data, **kwargs):
+        import torch
+
+        from .graph import build_knn_graph
+
+        opts = dict(self.kwargs)
+        opts.update(kwargs)
+        unsupported = [k for k in opts if k not in ("ksel", "profile")]
+        if unsupported:
+            raise NotImplementedError(
+                "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
+            )
+        if self.n_landmark is not None:
+            raise NotImplementedError("n_landmark is not implemented by the MI355X graph builder")
+        if self.decay is None:
+            raise NotImplementedError("decay=None (unweighted kNN graph) is not implemented")
+        if self.n_pca is not None and self.n_pca < min(data.shape):
+            raise NotImplementedError(
+                "PCA reduction (n_pca={} < min(X.shape)={}) is not implemented; reduce the data first "
+                "or pass n_pca=None".format(self.n_pca, min(data.shape))
+            )
+        if not torch.cuda.is_available():
+            raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        X = torch.from_numpy(data).to("cuda")
+        if self.thresh == 0:
+            from .dense import build_dense_graph
+
+            return build_dense_graph(X, knn=self.knn, decay=self.decay, anisotropy=self.anisotropy)
+        return build_knn_graph(
+            X, knn=self.knn, decay=self.decay, thresh=self.thresh, anisotropy=self.anisotropy,
+            ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)),
+        )
+
+    # -- indicators (reference meld/meld.py:143-191) ------------------------------------------------
+    def _create_sample_indicators(self, sample_labels):
+        """One 0/1 column per sample label, columns sorted like ``np.unique``."""
+        self.sample_labels_ = sample_labels
+        labels = getattr(sample_labels, "values", sample_labels)
+        labels = np.asarray(labels)
+        if labels.ndim > 1:
+            if labels.shape[1] == 1:
+                labels = labels.reshape(-1)
+            else:
+                raise ValueError("sample_labels must be a single column. Got" "shape={}".format(labels.shape))
+        # factorize by hashing (O(N)), then order the p uniques the way np.unique does
+        codes, uniques = pd.factorize(labels, sort=False)
+        uniques = np.asarray(uniques)
+        order = np.argsort(uniques, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.shape[0])
+        codes = rank[codes]
+        self.samples = uniques[order]
+        onehot = np.zeros((labels.shape[0], self.samples.shape[0]), dtype=np.int64)
+        onehot[np.arange(labels.shape[0]), codes] = 1
+        self.sample_indicators = pd.DataFrame(onehot, index=getattr(self, "_labels_index", None), columns=self.samples)
+        return self.sample_indicators
+
+    # -- transform (reference meld/meld.py:193-250) -------------------------------------------------
+    def transform(self, sample_labels):
+        """Filters the sample indicators of ``sample_labels`` over the data graph and returns
+        the ``[N, p]`` sample densities as a DataFrame."""
+        self.graph = utils._check_pygsp_graph(self.graph)
+        self._sample_labels = sample_labels
+
+        if sample_labels.shape[0] != self.graph.N:
+            raise ValueError(
+                "Input data ({}) and input graph ({}) "
+                "are not of the same size".format(sample_labels.shape, self.graph.N)
+            )
+        if len(pd.unique(np.asarray(getattr(sample_labels, "values", sample_labels)).ravel())) == 1:
+            raise ValueError(
+                "Found only one unqiue sample label. Cannot estimate density " "of a single sample."
+            )
+        self._labels_index = sample_labels.index if hasattr(sample_labels, "index") else None
+
+        self._create_sample_indicators(sample_labels)
+        if self.sample_normalize:
+            self.sample_indicators = self.sample_indicators / self.sample_indicators.sum(axis=0)
+
+        if self._lmax_override is not None:
+            self.graph.lmax = self._lmax_override
+        densities = _filter.filter(
+            signal=self.sample_indicators,
+            graph=self.graph,
+            filter=self.filter,
+            beta=self.beta,
+            offset=self.offset,
+            order=self.order,
+            solver=self.solver,
+            chebyshev_order=self.chebyshev_order,
+        )
+        self.sample_densities = pd.DataFrame(
+            densities, index=self._labels_index, columns=self.sample_indicators.columns
+        )
+        return self.sample_densities
+
+    def fit_transform(self, X, sample_labels, **kwargs):
+        """Builds the graph on ``X`` and estimates the density of each sample in
+        ``sample_labels`` (reference ``meld/meld.py:252-274``)."""
+        self.fit(X, **kwargs)
+        return self.transform(sample_labels)

@@ -1,0 +1,452 @@
+"""CPU oracle for the MELD hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  ``meld_amd`` never does (tests/test_no_oracle_in_product.py enforces it).
+
+What this is
+------------
+A NumPy / SciPy / scikit-learn restatement of the arithmetic behind
+``meld.MELD().fit_transform(X, sample_labels)`` (reference v1.0.2).  The reference package is a thin
+orchestration layer; the arithmetic lives in two un-vendored third-party dependencies that are *not
+installed here and not reachable* (no network):
+
+* ``graphtools>=1.5.0`` (reference ``setup.py:9``, call sites ``meld/meld.py:5,9,118``) --
+  kNN search, alpha-decay kernel, symmetrisation, anisotropy, PyGSP weight matrix;
+* ``pygsp`` (unpinned, PyPI latest 0.5.1; reference ``setup.py:12``, call sites
+  ``meld/filter.py:1,39,56,59``) -- Laplacian, ``estimate_lmax``, Chebyshev coefficients and
+  the three-term recurrence, exact (Fourier) filtering.
+
+Each function below restates the *published* algorithm of those libraries (tagged [UPSTREAM]) or
+follows the reference tree (cited file:line relative to /root/reference).  It uses the same
+primitives the reference stack uses (sklearn NearestNeighbors, scipy.sparse CSR, ARPACK eigsh,
+scipy CSR @ dense), so it doubles as the fair CPU baseline of bench.py.
+
+PARITY STATUS: **partially pinned / otherwise unpinned**.  The reference cannot be imported in the
+build container, so golden vectors could not be generated from it.  The oracle is pinned against
+the only known-answer test on this path that the reference holds:
+``test/test_meld.py:43-81`` (sum of the "treat" density == 532 for both filters, exact solver,
+thresh=0 dense graph) -- replayed in tests/test_oracle.py.  The second numeric pin
+(``test/test_benchmark.py:23``) needs ``phate`` and is not reproducible.  Pointwise filter values,
+kNN sets, kernel weights, lmax and Chebyshev coefficients rest on the [UPSTREAM] restatement.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+from scipy import sparse
+from scipy.sparse.linalg import eigsh
+from scipy.spatial.distance import pdist, squareform
+
+__all__ = [
+    "knn_kernel",
+    "dense_kernel",
+    "semantic_kernel_dense",
+    "symmetrize",
+    "apply_anisotropy",
+    "weights_from_kernel",
+    "laplacian",
+    "estimate_lmax",
+    "filter_kernel_fn",
+    "cheby_coeff",
+    "cheby_op",
+    "exact_filter",
+    "sample_indicators",
+    "build_graph",
+    "meld_filter",
+    "fit_transform",
+    "normalize_densities",
+    "OracleGraph",
+]
+
+
+# --------------------------------------------------------------------------------------------
+# A2 + A3  kNN search and alpha-decay kernel
+# --------------------------------------------------------------------------------------------
+def knn_kernel(
+    X,
+    knn=5,
+    decay=40,
+    thresh=1e-4,
+    search_multiplier=6,
+    n_jobs=1,
+    algorithm="ball_tree",
+    return_intermediates=False,
+):
+    """Directed alpha-decay kernel K (CSR, N x N, includes K_ii = 1).
+
+    [UPSTREAM graphtools 1.5.x ``kNNGraph.build_kernel`` -> ``build_kernel_to_data(Y=data,
+    knn=self.knn + 1)``], reached from reference ``meld/meld.py:273`` (``self.fit``) with the
+    kwargs forwarded at ``meld/meld.py:117-118``.
+
+    Steps restated:
+      * ``search_knn = min((knn+1) * search_multiplier, N)`` nearest neighbours *including self*
+        (sklearn ``NearestNeighbors(algorithm="ball_tree")``, euclidean);
+      * ``bandwidth_i = distances[i, knn]`` (k-th non-self neighbour), ``max(., eps)``;
+      * ``radius_i = bandwidth_i * (-log thresh)^(1/decay)``;
+      * rows whose farthest found neighbour is still inside ``radius_i`` are re-searched with
+        6x more neighbours while more than N//10 rows need it, then with a radius search;
+      * ``K_ij = exp(-(d_ij / bandwidth_i)^decay)``, NaN -> 1, values < thresh dropped.
+
+    Net semantics (what the GPU path must reproduce): K_ij = exp(-(d_ij/bw_i)^decay) for every j
+    for which that value is >= thresh, bw_i = (knn+1)-th smallest distance in row i counting self.
+    """
+    from sklearn.neighbors import NearestNeighbors
+
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N = X.shape[0]
+    if thresh < np.finfo(float).eps:
+        thresh = np.finfo(float).eps  # [UPSTREAM kNNGraph.__init__]
+    if knn > N - 2:
+        knn = N - 2  # [UPSTREAM kNNGraph.__init__] (warns upstream)
+    k1 = knn + 1
+    knn_max = N
+    tree = NearestNeighbors(n_neighbors=k1, algorithm=algorithm, metric="euclidean", n_jobs=n_jobs).fit(X)
+
+    search_knn = min(k1 * search_multiplier, knn_max)
+    distances, indices = tree.kneighbors(X, n_neighbors=search_knn)
+    bandwidth = distances[:, k1 - 1].copy()
+    bandwidth = np.maximum(bandwidth, np.finfo(float).eps)
+    radius = bandwidth * np.power(-1 * np.log(thresh), 1 / decay)
+    update_idx = np.argwhere(np.max(distances, axis=1) < radius).reshape(-1)
+    n_updated_first = len(update_idx)
+
+    if len(update_idx) > 0:
+        distances = [d for d in distances]
+        indices = [i for i in indices]
+
+    search_knn = min(search_knn * search_multiplier, knn_max)
+    while len(update_idx) > N // 10 and search_knn < N / 2 and search_knn < knn_max:
+        dist_new, ind_new = tree.kneighbors(X[update_idx], n_neighbors=search_knn)
+        for i, idx in enumerate(update_idx):
+            distances[idx] = dist_new[i]
+            indices[idx] = ind_new[i]
+        keep = [i for i, d in enumerate(dist_new) if np.max(d) < radius[update_idx[i]]]
+        update_idx = update_idx[keep]
+        search_knn = min(search_knn * search_multiplier, knn_max)
+    if search_knn > N / 2:
+        tree = NearestNeighbors(n_neighbors=search_knn, algorithm="brute", n_jobs=n_jobs).fit(X)
+    if len(update_idx) > 0:
+        if search_knn == knn_max:
+            dist_new, ind_new = tree.kneighbors(X[update_idx], n_neighbors=search_knn)
+        else:
+            dist_new, ind_new = tree.radius_neighbors(X[update_idx, :], radius=np.max(radius[update_idx]))
+        for i, idx in enumerate(update_idx):
+            distances[idx] = dist_new[i]
+            indices[idx] = ind_new[i]
+
+    data = np.concatenate([np.asarray(distances[i]) / bandwidth[i] for i in range(N)])
+    cols = np.concatenate([np.asarray(ix) for ix in indices])
+    indptr = np.concatenate([[0], np.cumsum([len(d) for d in distances])])
+    K = sparse.csr_matrix((data, cols, indptr), shape=(N, N))
+    K.data = np.exp(-1 * np.power(K.data, decay))
+    K.data = np.where(np.isnan(K.data), 1, K.data)
+    K.data[K.data < thresh] = 0
+    K = K.tocoo()
+    K.eliminate_zeros()
+    K = K.tocsr()
+    K.sort_indices()
+    if return_intermediates:
+        return K, dict(bandwidth=bandwidth, radius=radius, n_research_rows=n_updated_first)
+    return K
+
+
+def dense_kernel(X, knn=5, decay=40, thresh=0.0):
+    """Dense "exact" kernel used when thresh == 0.
+
+    [UPSTREAM graphtools ``api.Graph`` picks ``TraditionalGraph`` when ``decay is not None and
+    thresh == 0``; ``TraditionalGraph.build_kernel``]: pdist/squareform, bandwidth =
+    max of the (knn+1) smallest entries per row (self included), ``K = exp(-(pdx/bw)^decay)``,
+    NaN -> 1, ``K[K < thresh] = 0``.  Exercised by reference ``test/test_meld.py:59-69``.
+    """
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N = X.shape[0]
+    if knn > N - 2:
+        knn = N - 2
+    pdx = squareform(pdist(X, metric="euclidean"))
+    knn_dist = np.partition(pdx, knn + 1, axis=1)[:, : knn + 1]
+    bandwidth = np.max(knn_dist, axis=1)
+    pdx = (pdx.T / bandwidth).T
+    K = np.exp(-1 * np.power(pdx, decay))
+    K = np.where(np.isnan(K), 1, K)
+    K[K < thresh] = 0
+    return K
+
+
+def semantic_kernel_dense(X, knn=5, decay=40, thresh=1e-4):
+    """Brute-force statement of the kernel's *semantics* (small N only, O(N^2) memory).
+
+    K_ij = v_ij if v_ij >= thresh else 0, v_ij = exp(-(d_ij / bw_i)^decay), bw_i = (knn+1)-th
+    smallest distance of row i counting self.  Used by the tests to show that ``knn_kernel``'s
+    search/re-search control flow and the GPU candidate/fallback control flow both reduce to it.
+    """
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N = X.shape[0]
+    if knn > N - 2:
+        knn = N - 2
+    if thresh < np.finfo(float).eps:
+        thresh = np.finfo(float).eps
+    d = squareform(pdist(X, metric="euclidean"))
+    bw = np.maximum(np.sort(d, axis=1)[:, knn], np.finfo(float).eps)
+    v = np.exp(-np.power(d / bw[:, None], decay))
+    v[v < thresh] = 0
+    return sparse.csr_matrix(v), bw
+
+
+# --------------------------------------------------------------------------------------------
+# A4  symmetrise, anisotropy, weights      A5  Laplacian
+# --------------------------------------------------------------------------------------------
+def symmetrize(K):
+    """[UPSTREAM graphtools ``BaseGraph.symmetrize_kernel`` with the default kernel_symm="+"]:
+    ``K <- (K + K^T) / 2``."""
+    return (K + K.T) / 2
+
+
+def apply_anisotropy(K, anisotropy=1):
+    """[UPSTREAM graphtools ``BaseGraph.apply_anisotropy``]: ``d = K.sum(1)`` (diagonal
+    included); ``K_ij <- K_ij / (d_i d_j)^anisotropy``.  MELD forwards anisotropy=1
+    (reference ``meld/meld.py:104,118``)."""
+    if anisotropy == 0:
+        return K
+    if sparse.issparse(K):
+        d = np.array(K.sum(1)).flatten()
+        K = K.tocoo()
+        K.data = K.data / ((d[K.row] * d[K.col]) ** anisotropy)
+        return K.tocsr()
+    d = K.sum(1)
+    return K / (np.outer(d, d) ** anisotropy)
+
+
+def weights_from_kernel(K):
+    """[UPSTREAM graphtools ``PyGSPGraph._build_weight_from_kernel``]: W = K with zero diagonal."""
+    if sparse.issparse(K):
+        W = K.tolil(copy=True)
+        W.setdiag(0)
+        W = W.tocsr()
+        W.eliminate_zeros()
+        W.sort_indices()
+        return W
+    W = np.array(K, copy=True)
+    np.fill_diagonal(W, 0)
+    return W
+
+
+def laplacian(W):
+    """[UPSTREAM pygsp 0.5.1 ``Graph.compute_laplacian('combinatorial')``]: dw = W 1, L = D - W.
+    (``lap_type`` is stored by the reference but never forwarded -- ``meld/meld.py:113`` -- so the
+    Laplacian is always combinatorial.)"""
+    if sparse.issparse(W):
+        dw = np.ravel(W.sum(1))
+        return (sparse.diags(dw, 0) - W).tocsr(), dw
+    dw = W.sum(1)
+    return np.diag(dw) - W, dw
+
+
+# --------------------------------------------------------------------------------------------
+# A9  lmax
+# --------------------------------------------------------------------------------------------
+def estimate_lmax(L, dw=None):
+    """[UPSTREAM pygsp 0.5.1 ``Graph.estimate_lmax``] (called at reference ``meld/filter.py:39``):
+    ``1.01 * eigsh(L, k=1, tol=5e-3, ncv=min(N, 10))``; ``2 max(dw)`` if ARPACK fails."""
+    N = L.shape[0]
+    try:
+        lmax = eigsh(sparse.csr_matrix(L).astype(np.float64), k=1, tol=5e-3, ncv=min(N, 10), return_eigenvectors=False)
+        return float(lmax[0]) * 1.01
+    except sparse.linalg.ArpackNoConvergence:  # pragma: no cover
+        if dw is None:
+            dw = np.ravel(abs(L).sum(1)) / 2
+        return 2.0 * float(np.max(dw))
+
+
+# --------------------------------------------------------------------------------------------
+# A8  filter kernels     A10  Chebyshev     A10x  exact
+# --------------------------------------------------------------------------------------------
+def filter_kernel_fn(filter, beta, offset, order, lmax):
+    """Spectral kernels of reference ``meld/filter.py:42-53``."""
+    if filter.lower() == "laplacian":
+        return lambda x: 1 / (1 + (beta * np.abs(x / lmax - offset)) ** order)
+    elif filter.lower() == "heat":
+        return lambda x: np.exp(-beta * np.abs(x / lmax - offset) ** order)
+    raise NotImplementedError
+
+
+def cheby_coeff(h, lmax, m):
+    """[UPSTREAM pygsp 0.5.1 ``filters.approximations.compute_cheby_coeff(f, m)``], N = m + 1
+    quadrature points: c_o = 2/N * sum_j h(a1 cos(pi (j+.5)/N) + a2) cos(pi o (j+.5)/N)."""
+    N = m + 1
+    a1 = (lmax - 0) / 2
+    a2 = (lmax + 0) / 2
+    c = np.zeros(m + 1)
+    tmpN = np.arange(N)
+    num = np.cos(np.pi * (tmpN + 0.5) / N)
+    for o in range(m + 1):
+        c[o] = 2.0 / N * np.dot(h(a1 * num + a2), np.cos(np.pi * o * (tmpN + 0.5) / N))
+    return c
+
+
+def cheby_op(L, lmax, c, signal):
+    """[UPSTREAM pygsp 0.5.1 ``filters.approximations.cheby_op``], single filter (Nscales = 1):
+    T0 = s; T1 = (L s - a2 s)/a1; r = c0/2 T0 + c1 T1;
+    factor = 2/a1 (L - a2 I); Tk = factor T(k-1) - T(k-2); r += ck Tk."""
+    c = np.asarray(c)
+    M = c.shape[0]
+    if M < 2:
+        raise TypeError("The coefficients have an invalid shape")
+    a1 = float(lmax - 0) / 2.0
+    a2 = float(lmax + 0) / 2.0
+    signal = np.asarray(signal, dtype=np.float64)
+    L = sparse.csr_matrix(L)
+    twf_old = signal
+    twf_cur = (L.dot(signal) - a2 * signal) / a1
+    r = 0.5 * c[0] * twf_old + c[1] * twf_cur
+    factor = 2 / a1 * (L - a2 * sparse.eye(L.shape[0]))
+    factor = sparse.csr_matrix(factor)
+    for k in range(2, M):
+        twf_new = factor.dot(twf_cur) - twf_old
+        r += c[k] * twf_new
+        twf_old = twf_cur
+        twf_cur = twf_new
+    return r
+
+
+def exact_filter(L, h_of_lmax, signal):
+    """[UPSTREAM pygsp 0.5.1 ``Filter.filter(method='exact')`` + ``compute_fourier_basis``]:
+    e, U = eigh(L.toarray()); lmax <- e[-1]; r = U diag(h(e)) U^T s.
+    ``h_of_lmax(lmax)`` returns the kernel closure: the reference closure reads ``graph.lmax`` at
+    evaluation time (``meld/filter.py:45,50``), i.e. *after* the Fourier basis overwrote it with
+    the exact e[-1]."""
+    Ld = L.toarray() if sparse.issparse(L) else np.asarray(L)
+    e, U = np.linalg.eigh(Ld)
+    e[0] = 0 if abs(e[0]) < 1e-10 else e[0]
+    lmax = e[-1]
+    h = h_of_lmax(lmax)
+    s = np.asarray(signal, dtype=np.float64)
+    return U @ (h(e)[:, None] * (U.T @ s)), lmax
+
+
+# --------------------------------------------------------------------------------------------
+# A7  indicators     A11 wrap     next#1 normalize_densities
+# --------------------------------------------------------------------------------------------
+def sample_indicators(sample_labels, sample_normalize=True):
+    """Reference ``meld/meld.py:143-191`` + ``:229-232``: columns = sorted unique labels, one-hot,
+    each column divided by its sum.  Returns (samples, indicator ndarray [N, p])."""
+    labels = np.asarray(getattr(sample_labels, "values", sample_labels))
+    if labels.ndim > 1:
+        if labels.shape[1] == 1:
+            labels = labels.reshape(-1)
+        else:
+            raise ValueError("sample_labels must be a single column. Got" "shape={}".format(labels.shape))
+    samples = np.unique(labels)
+    ind = (labels[:, None] == samples[None, :]).astype(np.float64)
+    if sample_normalize:
+        ind = ind / ind.sum(axis=0)
+    return samples, ind
+
+
+def normalize_densities(sample_densities):
+    """Reference ``meld/utils.py:35-47``: L1 row normalisation (sklearn ``normalize(norm='l1')``:
+    divide by sum of |.|, rows of zeros left untouched)."""
+    a = np.asarray(sample_densities, dtype=np.float64)
+    norms = np.abs(a).sum(axis=1)
+    norms[norms == 0] = 1.0
+    return a / norms[:, None]
+
+
+# --------------------------------------------------------------------------------------------
+# whole path
+# --------------------------------------------------------------------------------------------
+class OracleGraph:
+    """Bag of intermediates (everything the parity tests compare stage by stage)."""
+
+    def __init__(self, K_directed, K, W, L, dw, info=None):
+        self.K_directed = K_directed
+        self.K = K
+        self.W = W
+        self.L = L
+        self.dw = dw
+        self.N = W.shape[0]
+        self.info = info or {}
+        self.lmax = None
+
+
+def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree"):
+    """A1-A5: data -> OracleGraph.  No PCA branch: graphtools only reduces when
+    ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger."""
+    if thresh == 0:
+        Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
+        K = apply_anisotropy(symmetrize(Kd), anisotropy)
+        W = weights_from_kernel(K)
+        L, dw = laplacian(W)
+        return OracleGraph(Kd, K, W, L, dw)
+    Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True)
+    K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
+    K.sort_indices()
+    W = weights_from_kernel(K)
+    L, dw = laplacian(W)
+    return OracleGraph(Kd, K, W, L, dw, info)
+
+
+def meld_filter(signal, graph, filter="heat", beta=60, offset=0, order=1, solver="chebyshev", chebyshev_order=50, lmax=None):
+    """Reference ``meld/filter.py:5-61``.  ``lmax=`` injects a precomputed value (pygsp's
+    ``estimate_lmax`` is a no-op when ``_lmax`` is already set [UPSTREAM])."""
+    if lmax is None:
+        lmax = graph.lmax if graph.lmax is not None else estimate_lmax(graph.L, graph.dw)
+    graph.lmax = lmax
+    if filter.lower() not in ("heat", "laplacian"):
+        raise NotImplementedError
+    if solver == "exact":
+        r, lmax_exact = exact_filter(graph.L, lambda lm: filter_kernel_fn(filter, beta, offset, order, lm), signal)
+        graph.lmax = lmax_exact
+        return r
+    h = filter_kernel_fn(filter, beta, offset, order, lmax)
+    c = cheby_coeff(h, lmax, chebyshev_order)
+    return cheby_op(graph.L, lmax, c, signal)
+
+
+def fit_transform(
+    X,
+    sample_labels,
+    beta=60,
+    offset=0,
+    order=1,
+    filter="heat",
+    solver="chebyshev",
+    chebyshev_order=50,
+    sample_normalize=True,
+    anisotropy=1,
+    knn=5,
+    decay=40,
+    thresh=1e-4,
+    n_jobs=1,
+    algorithm="ball_tree",
+    lmax=None,
+    return_graph=False,
+):
+    """``meld.MELD(**params).fit_transform(X, sample_labels)`` -- reference
+    ``meld/meld.py:252-274`` with the constructor defaults of ``meld/meld.py:94-107`` and the
+    graphtools defaults knn=5, decay=40, thresh=1e-4 [UPSTREAM GraphEstimator]."""
+    G = build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=anisotropy, n_jobs=n_jobs, algorithm=algorithm)
+    samples, ind = sample_indicators(sample_labels, sample_normalize)
+    dens = meld_filter(ind, G, filter=filter, beta=beta, offset=offset, order=order, solver=solver, chebyshev_order=chebyshev_order, lmax=lmax)
+    if return_graph:
+        return samples, dens, G
+    return samples, dens
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic inputs shared by tests and bench
+# --------------------------------------------------------------------------------------------
+def synthetic_cells(n_cells, n_dims=50, seed=0, latent_dim=10, n_clusters=20):
+    """Seeded low-intrinsic-dimension mixture of SURVEY.md section 8(d): 20 cluster centres
+    ~ N(0, 4 I_10), points = centre + N(0, I_10), embedded in ``n_dims`` by a fixed random
+    orthonormal map, plus N(0, 0.05^2) isotropic noise.  Labels: Bernoulli(expit(latent_0)) as in
+    reference ``meld/benchmark.py:174,181-184`` / ``test/test_meld.py:56-57``."""
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(0.0, 2.0, size=(n_clusters, latent_dim))
+    assign = rng.integers(0, n_clusters, size=n_cells)
+    latent = centres[assign] + rng.normal(0.0, 1.0, size=(n_cells, latent_dim))
+    q, _ = np.linalg.qr(rng.normal(size=(n_dims, latent_dim)))
+    X = latent @ q.T + rng.normal(0.0, 0.05, size=(n_cells, n_dims))
+    p = 1.0 / (1.0 + np.exp(-latent[:, 0]))
+    labels = np.where(rng.random(n_cells) < p, "expt", "ctrl")
+    return np.ascontiguousarray(X, dtype=np.float64), labels

@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances: graph weights 1e-10 relative (fp64 both sides, different but exact distance
+formulas amplified by the decay exponent), densities 1e-5 relative to the column maximum as
+BASELINE.json's north_star states (measured ~1e-12 with a common lmax)."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import meld_oracle as mo
+
+    return mo
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def _csr_close(A, B, rtol):
+    A = sparse.csr_matrix(A)
+    B = sparse.csr_matrix(B)
+    A.sort_indices()
+    B.sort_indices()
+    assert A.shape == B.shape
+    assert A.nnz == B.nnz, (A.nnz, B.nnz)
+    assert np.array_equal(A.indptr, B.indptr)
+    assert np.array_equal(A.indices, B.indices)
+    np.testing.assert_allclose(A.data, B.data, rtol=rtol, atol=0)
+
+
+@pytest.fixture(scope="module")
+def cells5k():
+    mo = _oracle()
+    X, labels = mo.synthetic_cells(5000, n_dims=50, seed=0)
+    G = mo.build_graph(X, knn=15, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute")
+    return X, labels, G
+
+
+def test_library_loads_on_gpu():
+    from meld_amd import _lib
+
+    lib = _lib.get_lib()
+    assert lib.meld_device_count() >= 1
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 6])
+def test_chebyshev_recurrence_matches_oracle(cells5k, p):
+    """A10: fused recurrence kernel vs pygsp-style scipy loop on the SAME (oracle-built) W."""
+    mo = _oracle()
+    import meld_amd
+    from meld_amd.filter import chebyshev_apply, chebyshev_coefficients, spectral_kernel
+
+    X, labels, G = cells5k
+    rng = np.random.default_rng(1)
+    sig = rng.random((G.N, p))
+    sig /= sig.sum(0)
+    lmax = 1.01 * float(sparse.linalg.eigsh(G.L, k=1, return_eigenvectors=False)[0])
+    h = mo.filter_kernel_fn("heat", 60, 0, 1, lmax)
+    c = mo.cheby_coeff(h, lmax, 30)
+    c2 = chebyshev_coefficients(spectral_kernel("heat", 60, 0, 1, lmax), lmax, 30)
+    np.testing.assert_allclose(c2, c, rtol=1e-13, atol=1e-16)
+    ref = mo.cheby_op(G.L, lmax, c, sig)
+    DG = meld_amd.DeviceGraph.from_scipy(G.W)
+    out = chebyshev_apply(DG, torch.from_numpy(sig).cuda(), c, lmax).cpu().numpy()
+    assert _rel(out, ref) < 1e-12
+
+
+def test_knn_candidates_contain_true_neighbours():
+    """A2: the MFMA search returns, for every row, a superset of its 32 nearest (fp64 brute force)."""
+    mo = _oracle()
+    from meld_amd._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    X, _ = mo.synthetic_cells(3000, n_dims=50, seed=3)
+    N, d = X.shape
+    Xd = torch.from_numpy(X).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    KP, TS, BQ = lib.meld_knn_padded_dim(d), lib.meld_knn_tile_refs(), lib.meld_knn_block_queries()
+    ksel = 64
+    cap = lib.meld_knn_row_capacity(ksel)
+    sums = torch.empty(d, dtype=torch.float64, device="cuda")
+    check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st))
+    np.testing.assert_allclose(sums.cpu().numpy(), X.sum(0), rtol=1e-12)
+    mean = sums / N
+    n_tiles = (N + TS - 1) // TS
+    Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device="cuda")
+    norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn_prepare_refs(ptr(Xd), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st))
+    q_pad = ((N + BQ - 1) // BQ) * BQ
+    Q = torch.empty(q_pad * KP, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn_prepare_queries(ptr(Xd), N, d, ptr(mean), KP, 0, N, ptr(Q), st))
+    ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
+    cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
+    cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
+    check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, N, ksel, ptr(ci), ptr(cd), ptr(cc), st))
+    torch.cuda.synchronize()
+    Xc = X - X.mean(0)
+    np.testing.assert_allclose(norm2.cpu().numpy(), (Xc**2).sum(1), rtol=1e-5)
+    assert abs(float(nmax.item()) - (Xc**2).sum(1).max()) < 1e-3
+    ci = ci.cpu().numpy().reshape(q_pad, cap)[:N, :ksel]
+    cd = cd.cpu().numpy().reshape(q_pad, cap)[:N, :ksel]
+    cc = cc.cpu().numpy()[:N]
+    assert np.all(cc == ksel)
+    D2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1) if N <= 1000 else None
+    from scipy.spatial.distance import cdist
+
+    D = cdist(X, X, "sqeuclidean")
+    true32 = np.argsort(D, axis=1, kind="stable")[:, :32]
+    for i in range(N):
+        assert set(true32[i]).issubset(set(ci[i])), i
+    # rows are sorted by (d2, idx) and d2 agrees with the exact value to fp32 accuracy
+    assert np.all(np.diff(cd, axis=1) >= 0)
+    exact = np.take_along_axis(D, ci.astype(np.int64), axis=1)
+    assert np.abs(cd - exact).max() < 2e-4 * (Xc**2).sum(1).max()
+
+
+@pytest.mark.parametrize("n,d,knn", [(5000, 50, 15), (2000, 10, 5), (777, 3, 7)])
+def test_graph_matches_oracle(n, d, knn):
+    """A2-A5: W (CSR, canonical order) and degrees equal the oracle's."""
+    mo = _oracle()
+    import meld_amd
+
+    X, _ = mo.synthetic_cells(n, n_dims=d, seed=5, latent_dim=min(10, d))
+    G = mo.build_graph(X, knn=knn, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute")
+    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=40, thresh=1e-4, anisotropy=1)
+    _csr_close(DG.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
+    _csr_close(DG.K, G.K, rtol=1e-9)
+    np.testing.assert_allclose(DG.bandwidth.cpu().numpy(), G.info["bandwidth"], rtol=1e-12)
+
+
+def test_graph_exact_sweep_path_matches_main_path():
+    """Rows sent through the exact fp64 sweep give the same graph as certified candidate rows."""
+    mo = _oracle()
+    import meld_amd
+
+    X, _ = mo.synthetic_cells(1500, n_dims=20, seed=9)
+    Xd = torch.from_numpy(X).cuda()
+    A = meld_amd.build_knn_graph(Xd, knn=10)
+    B = meld_amd.build_knn_graph(Xd, knn=10, force_fallback=True)
+    assert A.info["n_flagged_rows"] == 0 and B.info["n_flagged_rows"] == 1500
+    _csr_close(A.W, B.W, rtol=1e-12)
+    G = mo.build_graph(X, knn=10, algorithm="brute")
+    _csr_close(B.W, G.W, rtol=1e-9)
+
+
+def test_readme_toy_goes_through_radius_fallback():
+    """C1 (README.md:51-57): iid 100-d data -- most rows have more radius neighbours than the
+    candidate list holds, which exercises the flagged-row sweep like graphtools' re-search."""
+    mo = _oracle()
+    import meld_amd
+
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(500, 100))
+    labels = rng.choice(["treatment", "control"], size=500)
+    samples, dens, G = mo.fit_transform(X, labels, return_graph=True, algorithm="brute")
+    op = meld_amd.MELD(lmax=G.lmax)
+    out = op.fit_transform(X, labels)
+    assert op.graph.info["n_flagged_rows"] > 0
+    _csr_close(op.graph.W, G.W, rtol=1e-9)
+    assert list(out.columns) == list(samples)
+    assert _rel(out.values, dens) < 1e-5
+
+
+def test_fit_transform_parity_50k_config_scaled():
+    """C2-shaped (d=50, knn=15, beta=60, M=30) at N=20k so the oracle finishes in seconds; the full
+    50k case is run by bench.py --parity.  Common injected lmax ('lmax')."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(20000, n_dims=50, seed=0)
+    samples, dens, G = mo.fit_transform(X, labels, knn=15, beta=60, chebyshev_order=30, return_graph=True,
+                                        algorithm="brute", n_jobs=-1)
+    op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, lmax=G.lmax)
+    out = op.fit_transform(X, labels)
+    assert out.shape == dens.shape
+    for c in range(dens.shape[1]):
+        assert np.abs(out.values[:, c] - dens[:, c]).max() / np.abs(dens[:, c]).max() < 1e-5
+    np.testing.assert_allclose(out.values, dens, rtol=1e-5, atol=1e-5 * dens.max())
+    # native lmax: converged Lanczos vs ARPACK(tol=5e-3): same spectral bound to ~1e-3
+    op2 = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30)
+    op2.fit_transform(X, labels)
+    lam = float(sparse.linalg.eigsh(G.L, k=1, tol=1e-10, return_eigenvectors=False)[0])
+    assert abs(op2.graph.lmax / 1.01 - lam) / lam < 1e-6
+    assert abs(op2.graph.lmax - G.lmax) / G.lmax < 5e-3
+
+
+def test_mass_conservation_and_laplacian_filter():
+    """Invariant pinned by reference test/test_meld.py:78-81: 1^T h(L) x = h(0) 1^T x."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(4000, n_dims=30, seed=11)
+    for filt in ("heat", "laplacian"):
+        op = meld_amd.MELD(knn=10, filter=filt, sample_normalize=False, chebyshev_order=40)
+        out = op.fit_transform(X, labels)
+        samples, dens, G = mo.fit_transform(X, labels, knn=10, filter=filt, sample_normalize=False,
+                                            chebyshev_order=40, return_graph=True, lmax=op.graph.lmax, algorithm="brute")
+        assert _rel(out.values, dens) < 1e-9
+        counts = np.array([(labels == s).sum() for s in samples], dtype=float)
+        np.testing.assert_allclose(out.values.sum(0), dens.sum(0), rtol=1e-10)
+        np.testing.assert_allclose(out.values.sum(0), counts, rtol=1e-3)
+
+
+def test_normalize_densities_kernel():
+    mo = _oracle()
+    import pandas as pd
+
+    import meld_amd
+
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(1000, 3))
+    a[5] = 0
+    np.testing.assert_allclose(meld_amd.normalize_densities(a), mo.normalize_densities(a), rtol=1e-15)
+    df = pd.DataFrame(np.abs(a[:, :2]), index=["c%d" % i for i in range(1000)], columns=["A", "B"])
+    out = meld_amd.utils.normalize_densities(df)
+    assert list(out.index) == list(df.index) and list(out.columns) == ["A", "B"]
+    np.testing.assert_allclose(out.values.sum(1)[6:], 1.0, rtol=1e-14)
