@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- cells/sec through MELD.fit_transform (kNN + Chebyshev) on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+A "step" is one full ``MELD(knn=15, beta=60, chebyshev_order=30).fit_transform(X, labels)`` on the
+synthetic cells of SURVEY.md section 8(d): graph build (distance GEMM + top-k on the matrix cores,
+exact refinement, symmetrisation, anisotropy), lmax, 30 Chebyshev steps, densities back on the
+host as a DataFrame.  X is resident in HBM (fp64) when the timed region starts; labels are a host
+array of strings (they are factorised inside the timed region, as in the reference).
+
+Workload: BASELINE.json's metric is quoted at 1M cells x 50 dims (configs[3]); it fits one GPU, so
+N=1 runs exactly that.  With --gpus N > 1 the cells are row-sharded over the ranks (strong scaling:
+the problem size stays 1M cells).
+
+Extra objects on the JSON line: ``roofline`` (dominant kernel: the kNN distance/top-k kernel,
+MFMA-bound), ``roofline_cheby`` (the HBM-bound CSR recurrence the north star's 70 % target refers
+to), ``cpu_baseline`` (the oracle -- an in-repo scipy/sklearn restatement of the reference path --
+timed on a bounded sample on this box's host cores), ``stages`` (per-stage seconds of one step).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured-achievable)
+
+
+def cheby_bytes_per_step(nnz, n, p):
+    """Algorithmic HBM bytes of one recurrence step (SURVEY.md 8d / BASELINE.md): fp64 values +
+    int32 columns, row pointers, degree vector, five [N,p] vector passes (gather T_{k-1} counted
+    once, read T_{k-2}, write T_k, read r, write r)."""
+    return 12 * nnz + 4 * (n + 1) + 8 * n + 40 * n * p
+
+
+def cpu_baseline(sample_cells, dims, knn, beta, order):
+    """Oracle (kind='port') on a bounded sample, faithful configuration of the reference stack:
+    sklearn ball_tree kNN with n_jobs=1 (graphtools' defaults) and single-threaded scipy SpMM."""
+    from oracle import meld_oracle as mo
+
+    X, labels = mo.synthetic_cells(sample_cells, n_dims=dims, seed=0)
+    t0 = time.perf_counter()
+    mo.fit_transform(X, labels, knn=knn, beta=beta, chebyshev_order=order, algorithm="ball_tree", n_jobs=1)
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mo.fit_transform(X, labels, knn=knn, beta=beta, chebyshev_order=order, algorithm="brute", n_jobs=-1)
+    t_best = time.perf_counter() - t0
+    return {
+        "value": sample_cells / t_ref,
+        "unit": "cells/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "N={} cells x {} dims, full fit_transform, sklearn ball_tree n_jobs=1 + scipy CSR (the reference "
+        "stack's defaults); {:.1f} s".format(sample_cells, dims, t_ref),
+        "best_effort": {
+            "value": sample_cells / t_best,
+            "cores": os.cpu_count(),
+            "note": "same sample with sklearn brute-force kNN on all host cores (n_jobs=-1); {:.1f} s; "
+            "kNN is O(N^2): cells/s at 1M cells would be ~{}x lower".format(t_best, int(1_000_000 / sample_cells)),
+        },
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=1_000_000)
+    ap.add_argument("--dims", type=int, default=50)
+    ap.add_argument("--knn", type=int, default=15)
+    ap.add_argument("--beta", type=float, default=60)
+    ap.add_argument("--order", type=int, default=30)
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="cells in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import meld_amd
+    from meld_amd import graph as mgraph
+    from oracle import meld_oracle as mo  # synthetic input generator + cpu_baseline leg only
+
+    N, d = args.cells, args.dims
+    X_host, labels = mo.synthetic_cells(N, n_dims=d, seed=0)
+    X = torch.from_numpy(X_host).cuda()
+    del X_host
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        op = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)
+        if world > 1:
+            from meld_amd import distributed as mdist
+
+            return op, mdist.fit_transform_sharded(op, X, labels)
+        return op, op.fit_transform(X, labels)
+
+    for _ in range(args.warmup):
+        one_step()
+    mgraph.record_events(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op, dens = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev = mgraph.event_times_ms()
+    mgraph.record_events(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    G = op.graph
+    nnz = int(G.info.get("nnz_global", G.nnz))
+    p = dens.shape[1]
+    out = {
+        "metric": "cells/sec through MELD.fit_transform (kNN+Chebyshev)",
+        "value": N * args.steps / elapsed,
+        "unit": "cells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "{} cells x {} dims (BASELINE configs[3] size), 20-cluster 10-d latent mixture, seed 0; "
+            "knn={}, decay=40, thresh=1e-4, anisotropy=1, beta={}, heat filter, chebyshev_order={}, p={} labels".format(
+                N, d, args.knn, args.beta, args.order, p),
+            "parallelism": "single GPU" if world == 1 else "rows sharded over {} GPUs, all-gather per Chebyshev step".format(world),
+            "nnz_W": nnz,
+            "mean_degree": nnz / N,
+            "rows_through_exact_sweep": int(G.info.get("n_flagged_rows", 0)),
+            "lmax": float(G.lmax),
+            "lanczos_iterations": int(G.lmax_info.get("iterations", 0)),
+        },
+    }
+    if "knn_topk" in ev:
+        t_knn = float(np.mean(ev["knn_topk"])) * 1e-3
+        rows = N // world if world > 1 else N
+        flops = 2.0 * rows * N * d
+        out["roofline"] = {
+            "kernel": "knn_topk_kernel (fp32 MFMA distance GEMM + streaming top-k)",
+            "bound": "mfma",
+            "achieved": flops / t_knn / 1e12,
+            "peak": PEAK_MFMA_F32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": flops / t_knn / 1e12 / PEAK_MFMA_F32_TFLOPS,
+            "traffic": None,
+            "algorithmic": "2*Nq*N*d = {:.3e} flop per launch".format(flops),
+            "ms": 1e3 * t_knn,
+        }
+    if "cheby_steps" in ev:
+        t_ch = float(np.mean(ev["cheby_steps"])) * 1e-3
+        steps = args.order - 1
+        rows = N // world if world > 1 else N
+        byts = cheby_bytes_per_step(nnz // world if world > 1 else nnz, rows, p)
+        out["roofline_cheby"] = {
+            "kernel": "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence), {} launches".format(steps),
+            "bound": "hbm",
+            "achieved": byts * steps / t_ch / 1e9,
+            "peak": PEAK_HBM_GBS,
+            "unit": "GB/s",
+            "frac": byts * steps / t_ch / 1e9 / PEAK_HBM_GBS,
+            "traffic": None,
+            "algorithmic": "{} B per launch (12*nnz + 4(N+1) + 8N + 40*N*p)".format(byts),
+            "us_per_launch": 1e6 * t_ch / steps,
+        }
+    if args.stages and world == 1:
+        op2 = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order)
+        t0 = time.perf_counter()
+        op2.fit(X, profile=True)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        op2.transform(labels)
+        torch.cuda.synchronize()
+        out["stages"] = dict(op2.graph.info["stage_seconds"], fit_total=t_fit, transform_total=time.perf_counter() - t0)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,8 +158,10 @@ int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const double* val
 
 /* r = a * x  (n doubles) -- initialises r = c0/2 * T0 */
 int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream);
-/* y = a * x + b * y  (n doubles) -- Lanczos vector update */
-int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, meld_stream_t stream);
+/* y = a * x + b * y  (n doubles) -- Lanczos vector update.  If nrm2 != NULL it receives
+ * meld_spmm_dot_slots() partial sums of <y, y> (zeroed by the call; the caller adds them up). */
+int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, double* nrm2,
+                   meld_stream_t stream);
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */

@@ -54,7 +54,7 @@ SIGNATURES = {
         [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr],
     ),
     "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
-    "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr]),
+    "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
 }
 

@@ -177,9 +177,21 @@ __global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ x
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
-                                                    double* __restrict__ y, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    y[i] = a * x[i] + b * y[i];
+                                                    double* __restrict__ y, int64_t n, double* __restrict__ nrm2) {
+  __shared__ double s_part[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = a * x[i] + b * y[i];
+    y[i] = v;
+    acc += v * v;
+  }
+  if (nrm2 != nullptr) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicAdd(&nrm2[blockIdx.x % DOT_SLOTS], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  }
 }
 
 __global__ __launch_bounds__(256) void normalize_rows_l1_kernel(const double* __restrict__ in,
@@ -257,11 +269,13 @@ extern "C" int meld_scale_f64(const double* x, double a, double* r, int64_t n, m
   return MELD_OK;
 }
 
-extern "C" int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, meld_stream_t stream) {
+extern "C" int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, double* nrm2,
+                              meld_stream_t stream) {
   MELD_CHECK_ARG(x && y && n >= 0, "meld_axpby_f64: bad arguments");
+  if (nrm2) MELD_HIP_CALL(hipMemsetAsync(nrm2, 0, sizeof(double) * DOT_SLOTS, S(stream)));
   if (n == 0) return MELD_OK;
-  const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(n, 256));
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), a, x, b, y, n);
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n, 256));
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), a, x, b, y, n, nrm2);
   MELD_LAUNCH_CHECK("axpby_kernel");
   return MELD_OK;
 }

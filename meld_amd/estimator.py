@@ -153,6 +153,21 @@ class GraphEstimator(object):
             self.X = None
             self.graph = X
             return self
+        try:
+            import torch
+        except ImportError:  # pragma: no cover
+            torch = None
+        if torch is not None and isinstance(X, torch.Tensor):
+            # device-resident input: no host copy, no host-side equality check
+            if X.dim() != 2:
+                raise ValueError("Expected a 2D data matrix, got shape {}".format(tuple(X.shape)))
+            if self.X is not X:
+                self.graph = None
+            self.X = X
+            if self.graph is None:
+                self._log("Building graph on {} samples and {} features.".format(X.shape[0], X.shape[1]))
+                self.graph = self._build_graph(X, **kwargs)
+            return self
         if hasattr(X, "X") and not isinstance(X, np.ndarray):  # AnnData-like
             X = X.X
         if hasattr(X, "sparse") and hasattr(X.sparse, "to_dense"):
@@ -165,7 +180,9 @@ class GraphEstimator(object):
         data = np.ascontiguousarray(data, dtype=np.float64)
         if not np.all(np.isfinite(data)):
             raise ValueError("Input data contains NaN or infinity")
-        if self.X is not None and (self.X.shape != data.shape or not np.array_equal(self.X, data)):
+        if self.X is not None and (
+            not isinstance(self.X, np.ndarray) or self.X.shape != data.shape or not np.array_equal(self.X, data)
+        ):
             self.graph = None  # new data: rebuild
         self.X = data
         if self.graph is None:

@@ -17,7 +17,42 @@ import torch
 
 from ._lib import check, get_lib, ptr
 
-__all__ = ["DeviceGraph", "build_knn_graph", "default_ksel"]
+__all__ = ["DeviceGraph", "build_knn_graph", "default_ksel", "EVENTS", "record_events"]
+
+# Optional HIP-event timing of the hot kernels (bench.py turns it on).  Events are recorded on
+# the stream the kernels are launched on (torch's current stream).
+EVENTS = {"enabled": False, "pairs": []}
+
+
+def record_events(enabled=True):
+    EVENTS["enabled"] = bool(enabled)
+    EVENTS["pairs"] = []
+
+
+class _EventSpan:
+    def __init__(self, name, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if EVENTS["enabled"]:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if EVENTS["enabled"]:
+            self.b.record()
+            EVENTS["pairs"].append((self.name, self.a, self.b, self.meta))
+        return False
+
+
+def event_times_ms():
+    """name -> list of elapsed ms (call after a device sync)."""
+    out = {}
+    for name, a, b, meta in EVENTS["pairs"]:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return out
 
 
 def _stream():
@@ -104,7 +139,7 @@ class DeviceGraph:
     def lmax(self, value):
         self._lmax = None if value is None else float(value)
 
-    def estimate_lmax(self, recompute=False, tol=1e-7, max_iter=300):
+    def estimate_lmax(self, recompute=False, tol=1e-5, max_iter=300):
         """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
         ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
         tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos
@@ -220,7 +255,8 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
     cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
     cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
-    check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, N, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
+    with _EventSpan("knn_topk", N=N, d=d):
+        check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, N, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
     tm.stop("knn_topk")
     del Q, Rt
 

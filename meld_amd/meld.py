@@ -122,14 +122,17 @@ class MELD(GraphEstimator):
             raise NotImplementedError("n_landmark is not implemented by the MI355X graph builder")
         if self.decay is None:
             raise NotImplementedError("decay=None (unweighted kNN graph) is not implemented")
-        if self.n_pca is not None and self.n_pca < min(data.shape):
+        if self.n_pca is not None and self.n_pca < min(tuple(data.shape)):
             raise NotImplementedError(
                 "PCA reduction (n_pca={} < min(X.shape)={}) is not implemented; reduce the data first "
-                "or pass n_pca=None".format(self.n_pca, min(data.shape))
+                "or pass n_pca=None".format(self.n_pca, min(tuple(data.shape)))
             )
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
-        X = torch.from_numpy(data).to("cuda")
+        if isinstance(data, torch.Tensor):
+            X = data.to(device="cuda", dtype=torch.float64)
+        else:
+            X = torch.from_numpy(data).to("cuda")
         if self.thresh == 0:
             from .dense import build_dense_graph
 
