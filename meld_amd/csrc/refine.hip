@@ -5,7 +5,7 @@
 // (-log thresh)^(1/decay), re-search of rows whose farthest neighbour is inside the radius,
 // K = exp(-(d/bw)^decay), K < thresh dropped), reached from reference meld/meld.py:273.
 //
-// Net semantics reproduced here (see oracle/meld_oracle.py::semantic_kernel_dense):
+// Net semantics reproduced here (the tests restate them by O(N^2) brute force):
 //   bw_i  = (knn+1)-th smallest euclidean distance of row i, self counted, clipped to eps
 //   K_ij  = exp(-(d_ij / bw_i)^decay)  for every j with K_ij >= thresh
 //

@@ -1,0 +1,125 @@
+"""Host-side contract of the estimator that needs no GPU: constructor validation, indicator
+construction, parameter / reset semantics, type guards.  Mirrors reference test/test_meld.py
+(:17-28, :96-105, :175-181) and the descriptor semantics of meld/meld.py:42-141."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import meld_amd as meld
+
+
+def test_exports_match_reference_names():
+    for name in ("MELD", "get_meld_cmap", "normalize_densities", "utils", "__version__"):
+        assert hasattr(meld, name)
+    with pytest.raises(NotImplementedError):
+        meld.VertexFrequencyCluster
+
+
+def test_constructor_defaults():
+    op = meld.MELD()
+    assert (op.beta, op.offset, op.order, op.filter, op.solver, op.chebyshev_order) == (60, 0, 1, "heat", "chebyshev", 50)
+    assert (op.lap_type, op.sample_normalize, op.anisotropy, op.n_landmark) == ("combinatorial", True, 1, None)
+    assert (op.knn, op.decay, op.n_pca, op.thresh, op.distance) == (5, 40, 100, 1e-4, "euclidean")
+    assert op.graph is None and op.sample_densities is None
+
+
+def test_invalid_lap_type_message():
+    lap_type = "hello world"
+    with pytest.raises(ValueError) as e:
+        meld.MELD(verbose=0, lap_type=lap_type)
+    assert str(e.value) == (
+        "lap_type value {} not recognized. " "Choose from ['combinatorial', 'normalized']".format(lap_type)
+    )
+
+
+@pytest.mark.parametrize(
+    "kw,msg",
+    [
+        (dict(beta=-1), "Expected beta > 0, got -1"),
+        (dict(filter="gauss"), "filter value gauss not recognized. Choose from ['heat', 'laplacian']"),
+        (dict(solver="cg"), "solver value cg not recognized. Choose from ['chebyshev', 'exact']"),
+        (dict(chebyshev_order=2.5), "Expected chebyshev_order integer, got 2.5"),
+        (dict(chebyshev_order=0), "Expected chebyshev_order > 0, got 0"),
+        (dict(knn=0), "Expected knn > 0, got 0"),
+        (dict(decay=-3), "Expected decay > 0, got -3"),
+    ],
+)
+def test_validation_messages(kw, msg):
+    with pytest.raises(ValueError) as e:
+        meld.MELD(**kw)
+    assert str(e.value) == msg
+
+
+def test_check_graph_type_guard():
+    with pytest.raises(TypeError) as e:
+        meld.utils._check_pygsp_graph(G="hello world")
+    assert str(e.value) == (
+        "Input graph should be of type graphtools.base.BaseGraph. "
+        "With graphtools, use the `use_pygsp=True` flag."
+    )
+    with pytest.raises(TypeError):
+        meld.MELD().transform(np.array(["a", "b"]))  # transform before fit
+
+
+def test_sample_labels_2d_message():
+    labels = np.ones((10, 2))
+    with pytest.raises(ValueError) as e:
+        meld.MELD()._create_sample_indicators(labels)
+    assert str(e.value) == "sample_labels must be a single column. Got" "shape={}".format(labels.shape)
+
+
+def test_indicator_columns_sorted_and_binary():
+    op = meld.MELD()
+    ind = op._create_sample_indicators(np.array(["B", "A", "C", "A", "B"]))
+    assert list(ind.columns) == ["A", "B", "C"] and list(op.samples) == ["A", "B", "C"]
+    assert ind.values.tolist() == [[0, 1, 0], [1, 0, 0], [0, 0, 1], [1, 0, 0], [0, 1, 0]]
+    # numeric labels and column-vector DataFrame input
+    df = pd.DataFrame(np.array([[1.0], [0.0], [1.0]]), index=["x", "y", "z"], columns=["lab"])
+    op._labels_index = df.index
+    ind = op._create_sample_indicators(df)
+    assert list(ind.columns) == [0.0, 1.0] and list(ind.index) == ["x", "y", "z"]
+    assert ind.values.tolist() == [[0, 1], [1, 0], [0, 1]]
+
+
+def test_set_params_semantics_without_graph():
+    op = meld.MELD()
+    op.sample_densities = "sentinel"
+    op.set_params(beta=op.beta)  # unchanged value: nothing is reset
+    assert op.sample_densities == "sentinel"
+    op.set_params(beta=op.beta + 1)
+    assert op.sample_densities is None and op.beta == 61
+    op._graph = "sentinel-graph"
+    op.set_params(verbose=1)  # passive parameter keeps the graph
+    assert op.graph == "sentinel-graph"
+    op.set_params(knn=op.knn + 1)  # graph parameter drops it (reference test/test_meld.py:90-93)
+    assert op.graph is None and op.sample_densities is None
+    with pytest.raises(ValueError):
+        op.set_params(not_a_parameter=1)
+
+
+def test_unknown_filter_raises_not_implemented():
+    from meld_amd.filter import spectral_kernel
+
+    with pytest.raises(NotImplementedError):
+        spectral_kernel("gaussian", 1, 0, 1, 1.0)
+
+
+def test_chebyshev_coefficients_reproduce_the_kernel():
+    from meld_amd.filter import chebyshev_coefficients, spectral_kernel
+
+    lmax = 0.37
+    h = spectral_kernel("heat", 60, 0, 1, lmax)
+    c = chebyshev_coefficients(h, lmax, 50)
+    x = np.linspace(0, lmax, 101)
+    t = (x - lmax / 2) / (lmax / 2)
+    T = np.polynomial.chebyshev.chebval(t, np.concatenate([[c[0] / 2], c[1:]]))
+    assert np.abs(T - h(x)).max() < 1e-6
+
+
+def test_fit_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        meld.MELD().fit(np.random.normal(size=(50, 3)))
