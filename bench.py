@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--order", type=int, default=30)
     ap.add_argument("--cpu-sample", type=int, default=20000, help="cells in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
+    ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded driver even with one rank (testing)")
     args = ap.parse_args()
 
     import torch
@@ -93,10 +94,14 @@ def main():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import meld_amd
@@ -115,7 +120,7 @@ def main():
 
     def one_step():
         op = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)
-        if world > 1:
+        if sharded:
             from meld_amd import distributed as mdist
 
             return op, mdist.fit_transform_sharded(op, X, labels)

@@ -1,0 +1,153 @@
+"""Row-sharded MELD across the GPUs of one node (one process per GPU, ``torch.distributed``;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference has no distributed code; this is the design of SURVEY.md section 8(e):
+
+* cells are row-sharded: rank g owns rows [g*R, (g+1)*R), R = ceil(N / world) (the tail is padded
+  with isolated rows so that every collective is equal-sized);
+* kNN: X is replicated; each rank searches its own queries against all N references -- no
+  communication in the dominant, compute-bound stage;
+* symmetrisation (K + K^T)/2: every directed entry (i -> j) also belongs to row j's owner, so the
+  transposed COO entries are bucketed by owner and exchanged with ONE all-to-all-v; each rank then
+  sort-merges its own rows;
+* anisotropy needs the kernel row sums of remote columns: one all-gather of an [N] fp64 vector;
+* lmax: Lanczos with the sharded SpMV (all-gather of the iterate + two scalar all-reduces per
+  iteration);
+* Chebyshev: each step computes the local rows of T_k and all-gathers the [N, p] iterate.
+
+Local work goes through an ``ops`` object (``meld_amd.graph.HipOps`` in production); the CPU
+tests inject a NumPy stand-in to exercise exactly this communication code under gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.distributed as dist
+
+from .graph import DeviceGraph, resolve_graph_params
+
+__all__ = ["Comm", "shard_range", "build_sharded_graph", "fit_transform_sharded"]
+
+
+class Comm:
+    """Thin wrapper over the default process group (equal-sized collectives only, plus one
+    all-to-all-v)."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather_rows(self, full, local):
+        """full[rank*R:(rank+1)*R] <- local, for every rank (in place when local is that slice)."""
+        dist.all_gather_into_tensor(full, local.contiguous(), group=self.group)
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_reduce_max(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def exchange_by_owner(self, keys_sorted, vals_sorted, rows_per_rank):
+        """keys are (row << 32 | col), sorted; entry e goes to rank row // rows_per_rank.
+        Returns the (keys, vals) received from every rank (concatenated)."""
+        dev = keys_sorted.device
+        bounds = (torch.arange(1, self.world, dtype=torch.int64, device=dev) * rows_per_rank) << 32
+        cuts = torch.searchsorted(keys_sorted, bounds)
+        edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cuts, torch.tensor([keys_sorted.shape[0]], dtype=torch.int64, device=dev)])
+        send_counts = (edges[1:] - edges[:-1]).contiguous()
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        send_l = [int(v) for v in send_counts.cpu()]
+        recv_l = [int(v) for v in recv_counts.cpu()]
+        n_recv = sum(recv_l)
+        rk = torch.empty(n_recv, dtype=keys_sorted.dtype, device=dev)
+        rv = torch.empty(n_recv, dtype=vals_sorted.dtype, device=dev)
+        dist.all_to_all_single(rk, keys_sorted.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l, group=self.group)
+        dist.all_to_all_single(rv, vals_sorted.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l, group=self.group)
+        return rk, rv
+
+
+def shard_range(N, world, rank):
+    """(rows_per_rank R, first row, number of real rows) of a rank."""
+    R = (N + world - 1) // world
+    begin = min(rank * R, N)
+    end = min(begin + R, N)
+    return R, begin, end - begin
+
+
+def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None):
+    """Every rank holds the full ``X`` [N, d] (fp64, on its device) and builds the rows it owns."""
+    N, d = int(X.shape[0]), int(X.shape[1])
+    knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
+    R, r0, n_loc = shard_range(N, comm.world, comm.rank)
+    dev = X.device
+
+    if n_loc > 0:
+        keys, vals, bw, info = ops.directed_kernel_coo(X, r0, n_loc, knn, decay, thresh, ksel)
+    else:
+        keys = torch.empty(0, dtype=torch.int64, device=dev)
+        vals = torch.empty(0, dtype=torch.float64, device=dev)
+        bw, info = torch.empty(0, dtype=torch.float64, device=dev), dict(ksel=ksel, n_flagged_rows=0, nnz_directed=0)
+    M = keys.shape[0] // 2
+    direct_k, direct_v = keys[:M], vals[:M]  # rows owned by this rank
+    trans_k, trans_v = ops.sort_pairs(keys[M:].contiguous(), vals[M:].contiguous(), N)  # rows owned by anyone
+    recv_k, recv_v = comm.exchange_by_owner(trans_k, trans_v, R)
+    all_k = torch.cat([direct_k, recv_k])
+    all_v = torch.cat([direct_v, recv_v])
+    rows_here = max(n_loc, 1)
+    rowptr, col, val = ops.assemble_rows(all_k, all_v, r0, rows_here, N)
+    if n_loc == 0:
+        rowptr = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    # kernel row sums (diag = K_ii = 1 included) of every row, for the anisotropy of remote columns
+    ksum_loc = torch.ones(R, dtype=torch.float64, device=dev)
+    if n_loc > 0:
+        ksum_loc[:n_loc] = ops.row_sums(rowptr, val, n_loc, 1.0)
+    ksum_all = torch.empty(R * comm.world, dtype=torch.float64, device=dev)
+    comm.all_gather_rows(ksum_all, ksum_loc)
+    if n_loc > 0:
+        ops.anisotropy(rowptr, col, val, n_loc, ksum_all, r0, anisotropy)
+        dw = ops.row_sums(rowptr, val, n_loc, 0.0)
+    else:
+        dw = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    nnz_loc = torch.tensor([int(col.shape[0]), int(info["n_flagged_rows"])], dtype=torch.int64, device=dev)
+    comm.all_reduce_sum(nnz_loc)
+    info.update(N=N, d=d, knn=knn, nnz=int(col.shape[0]), nnz_global=int(nnz_loc[0]), n_flagged_rows=int(nnz_loc[1]),
+                rows_per_rank=R, row_begin=r0, rows_local=n_loc, world=comm.world)
+    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum_all, anisotropy=anisotropy, row_begin=r0, n_total=N, info=info)
+    G.n_rows = n_loc
+    G.rows_pad = R
+    G.n_pad = R * comm.world
+    G.comm = comm
+    G.ops = ops
+    G.bandwidth = bw
+    return G
+
+
+def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
+    """``op.fit_transform(X, sample_labels)`` with the cells row-sharded over the process group.
+    ``op`` is a ``meld_amd.MELD``; every rank passes the same ``X`` / labels and receives the same
+    full ``[N, p]`` DataFrame."""
+    if comm is None:
+        comm = Comm()
+    if ops is None:
+        from .graph import HipOps
+
+        ops = HipOps()
+    if not isinstance(X, torch.Tensor):
+        X = torch.from_numpy(np.ascontiguousarray(np.asarray(getattr(X, "values", X)), dtype=np.float64))
+    X = X.to(device=ops.device, dtype=torch.float64).contiguous()
+    if op.thresh == 0 or op.n_landmark is not None or op.decay is None:
+        raise NotImplementedError("the sharded builder supports the sparse alpha-decay kNN graph only")
+    op.X = X
+    op.graph = build_sharded_graph(
+        X, ops, comm, knn=op.knn, decay=op.decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
+    )
+    return op.transform(sample_labels)

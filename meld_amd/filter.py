@@ -52,46 +52,57 @@ def chebyshev_coefficients(h, lmax, m):
     return c
 
 
-def _spmv_args(G):
-    return ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz
+def _ops_of(G):
+    ops = getattr(G, "ops", None)
+    if ops is None:
+        from .graph import HipOps
+
+        ops = HipOps(G.val.device)
+        G.ops = ops
+    return ops
+
+
+def _local(G, full):
+    """View of the local rows of a full-length [N_pad, ...] buffer."""
+    return full[G.row_begin : G.row_begin + G.rows_pad]
 
 
 def chebyshev_apply(G, signal, coeffs, lmax):
-    """r = sum_k c_k T_k(2 L / lmax - I) signal, on the device.  ``signal``: CUDA fp64 [N, p].
+    """r = sum_k c_k T_k(2 L / lmax - I) signal, on the device.
+
+    ``signal``: fp64 tensor [N_pad, p] on the graph's device (the full signal; every rank of a
+    sharded graph holds it).  Returns the local rows of r ([rows_pad, p]; the whole result on a
+    single GPU).
 
     T0 = s; T1 = (L s - a2 s)/a1; r = c0/2 T0 + c1 T1; Tk = (2/a1)(L - a2 I) T(k-1) - T(k-2);
-    r += ck Tk  [UPSTREAM pygsp ``cheby_op``], a1 = a2 = lmax/2.  Two ping-pong vectors: each
-    step overwrites T(k-2) with T(k)."""
-    lib = get_lib()
-    st = _stream()
-    if G.n_rows != G.N:
-        raise ValueError("chebyshev_apply on a sharded graph must go through meld_amd.distributed")
+    r += ck Tk  [UPSTREAM pygsp ``cheby_op``], a1 = a2 = lmax/2.  Two full-length ping-pong
+    buffers: each step overwrites the local rows of T(k-2) with T(k); on a sharded graph the
+    local slices are then all-gathered (one collective per step)."""
+    ops = _ops_of(G)
+    comm = getattr(G, "comm", None)
     c = np.asarray(coeffs, dtype=np.float64)
     if c.shape[0] < 2:
         raise TypeError("The coefficients have an invalid shape")
-    s = signal.contiguous()
-    n, p = int(s.shape[0]), int(s.shape[1])
+    t_old = signal.contiguous().clone()
+    if t_old.shape[0] != G.n_pad:
+        raise ValueError("signal has {} rows, the graph expects {}".format(t_old.shape[0], G.n_pad))
+    p = int(t_old.shape[1])
     a1 = a2 = float(lmax) / 2.0
-    rp, col, val, dw, n_rows, nnz = _spmv_args(G)
-    t_old = s.clone()
-    t_cur = torch.empty_like(s)
-    r = torch.empty_like(s)
-    check(lib.meld_scale_f64(ptr(t_old), 0.5 * c[0], ptr(r), n * p, st), "meld_scale_f64")
-    check(
-        lib.meld_cheby_step(rp, col, val, dw, n_rows, nnz, p, ptr(t_old), 0, None, ptr(t_cur), ptr(r),
-                            1.0 / a1, -a2 / a1, 0.0, float(c[1]), None, st),
-        "meld_cheby_step",
-    )
+    t_cur = torch.zeros_like(t_old)
+    r = torch.empty_like(_local(G, t_old))
+    ops.scale(_local(G, t_old), 0.5 * c[0], r)
     from .graph import _EventSpan
 
-    with _EventSpan("cheby_steps", steps=int(c.shape[0] - 2), N=n, p=p, nnz=nnz):
+    ops.cheby_step(G, p, t_old, G.row_begin, None, _local(G, t_cur), r, 1.0 / a1, -a2 / a1, 0.0, c[1])
+    if comm is not None:
+        comm.all_gather_rows(t_cur, _local(G, t_cur))
+    with _EventSpan("cheby_steps", steps=int(c.shape[0] - 2), N=G.N, p=p, nnz=G.nnz):
         for k in range(2, c.shape[0]):
-            # T_k overwrites T_{k-2} (z and y alias; each element is read before it is written)
-            check(
-                lib.meld_cheby_step(rp, col, val, dw, n_rows, nnz, p, ptr(t_cur), 0, ptr(t_old), ptr(t_old), ptr(r),
-                                    2.0 / a1, -2.0 * a2 / a1, -1.0, float(c[k]), None, st),
-                "meld_cheby_step",
-            )
+            # T_k overwrites the local rows of T_{k-2} (z and y alias; read-before-write per element)
+            loc = _local(G, t_old)
+            ops.cheby_step(G, p, t_cur, G.row_begin, loc, loc, r, 2.0 / a1, -2.0 * a2 / a1, -1.0, c[k])
+            if comm is not None:
+                comm.all_gather_rows(t_old, loc)
             t_old, t_cur = t_cur, t_old
     return r
 
@@ -102,24 +113,29 @@ def lanczos_lmax(G, tol=1e-5, max_iter=300, check_every=10, seed=0):
     Vectors stay un-normalised on the device (u_k = beta_{k-1} v_k); the 1/beta scalings are folded
     into the alpha/gamma arguments of ``meld_cheby_step``, which also returns <y, u>, so one
     iteration = one SpMV kernel + one axpby kernel (which returns |w|^2 directly -- the shortcut
-    |y|^2 - alpha^2 is unstable) + two 0.5 KiB read-backs.  Convergence: relative Ritz residual
+    |y|^2 - alpha^2 is unstable) + two small read-backs (+ two scalar all-reduces and one
+    all-gather of the new vector on a sharded graph).  Convergence: relative Ritz residual
     |beta_m s_m| / theta <= tol (s = last component of the top eigenvector of the tridiagonal
     matrix); the eigenvalue error is then ~ tol^2 / gap, far below tol."""
-    lib = get_lib()
-    st = _stream()
-    if G.n_rows != G.N:
-        raise ValueError("lanczos_lmax on a sharded graph must go through meld_amd.distributed")
-    n = G.N
+    ops = _ops_of(G)
+    comm = getattr(G, "comm", None)
     dev = G.val.device
-    slots = lib.meld_spmm_dot_slots()
+    slots = ops.dot_slots()
     gen = torch.Generator(device="cpu").manual_seed(seed)
-    u = torch.randn(n, generator=gen, dtype=torch.float64).to(dev)
-    nrm = float(torch.linalg.vector_norm(u).item())
-    u_prev = torch.zeros(n, dtype=torch.float64, device=dev)
-    y = torch.empty(n, dtype=torch.float64, device=dev)
-    dots = torch.empty(2 * slots, dtype=torch.float64, device=dev)
-    nrm2 = torch.empty(slots, dtype=torch.float64, device=dev)
-    rp, col, val, dw, n_rows, nnz = _spmv_args(G)
+    u0 = torch.zeros(G.n_pad, dtype=torch.float64)
+    u0[: G.N] = torch.randn(G.N, generator=gen, dtype=torch.float64)
+    nrm = float(torch.linalg.vector_norm(u0).item())
+    u = u0.to(dev)
+    u_prev = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)
+    y = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)
+    dots = torch.zeros(2 * slots, dtype=torch.float64, device=dev)
+    nrm2 = torch.zeros(slots, dtype=torch.float64, device=dev)
+
+    def total(t):
+        s = t.sum().reshape(1)
+        if comm is not None:
+            comm.all_reduce_sum(s)
+        return float(s.item())
 
     alphas, betas = [], []
     s_cur = 1.0 / nrm  # v_k = s_cur * u
@@ -127,18 +143,14 @@ def lanczos_lmax(G, tol=1e-5, max_iter=300, check_every=10, seed=0):
     beta_prev = 0.0
     theta, resid = 0.0, float("inf")
     it = 0
-    max_iter = min(max_iter, n)
+    max_iter = min(max_iter, G.N)
     while it < max_iter:
-        # y = L v_k - beta_{k-1} v_{k-1}
-        check(
-            lib.meld_cheby_step(rp, col, val, dw, n_rows, nnz, 1, ptr(u), 0, ptr(u_prev), ptr(y), None,
-                                s_cur, 0.0, -beta_prev * s_prev, 0.0, ptr(dots), st),
-            "meld_cheby_step",
-        )
-        alpha = float(dots[:slots].sum().item()) * s_cur  # <y, v_k>
+        # y = L v_k - beta_{k-1} v_{k-1}   (local rows)
+        ops.cheby_step(G, 1, u, G.row_begin, _local(G, u_prev), _local(G, y), None, s_cur, 0.0, -beta_prev * s_prev, 0.0, dots)
+        alpha = total(dots[:slots]) * s_cur  # <y, v_k>
         # w = y - alpha v_k (stored in y), beta = |w|
-        check(lib.meld_axpby_f64(-alpha * s_cur, ptr(u), 1.0, ptr(y), n, ptr(nrm2), st), "meld_axpby_f64")
-        beta = float(np.sqrt(nrm2.sum().item()))
+        ops.axpby(-alpha * s_cur, _local(G, u), 1.0, _local(G, y), nrm2)
+        beta = float(np.sqrt(total(nrm2)))
         alphas.append(alpha)
         it += 1
         done = beta <= 1e-14 * max(abs(alpha), 1e-300)
@@ -149,6 +161,8 @@ def lanczos_lmax(G, tol=1e-5, max_iter=300, check_every=10, seed=0):
             resid = abs(beta * evec[-1, -1]) / max(abs(theta), 1e-300)
             if resid <= tol or done:
                 break
+        if comm is not None:
+            comm.all_gather_rows(y, _local(G, y))
         betas.append(beta)
         u_prev, u, y = u, y, u_prev
         s_prev, s_cur = s_cur, 1.0 / beta
@@ -176,9 +190,16 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
         if chebyshev_order is None:
             chebyshev_order = 30  # pygsp's default order
         c = chebyshev_coefficients(h, graph.lmax, chebyshev_order)
-        s_dev = torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+        full = np.zeros((graph.n_pad, sig.shape[1]))
+        full[: graph.N] = sig
+        s_dev = torch.from_numpy(full).to(dev)
         r = chebyshev_apply(graph, s_dev, c, graph.lmax)
-        out = r.cpu().numpy()
+        comm = getattr(graph, "comm", None)
+        if comm is not None:
+            r_full = torch.empty_like(s_dev)
+            comm.all_gather_rows(r_full, r)
+            r = r_full
+        out = r.cpu().numpy()[: graph.N]
     elif solver == "exact":
         from .dense import exact_filter
 

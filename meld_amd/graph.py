@@ -110,6 +110,11 @@ class DeviceGraph:
         self.info = info or {}
         self._lmax = None
         self.lmax_info = {}
+        # sharding: a single-GPU graph is one shard that owns every row
+        self.rows_pad = self.n_rows  # local rows incl. padding (equal on every rank)
+        self.n_pad = self.N  # global rows incl. padding
+        self.comm = None
+        self.ops = None
 
     @classmethod
     def from_scipy(cls, W, device="cuda"):
@@ -199,165 +204,232 @@ def _scan_i32(lib, x, st):
     return out
 
 
-def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False):
-    """Data [N, d] -> DeviceGraph.  Rows A2-A5 of SURVEY.md section 8(a).
+class HipOps:
+    """Local (per-GPU) stages of the path as calls into libmeld_hip.so.  The single-GPU builder
+    and the row-sharded driver (``meld_amd.distributed``) compose the same stages; only the
+    exchanges between them differ."""
 
-    ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
-    distance GEMM with fused top-ksel, exact fp64 refinement + alpha-decay kernel, exact sweep for
-    rows whose candidate list is provably incomplete, COO emit + radix sort + merge = (K + K^T)/2,
-    anisotropy, degrees.
-    """
-    lib = get_lib()
-    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float64 and X.dim() == 2):
-        raise TypeError("build_knn_graph expects a CUDA float64 tensor [N, d]")
-    X = X.contiguous()
-    N, d = int(X.shape[0]), int(X.shape[1])
-    dev = X.device
-    st = _stream()
-    tm = _Timer(profile)
+    name = "hip"
 
+    def __init__(self, device=None):
+        self.lib = get_lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False):
+        """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
+        key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2)."""
+        lib, st, dev = self.lib, _stream(), X.device
+        tm = tm or _Timer(False)
+        N, d = int(X.shape[0]), int(X.shape[1])
+        KP = lib.meld_knn_padded_dim(d)
+        if KP < 0:
+            check(KP, "meld_knn_padded_dim")
+        TS = lib.meld_knn_tile_refs()
+        BQ = lib.meld_knn_block_queries()
+        cap = lib.meld_knn_row_capacity(ksel)
+        if cap < 0:
+            check(cap, "meld_knn_row_capacity")
+
+        # operands of the distance GEMM
+        tm.start()
+        sums = torch.empty(d, dtype=torch.float64, device=dev)
+        check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
+        mean = sums / N
+        n_tiles = (N + TS - 1) // TS
+        Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
+        norm2 = torch.empty(N, dtype=torch.float32, device=dev)
+        nmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
+        q_pad = ((q_count + BQ - 1) // BQ) * BQ
+        Q = torch.empty(q_pad * KP, dtype=torch.float32, device=dev)
+        check(lib.meld_knn_prepare_queries(ptr(X), N, d, ptr(mean), KP, q_begin, q_count, ptr(Q), st), "meld_knn_prepare_queries")
+        tm.stop("prepare")
+
+        # candidate search on the matrix cores
+        cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
+        cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
+        cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+        with _EventSpan("knn_topk", N=N, d=d, q=q_count):
+            check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
+        tm.stop("knn_topk")
+        del Q, Rt
+
+        # exact refinement + alpha-decay kernel
+        bw = torch.empty(q_count, dtype=torch.float64, device=dev)
+        cand_val = torch.empty(q_count * ksel, dtype=torch.float64, device=dev)
+        keep_cnt = torch.empty(q_count, dtype=torch.int32, device=dev)
+        flag_rows = torch.empty(q_count, dtype=torch.int32, device=dev)
+        n_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        nmax_used = nmax
+        if force_fallback:  # test hook: an infinite error bound flags every row
+            nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
+        check(
+            lib.meld_knn_refine(
+                ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, knn, float(decay),
+                float(thresh), ptr(nmax_used), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
+            ),
+            "meld_knn_refine",
+        )
+        keep_off = _scan_i32(lib, keep_cnt, st)
+        n_flag_h = int(n_flag.item())
+        m_main = int(keep_off[q_count].item())
+        tm.stop("refine")
+
+        # exact sweep for rows the candidate list could not certify
+        fb_total = 0
+        fb_off = fb_col = fb_val = None
+        if n_flag_h > 0:
+            flag_rows = torch.sort(flag_rows[:n_flag_h]).values.contiguous()  # deterministic order
+            fb_cnt = torch.empty(n_flag_h, dtype=torch.int32, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            check(
+                lib.meld_knn_radius_exact(
+                    ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
+                    ptr(fb_cnt), None, None, None, None, ptr(err), st,
+                ),
+                "meld_knn_radius_exact(count)",
+            )
+            fb_off = _scan_i32(lib, fb_cnt, st)
+            fb_total = int(fb_off[n_flag_h].item())
+            if int(err.item()) != 0:
+                raise NotImplementedError(
+                    "degenerate neighbourhoods (more than {} references tie below the bandwidth of a row); "
+                    "this data needs the dense exact graph".format(ksel)
+                )
+            fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
+            fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
+            cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)
+            check(
+                lib.meld_knn_radius_exact(
+                    ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 1,
+                    None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,
+                ),
+                "meld_knn_radius_exact(fill)",
+            )
+        tm.stop("radius_exact")
+
+        M = m_main + fb_total
+        keys = torch.empty(2 * M, dtype=torch.int64, device=dev)
+        vals = torch.empty(2 * M, dtype=torch.float64, device=dev)
+        if M > 0:
+            check(
+                lib.meld_coo_emit(
+                    q_begin, q_count, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, ptr(keep_off), ptr(flag_rows),
+                    n_flag_h, ptr(fb_off), ptr(fb_col), ptr(fb_val), m_main, M, ptr(keys), ptr(vals), st,
+                ),
+                "meld_coo_emit",
+            )
+        tm.stop("coo_emit")
+        info = dict(ksel=int(ksel), KP=int(KP), n_flagged_rows=n_flag_h, nnz_directed=M)
+        return keys, vals, bw, info
+
+    # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------
+    def sort_pairs(self, keys, vals, N):
+        lib, st = self.lib, _stream()
+        n = int(keys.shape[0])
+        keys2 = torch.empty_like(keys)
+        vals2 = torch.empty_like(vals)
+        if n == 0:
+            return keys2, vals2
+        tb = lib.meld_sort_temp_bytes(n)
+        tmp = torch.empty(tb, dtype=torch.uint8, device=keys.device)
+        end_bit = 32 + max(1, int(N - 1).bit_length())
+        check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(keys2), ptr(vals), ptr(vals2), n, end_bit, ptr(tmp), tb, st), "meld_sort_pairs_u64_f64")
+        return keys2, vals2
+
+    def assemble_rows(self, keys, vals, row_begin, n_rows, N):
+        """Sort by key, sum duplicate keys, build CSR of the local rows."""
+        lib, st, dev = self.lib, _stream(), keys.device
+        n = int(keys.shape[0])
+        keys2, vals2 = self.sort_pairs(keys, vals, N)
+        tb = lib.meld_merge_temp_bytes(max(n, 1))
+        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
+        ukeys = torch.empty_like(keys2)
+        uvals = torch.empty_like(vals2)
+        check(lib.meld_coo_merge(ptr(keys2), ptr(vals2), n, ptr(ukeys), ptr(uvals), ptr(n_unique), ptr(tmp), tb, st), "meld_coo_merge")
+        nnz = int(n_unique.item())
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        check(lib.meld_csr_from_keys(ptr(ukeys), nnz, row_begin, n_rows, ptr(rowptr), ptr(col), st), "meld_csr_from_keys")
+        return rowptr, col, uvals[:nnz].clone()
+
+    def row_sums(self, rowptr, val, n_rows, diag):
+        out = torch.empty(n_rows, dtype=torch.float64, device=rowptr.device)
+        check(self.lib.meld_csr_row_sums(ptr(rowptr), ptr(val), n_rows, float(diag), ptr(out), _stream()), "meld_csr_row_sums")
+        return out
+
+    def anisotropy(self, rowptr, col, val, n_rows, ksum_all, row_off, a):
+        check(self.lib.meld_csr_anisotropy(ptr(rowptr), ptr(col), ptr(val), n_rows, ptr(ksum_all), row_off, float(a), _stream()), "meld_csr_anisotropy")
+
+    # ---- A9 / A10: operator steps -----------------------------------------------------------------
+    def dot_slots(self):
+        return self.lib.meld_spmm_dot_slots()
+
+    def cheby_step(self, G, p, x_full, x_row_off, z, y, r, alpha, beta, gamma, coef, dots=None):
+        check(
+            self.lib.meld_cheby_step(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz, p, ptr(x_full),
+                                     x_row_off, ptr(z), ptr(y), ptr(r), float(alpha), float(beta), float(gamma),
+                                     float(coef), ptr(dots), _stream()),
+            "meld_cheby_step",
+        )
+
+    def scale(self, x, a, r):
+        check(self.lib.meld_scale_f64(ptr(x), float(a), ptr(r), x.numel(), _stream()), "meld_scale_f64")
+
+    def axpby(self, a, x, b, y, nrm2=None):
+        check(self.lib.meld_axpby_f64(float(a), ptr(x), float(b), ptr(y), y.numel(), ptr(nrm2), _stream()), "meld_axpby_f64")
+
+
+def resolve_graph_params(N, knn, thresh, ksel):
+    """Parameter clipping shared by every builder ([UPSTREAM graphtools kNNGraph.__init__])."""
     if N < 3:
         raise ValueError("need at least 3 points to build a kNN graph, got {}".format(N))
-    if knn > N - 2:  # [UPSTREAM graphtools kNNGraph.__init__] clips (with a warning)
+    if knn > N - 2:  # graphtools clips (with a warning)
         knn = N - 2
-    thresh = float(max(thresh, np.finfo(float).eps))  # [UPSTREAM] thresh floor
+    thresh = float(max(thresh, np.finfo(float).eps))  # graphtools' thresh floor
     if ksel is None:
         ksel = default_ksel(knn)
     if ksel < knn + 2:
         raise NotImplementedError(
             "knn={} needs a candidate list of at least knn+2 entries but the search kernel holds at most 128".format(knn)
         )
-    KP = lib.meld_knn_padded_dim(d)
-    if KP < 0:
-        check(KP, "meld_knn_padded_dim")
-    TS = lib.meld_knn_tile_refs()
-    BQ = lib.meld_knn_block_queries()
-    cap = lib.meld_knn_row_capacity(ksel)
-    if cap < 0:
-        check(cap, "meld_knn_row_capacity")
+    return int(knn), thresh, int(ksel)
 
-    # ---- operands of the distance GEMM ---------------------------------------------------------
-    tm.start()
-    sums = torch.empty(d, dtype=torch.float64, device=dev)
-    check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
-    mean = sums / N
-    n_tiles = (N + TS - 1) // TS
-    Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
-    norm2 = torch.empty(N, dtype=torch.float32, device=dev)
-    nmax = torch.zeros(1, dtype=torch.float32, device=dev)
-    check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
-    q_pad = ((N + BQ - 1) // BQ) * BQ
-    Q = torch.empty(q_pad * KP, dtype=torch.float32, device=dev)
-    check(lib.meld_knn_prepare_queries(ptr(X), N, d, ptr(mean), KP, 0, N, ptr(Q), st), "meld_knn_prepare_queries")
-    tm.stop("prepare")
 
-    # ---- candidate search on the matrix cores -----------------------------------------------------
-    cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
-    cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
-    cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
-    with _EventSpan("knn_topk", N=N, d=d):
-        check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, N, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
-    tm.stop("knn_topk")
-    del Q, Rt
+def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False):
+    """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
-    # ---- exact refinement + alpha-decay kernel ----------------------------------------------------
-    bw = torch.empty(N, dtype=torch.float64, device=dev)
-    cand_val = torch.empty(N * ksel, dtype=torch.float64, device=dev)
-    keep_cnt = torch.empty(N, dtype=torch.int32, device=dev)
-    flag_rows = torch.empty(N, dtype=torch.int32, device=dev)
-    n_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    nmax_used = nmax
-    if force_fallback:  # test hook: an infinite error bound flags every row
-        nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
-    check(
-        lib.meld_knn_refine(
-            ptr(X), N, d, 0, N, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, knn, float(decay), thresh,
-            ptr(nmax_used), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
-        ),
-        "meld_knn_refine",
-    )
-    keep_off = _scan_i32(lib, keep_cnt, st)
-    n_flag_h = int(n_flag.item())
-    m_main = int(keep_off[N].item())
-    tm.stop("refine")
+    ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
+    distance GEMM with fused top-ksel, exact fp64 refinement + alpha-decay kernel, exact sweep for
+    rows whose candidate list is provably incomplete, COO emit + radix sort + merge = (K + K^T)/2,
+    anisotropy, degrees.
+    """
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float64 and X.dim() == 2):
+        raise TypeError("build_knn_graph expects a CUDA float64 tensor [N, d]")
+    X = X.contiguous()
+    N, d = int(X.shape[0]), int(X.shape[1])
+    ops = HipOps(X.device)
+    tm = _Timer(profile)
+    knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
 
-    # ---- exact sweep for rows the candidate list could not certify --------------------------------
-    fb_total = 0
-    fb_off = fb_col = fb_val = None
-    if n_flag_h > 0:
-        flag_rows = torch.sort(flag_rows[:n_flag_h]).values.contiguous()  # deterministic order
-        fb_cnt = torch.empty(n_flag_h, dtype=torch.int32, device=dev)
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(
-            lib.meld_knn_radius_exact(
-                ptr(X), N, d, 0, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), thresh, 0,
-                ptr(fb_cnt), None, None, None, None, ptr(err), st,
-            ),
-            "meld_knn_radius_exact(count)",
-        )
-        fb_off = _scan_i32(lib, fb_cnt, st)
-        fb_total = int(fb_off[n_flag_h].item())
-        if int(err.item()) != 0:
-            raise NotImplementedError(
-                "degenerate neighbourhoods (more than {} references tie below the bandwidth of a row); "
-                "this data needs the dense exact graph".format(ksel)
-            )
-        fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
-        fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
-        cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)
-        check(
-            lib.meld_knn_radius_exact(
-                ptr(X), N, d, 0, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), thresh, 1,
-                None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,
-            ),
-            "meld_knn_radius_exact(fill)",
-        )
-    tm.stop("radius_exact")
-
-    # ---- (K + K^T)/2 as sorted CSR ---------------------------------------------------------------
-    M = m_main + fb_total
-    if M == 0:
+    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback)
+    if keys.shape[0] == 0:
         raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
-    keys = torch.empty(2 * M, dtype=torch.int64, device=dev)
-    vals = torch.empty(2 * M, dtype=torch.float64, device=dev)
-    check(
-        lib.meld_coo_emit(
-            0, N, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, ptr(keep_off), ptr(flag_rows), n_flag_h,
-            ptr(fb_off), ptr(fb_col), ptr(fb_val), m_main, M, ptr(keys), ptr(vals), st,
-        ),
-        "meld_coo_emit",
-    )
-    del cand_idx, cand_d2, cand_val
-    keys2 = torch.empty_like(keys)
-    vals2 = torch.empty_like(vals)
-    tb = lib.meld_sort_temp_bytes(2 * M)
-    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
-    end_bit = 32 + max(1, int(N - 1).bit_length())
-    check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(keys2), ptr(vals), ptr(vals2), 2 * M, end_bit, ptr(tmp), tb, st), "meld_sort_pairs_u64_f64")
-    tb = lib.meld_merge_temp_bytes(2 * M)
-    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
-    n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
-    check(lib.meld_coo_merge(ptr(keys2), ptr(vals2), 2 * M, ptr(keys), ptr(vals), ptr(n_unique), ptr(tmp), tb, st), "meld_coo_merge")
-    nnz = int(n_unique.item())
-    rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
-    col = torch.empty(nnz, dtype=torch.int32, device=dev)
-    check(lib.meld_csr_from_keys(ptr(keys), nnz, 0, N, ptr(rowptr), ptr(col), st), "meld_csr_from_keys")
-    val = vals[:nnz].clone()
-    del keys, keys2, vals, vals2, tmp
+    tm.start()
+    rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
+    del keys, vals
     tm.stop("symmetrize")
-
-    # ---- anisotropy + degrees ---------------------------------------------------------------------
-    ksum = torch.empty(N, dtype=torch.float64, device=dev)
-    check(lib.meld_csr_row_sums(ptr(rowptr), ptr(val), N, 1.0, ptr(ksum), st), "meld_csr_row_sums")
-    check(lib.meld_csr_anisotropy(ptr(rowptr), ptr(col), ptr(val), N, ptr(ksum), 0, float(anisotropy), st), "meld_csr_anisotropy")
-    dw = torch.empty(N, dtype=torch.float64, device=dev)
-    check(lib.meld_csr_row_sums(ptr(rowptr), ptr(val), N, 0.0, ptr(dw), st), "meld_csr_row_sums")
+    ksum = ops.row_sums(rowptr, val, N, 1.0)
+    ops.anisotropy(rowptr, col, val, N, ksum, 0, anisotropy)
+    dw = ops.row_sums(rowptr, val, N, 0.0)
     tm.stop("anisotropy_degree")
 
-    info = dict(
-        N=N, d=d, knn=int(knn), ksel=int(ksel), KP=int(KP), n_flagged_rows=n_flag_h, nnz_directed=M, nnz=nnz,
-        mean_degree=nnz / N, stage_seconds=dict(tm.t),
-    )
+    nnz = int(col.shape[0])
+    info.update(N=N, d=d, knn=knn, nnz=nnz, mean_degree=nnz / N, stage_seconds=dict(tm.t))
     G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=info)
     G.bandwidth = bw
     return G

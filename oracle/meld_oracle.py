@@ -442,6 +442,7 @@ def synthetic_cells(n_cells, n_dims=50, seed=0, latent_dim=10, n_clusters=20):
     orthonormal map, plus N(0, 0.05^2) isotropic noise.  Labels: Bernoulli(expit(latent_0)) as in
     reference ``meld/benchmark.py:174,181-184`` / ``test/test_meld.py:56-57``."""
     rng = np.random.default_rng(seed)
+    latent_dim = min(latent_dim, n_dims)
     centres = rng.normal(0.0, 2.0, size=(n_clusters, latent_dim))
     assign = rng.integers(0, n_clusters, size=n_cells)
     latent = centres[assign] + rng.normal(0.0, 1.0, size=(n_cells, latent_dim))

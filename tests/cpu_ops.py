@@ -1,0 +1,92 @@
+"""NumPy/SciPy stand-in for ``meld_amd.graph.HipOps`` -- TEST INFRASTRUCTURE ONLY.
+
+It lets the world_size-2 gloo tests drive the real communication code of
+``meld_amd.distributed`` (sharding, all-to-all-v of transposed edges, all-gathers, all-reduces,
+Lanczos / Chebyshev loops) on CPU tensors, where the HIP kernels cannot run.  The local
+arithmetic is taken from the oracle; nothing here is imported by the product.
+"""
+import numpy as np
+import torch
+from scipy import sparse
+
+from oracle import meld_oracle as mo
+
+
+class CpuOps:
+    name = "cpu-test"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self._Kd = None
+
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False):
+        Xn = X.numpy()
+        if self._Kd is None:  # every rank can afford the whole directed kernel at test sizes
+            self._Kd, self._info = mo.knn_kernel(Xn, knn=knn, decay=decay, thresh=thresh, algorithm="brute", return_intermediates=True)
+        K = self._Kd[q_begin : q_begin + q_count].tocoo()
+        rows = K.row.astype(np.int64) + q_begin
+        cols = K.col.astype(np.int64)
+        keep = rows != cols  # the diagonal is carried analytically (K_ii = 1)
+        rows, cols, v = rows[keep], cols[keep], 0.5 * K.data[keep]
+        keys = np.concatenate([(rows << 32) | cols, (cols << 32) | rows])
+        vals = np.concatenate([v, v])
+        bw = torch.from_numpy(self._info["bandwidth"][q_begin : q_begin + q_count].copy())
+        return torch.from_numpy(keys), torch.from_numpy(vals), bw, dict(ksel=ksel, n_flagged_rows=0, nnz_directed=len(v))
+
+    def sort_pairs(self, keys, vals, N):
+        order = torch.argsort(keys, stable=True)
+        return keys[order].contiguous(), vals[order].contiguous()
+
+    def assemble_rows(self, keys, vals, row_begin, n_rows, N):
+        k = keys.numpy()
+        uk, inv = np.unique(k, return_inverse=True)
+        uv = np.zeros(uk.shape[0])
+        np.add.at(uv, inv, vals.numpy())
+        rows = (uk >> 32) - row_begin
+        cols = (uk & 0xFFFFFFFF).astype(np.int32)
+        rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+        np.add.at(rowptr, rows + 1, 1)
+        rowptr = np.cumsum(rowptr)
+        return torch.from_numpy(rowptr), torch.from_numpy(cols), torch.from_numpy(uv)
+
+    def row_sums(self, rowptr, val, n_rows, diag):
+        rp = rowptr.numpy()
+        out = np.add.reduceat(np.concatenate([val.numpy(), [0.0]]), rp[:-1])[:n_rows]
+        out[rp[1:] == rp[:-1]] = 0.0
+        return torch.from_numpy(out + diag)
+
+    def anisotropy(self, rowptr, col, val, n_rows, ksum_all, row_off, a):
+        rp = rowptr.numpy()
+        rows = np.repeat(np.arange(n_rows), np.diff(rp)[:n_rows])
+        ks = ksum_all.numpy()
+        v = val.numpy()
+        v /= (ks[row_off + rows] * ks[col.numpy()]) ** a
+
+    def dot_slots(self):
+        return 4
+
+    def cheby_step(self, G, p, x_full, x_row_off, z, y, r, alpha, beta, gamma, coef, dots=None):
+        n = G.n_rows
+        xf = x_full.numpy().reshape(x_full.shape[0], -1)
+        W = sparse.csr_matrix((G.val.numpy(), G.col.numpy(), G.rowptr.numpy()[: n + 1]), shape=(n, xf.shape[0]))
+        xl = xf[x_row_off : x_row_off + n]
+        yv = alpha * (G.dw_dev.numpy()[:n, None] * xl - W @ xf) + beta * xl
+        if gamma != 0.0:
+            yv = yv + gamma * z.numpy().reshape(z.shape[0], -1)[:n]
+        y.numpy().reshape(y.shape[0], -1)[:n] = yv
+        if r is not None:
+            r.numpy().reshape(r.shape[0], -1)[:n] += coef * yv
+        if dots is not None:
+            dots.zero_()
+            s = self.dot_slots()
+            dots[0] = float((yv * xl).sum())
+            dots[s] = float((yv * yv).sum())
+
+    def scale(self, x, a, r):
+        r.copy_(a * x)
+
+    def axpby(self, a, x, b, y, nrm2=None):
+        y.copy_(a * x + b * y)
+        if nrm2 is not None:
+            nrm2.zero_()
+            nrm2[0] = float((y * y).sum())

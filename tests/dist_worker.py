@@ -1,0 +1,36 @@
+"""Worker of tests/test_distributed_gloo.py: one rank of a gloo group running the sharded
+fit_transform of meld_amd.distributed on CPU tensors with the NumPy stand-in ops."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path, n, d, knn, n_labels):
+    dist.init_process_group("gloo")
+    import meld_amd
+    from meld_amd import distributed as mdist
+    from oracle import meld_oracle as mo
+    from tests.cpu_ops import CpuOps
+
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    if n_labels == 3:
+        labels = np.random.default_rng(1).choice(["A", "B", "C"], size=n)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25)
+    dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
+    G = op.graph
+    np.savez(
+        out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, columns=np.asarray(dens.columns, dtype=str),
+        lmax=G.lmax, lanczos_iters=G.lmax_info["iterations"], row_begin=G.row_begin, n_rows=G.n_rows,
+        rowptr=G.rowptr.numpy(), col=G.col.numpy(), val=G.val.numpy(), dw=G.dw_dev.numpy(), nnz_global=G.info["nnz_global"],
+    )
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))

@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo.  The real communication code of
+meld_amd.distributed (row sharding, all-to-all-v of the transposed edges, all-gather of the
+kernel row sums / Lanczos vector / Chebyshev iterate, scalar all-reduces) runs on CPU tensors
+with a NumPy stand-in for the per-GPU kernels (tests/cpu_ops.py); results must equal the
+single-process oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import meld_oracle as mo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, tmp_path, n, d, knn, n_labels):
+    out = str(tmp_path / "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(d), str(knn), str(n_labels)]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n,n_labels", [(2, 1001, 2), (3, 700, 3)])
+def test_sharded_fit_transform_equals_oracle(world, n, n_labels, tmp_path):
+    d, knn = 8, 7
+    ranks = _run(world, tmp_path, n, d, knn, n_labels)
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    if n_labels == 3:
+        labels = np.random.default_rng(1).choice(["A", "B", "C"], size=n)
+    G = mo.build_graph(X, knn=knn, algorithm="brute")
+    # graph: the shards tile the oracle's W exactly
+    W = sparse.vstack([
+        sparse.csr_matrix((r["val"], r["col"], r["rowptr"][: int(r["n_rows"]) + 1]), shape=(int(r["n_rows"]), n)) for r in ranks
+    ]).tocsr()
+    assert [int(r["row_begin"]) for r in ranks] == [i * (-(-n // world)) for i in range(world)]
+    assert W.nnz == G.W.nnz == int(ranks[0]["nnz_global"])
+    assert abs(W - G.W).max() < 1e-13
+    np.testing.assert_allclose(np.concatenate([r["dw"][: int(r["n_rows"])] for r in ranks]), G.dw, rtol=1e-12)
+    # lmax: every rank agrees, and it is the converged top eigenvalue x 1.01
+    lam = float(sparse.linalg.eigsh(G.L, k=1, tol=1e-12, return_eigenvectors=False)[0])
+    for r in ranks:
+        assert float(r["lmax"]) == float(ranks[0]["lmax"])
+    assert abs(float(ranks[0]["lmax"]) / 1.01 - lam) / lam < 1e-6
+    # densities: identical on every rank and equal to the oracle with the same lmax
+    samples, ind = mo.sample_indicators(labels)
+    ref = mo.meld_filter(ind, G, beta=40, chebyshev_order=25, lmax=float(ranks[0]["lmax"]))
+    for r in ranks:
+        assert list(r["columns"]) == list(samples)
+        assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < 1e-11
+        np.testing.assert_array_equal(r["dens"], ranks[0]["dens"])
+
+
+def test_shard_range_covers_everything():
+    from meld_amd.distributed import shard_range
+
+    for n, w in [(10, 3), (7, 8), (1000, 8), (64, 2)]:
+        got = []
+        for r in range(w):
+            R, b, c = shard_range(n, w, r)
+            got += list(range(b, b + c))
+            assert c <= R
+        assert got == list(range(n))

@@ -125,7 +125,7 @@ def test_graph_matches_oracle(n, d, knn):
     mo = _oracle()
     import meld_amd
 
-    X, _ = mo.synthetic_cells(n, n_dims=d, seed=5, latent_dim=min(10, d))
+    X, _ = mo.synthetic_cells(n, n_dims=d, seed=5)
     G = mo.build_graph(X, knn=knn, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute")
     DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=40, thresh=1e-4, anisotropy=1)
     _csr_close(DG.W, G.W, rtol=1e-9)
@@ -221,3 +221,36 @@ def test_normalize_densities_kernel():
     out = meld_amd.utils.normalize_densities(df)
     assert list(out.index) == list(df.index) and list(out.columns) == ["A", "B"]
     np.testing.assert_allclose(out.values.sum(1)[6:], 1.0, rtol=1e-14)
+
+
+def test_sharded_driver_on_one_gpu_matches_single_gpu_path(tmp_path):
+    """The row-sharded driver with HipOps over NCCL (=RCCL) and a 1-rank group must reproduce
+    the single-GPU path bit for bit (same kernels, same order)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import meld_amd
+from meld_amd import distributed as mdist
+from oracle import meld_oracle as mo
+X, labels = mo.synthetic_cells(6000, n_dims=50, seed=2)
+a = meld_amd.MELD(knn=15, chebyshev_order=30)
+da = mdist.fit_transform_sharded(a, torch.from_numpy(X).cuda(), labels)
+b = meld_amd.MELD(knn=15, chebyshev_order=30)
+db = b.fit_transform(X, labels)
+assert a.graph.nnz == b.graph.nnz and a.graph.info["nnz_global"] == b.graph.nnz
+assert torch.equal(a.graph.val, b.graph.val) and torch.equal(a.graph.col, b.graph.col)
+assert a.graph.lmax == b.graph.lmax, (a.graph.lmax, b.graph.lmax)
+assert np.array_equal(da.values, db.values)
+dist.destroy_process_group()
+print("SHARDED_OK")
+""" % root
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "SHARDED_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
