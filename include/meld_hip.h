@@ -47,6 +47,7 @@ int meld_knn_padded_dim(int d);     /* KP: augmented (d+2) dimension rounded up 
 int meld_knn_tile_refs(void);       /* TS: reference points per LDS tile (reference array is padded to a multiple) */
 int meld_knn_block_queries(void);   /* BQ: queries per workgroup (query arrays are padded to a multiple) */
 int meld_knn_row_capacity(int ksel);/* CAP: row stride of the candidate buffers for a given ksel; <0 if unsupported */
+double meld_knn_error_coef(int d);  /* fp32 FMA-chain bound KP * 2^-21 of meld_knn_topk */
 
 /* column sums of X[N,d] (fp64) -> sums[d] (zeroed by the call).  Used for centring. */
 int meld_col_sums_f64(const double* X, int64_t N, int d, double* sums, meld_stream_t stream);
@@ -69,6 +70,26 @@ int meld_knn_prepare_queries(const double* X, int64_t N, int d, const double* me
 int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_t q_count, int ksel,
                   int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
 
+/* ---- second-generation search: split-fp16 operands on v_mfma_f32_32x32x16_f16 (knn16.hip).
+ * Same role and output contract as meld_knn_topk (ksel smallest approximate squared distances,
+ * rows of stride CAP sorted by (d2, idx), d2 in input units); ~4x less matrix-pipe time.
+ *   meld_knn16_prepare: centre by mean[d], scale into [-1,1], augment, split hi/lo:
+ *       Rt16  : roundup(N, TS) * KB * 64 bytes   (tile-major [tile][kb][half][plane][ref][8 x fp16])
+ *       Q16   : roundup(q_count, BQ) * KB * 64 bytes
+ *       norm2[N], norm2_max[1] (input units), scale_info[4] floats (s, 1/s^2, absmax, pad)
+ *   meld_knn16_error_coef: E / max|x~|^2 to pass to meld_knn_refine for this search. */
+int meld_knn16_kblocks(int d);           /* KB = ceil((d+2)/16); <0 if d unsupported (d <= 126) */
+int meld_knn16_tile_refs(void);          /* TS */
+int meld_knn16_block_queries(void);      /* BQ */
+int meld_knn16_row_capacity(int ksel);   /* CAP */
+double meld_knn16_error_coef(void);
+int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
+                       int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
+                       float* scale_info, meld_stream_t stream);
+int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
+                    int64_t q_count, int ksel, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                    meld_stream_t stream);
+
 /* ---- exact re-evaluation + alpha-decay kernel (replaces [UPSTREAM graphtools
  *      kNNGraph.build_kernel_to_data, "affinities" block]) ---------------------------------- */
 
@@ -78,10 +99,12 @@ int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_
  * is appended to flag_rows (its keep_cnt is set to 0) and must go through meld_knn_radius_exact.
  *   cand_val[q_count][ksel] : kernel value or 0
  *   keep_cnt[q_count]       : number of kept OFF-DIAGONAL entries (0 for flagged rows)
+ *   err_coef                : bound on |d2_search - d2_exact| / norm2_max of the search kernel used
+ *                             (meld_knn_error_coef(d) for meld_knn_topk, meld_knn16_error_coef())
  *   n_flag[1]               : atomic counter, zeroed by the caller */
 int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                     const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                    int knn, double decay, double thresh, const float* norm2_max, double* bw,
+                    int knn, double decay, double thresh, const float* norm2_max, double err_coef, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                     meld_stream_t stream);
 

@@ -342,6 +342,10 @@ extern "C" int meld_knn_padded_dim(int d) {
   set_err("meld_knn_padded_dim: d=%d exceeds the largest instantiated distance kernel (d <= 126)", d);
   return MELD_ERR_UNSUPPORTED;
 }
+extern "C" double meld_knn_error_coef(int d) {
+  const int kp = meld_knn_padded_dim(d);
+  return kp < 0 ? -1.0 : (double)kp * 4.76837158203125e-07; /* KP * 2^-21 */
+}
 extern "C" int meld_knn_tile_refs(void) { return KNN_TS; }
 extern "C" int meld_knn_block_queries(void) { return KNN_BQ; }
 extern "C" int meld_knn_row_capacity(int ksel) {

@@ -1,0 +1,475 @@
+// knn16.hip -- candidate search, second generation: split-fp16 distance GEMM on
+// v_mfma_f32_32x32x16_f16.
+//
+// Same contract as knn.hip (ksel smallest approximate squared distances per query, every
+// candidate re-evaluated in fp64 afterwards); what changes is how the N x N distance matrix is
+// produced.  gfx950 has no fast fp32 matrix path (f32 MFMA = 157 TF, 1/16 of the f16 rate) and
+// no xf32, so each fp32 operand v is split into two fp16 numbers  v = hi + lo  (|v - hi - lo| <=
+// 2^-22 |v| after scaling the data into [-1, 1]) and the product is evaluated as
+//     a.b  ~=  a_hi.b_hi + a_hi.b_lo + a_lo.b_hi          (the dropped a_lo.b_lo is O(2^-22))
+// i.e. 3 f16 MFMAs per 16-deep K block, accumulated in fp32: 12 MFMAs x 32 cycles per 32x32
+// block of distances at d = 50 (K = 64) against 26 x 64 cycles on the f32 MFMA -- 4.3x less
+// matrix-pipe time for an error of a few 1e-6 |x|^2, which refine.hip's completeness test
+// budgets for (err_coef below).
+//
+// Decomposition: workgroup = 8 waves = 512 queries (each wave: 2 groups of 32 queries held as
+// B fragments, 64 VGPRs); all waves share the reference tile stream (64 refs, 16 KiB: hi and lo
+// planes) double-buffered in LDS.  One A fragment (ds_read_b128 x2) feeds two MFMA chains
+// (the two query groups), so the matrix pipe never waits on a dependent accumulator.  HBM/L2:
+// each tile is read once per workgroup: 16 KiB per 1536 matrix-pipe cycles ~ 11 B/clk/CU.
+//
+// Selection: as in knn.hip (threshold per query, append to the row buffer, compact when full),
+// but compaction finds the new threshold by a 32-step radix select on the ordered float bits and
+// squeezes the survivors with ballots (~5x cheaper than ranking); rows are ranked once, at the end.
+#include "common.hpp"
+
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+
+namespace meld {
+
+constexpr int K16_TS = 64;         // references per LDS tile
+constexpr int K16_BQ = 512;        // queries per workgroup
+constexpr int K16_THREADS = 512;   // 8 waves
+constexpr int K16_SLACK = 64;      // CAP = ksel + slack
+constexpr int K16_CAPMAX = 192;
+constexpr float K16_BIG = 30000.0f;  // fp16-representable "infinitely far" squared norm (scaled space: |x|^2 <= d)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ float ld_sc1_f(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_sc1_i(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Keep (unsorted) the entries of a candidate row whose d2 is <= the ksel-th smallest d2.
+// Returns the new count through *n_out and the threshold as return value.  Wave-uniform args.
+__device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__ d2row, int* __restrict__ idxrow,
+                                   int lane, int* n_out) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's append stores have reached L2
+  float d[3];
+  int ix[3];
+  unsigned key[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int p = lane + 64 * e;
+    if (p < n) {
+      d[e] = ld_sc1_f(d2row + p);
+      ix[e] = ld_sc1_i(idxrow + p);
+      key[e] = ordered_bits(d[e]);
+    } else {
+      d[e] = INFINITY;
+      ix[e] = 0x7fffffff;
+      key[e] = 0xffffffffu;
+    }
+  }
+  // radix select: T = ksel-th smallest key  (largest T with count(key < T) < ksel)
+  unsigned T = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned trial = T | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) c += __popcll(__ballot(key[e] < trial));
+    if (c < ksel) T = trial;
+  }
+  // survivors: key <= T (ties at T all stay; if that overflows the row the caller re-ranks)
+  int base = 0;
+  float thr = INFINITY;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const bool keep = key[e] <= T && (lane + 64 * e) < n;
+    const unsigned long long b = __ballot(keep);
+    if (keep) {
+      const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        d2row[pos] = d[e];
+        idxrow[pos] = ix[e];
+      }
+    }
+    base += __popcll(b);
+    const unsigned long long bt = __ballot(keep && key[e] == T);
+    if (bt) thr = __shfl(d[e], __ffsll((long long)bt) - 1, 64);
+  }
+  *n_out = min(base, cap);
+  return thr;
+}
+
+// Final ordering of a row: rank by (d2, idx), keep the ksel smallest sorted, scale back.
+__device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restrict__ d2row, int* __restrict__ idxrow,
+                               float* sd, int* si, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float d[3];
+  int ix[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int p = lane + 64 * e;
+    if (p < n) {
+      d[e] = ld_sc1_f(d2row + p);
+      ix[e] = ld_sc1_i(idxrow + p);
+    } else {
+      d[e] = INFINITY;
+      ix[e] = 0x7fffffff;
+    }
+    sd[p] = d[e];
+    si[p] = ix[e];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int rk[3] = {0, 0, 0};
+  for (int e = 0; e < n; ++e) {
+    const float de = sd[e];
+    const int ie = si[e];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rk[q] += (de < d[q] || (de == d[q] && ie < ix[q])) ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int p = lane + 64 * q;
+    if (p < n && rk[q] < ksel) {
+      d2row[rk[q]] = d[q] * out_scale;
+      idxrow[rk[q]] = ix[q];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int KB>  // 16-deep K blocks: KP16 = 16 * KB >= d + 2
+__global__ __launch_bounds__(K16_THREADS, 2) void knn16_topk_kernel(
+    const _Float16* __restrict__ Q16, const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
+    int n_ref, int n_tiles, int ksel, int cap, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
+    int* __restrict__ cand_cnt) {
+  constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
+  constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
+  constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (KB / 2, or 0 + tail)
+  constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;
+  static_assert(NV <= 4, "tile too large for the staging registers");
+
+  __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
+  __shared__ int lds_cnt[8][64];
+  __shared__ float lds_sd[8][K16_CAPMAX];
+  __shared__ int lds_si[8][K16_CAPMAX];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int jq = lane & 31;
+  const int h = lane >> 5;
+  const int q_base = blockIdx.x * K16_BQ + wave * 64;  // first query of this wave
+
+  // B fragments of both query groups: [g][kb] hi / lo, 8 halves each
+  f16x8 bhi[2][KB], blo[2][KB];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f16x8* qrow = reinterpret_cast<const f16x8*>(Q16 + (size_t)(q_base + g * 32 + jq) * (KB * 32));
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
+      blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
+    }
+  }
+
+  lds_cnt[wave][lane] = 0;
+  float thr[2] = {INFINITY, INFINITY};
+
+  const float4* R4 = reinterpret_cast<const float4*>(Rt16);
+  const bool tail_ok = HAS_TAIL && (NV * K16_THREADS + tid < TILE_V4);
+  float4 p0, p1, p2, p3, pt;
+  p0 = p1 = p2 = p3 = pt = make_float4(0.f, 0.f, 0.f, 0.f);
+#define K16_LOAD(SRC)                                            \
+  do {                                                           \
+    if constexpr (NV > 0) p0 = (SRC)[tid + 0 * K16_THREADS];     \
+    if constexpr (NV > 1) p1 = (SRC)[tid + 1 * K16_THREADS];     \
+    if constexpr (NV > 2) p2 = (SRC)[tid + 2 * K16_THREADS];     \
+    if constexpr (NV > 3) p3 = (SRC)[tid + 3 * K16_THREADS];     \
+    if (tail_ok) pt = (SRC)[tid + NV * K16_THREADS];             \
+  } while (0)
+#define K16_STORE(DST)                                           \
+  do {                                                           \
+    if constexpr (NV > 0) (DST)[tid + 0 * K16_THREADS] = p0;     \
+    if constexpr (NV > 1) (DST)[tid + 1 * K16_THREADS] = p1;     \
+    if constexpr (NV > 2) (DST)[tid + 2 * K16_THREADS] = p2;     \
+    if constexpr (NV > 3) (DST)[tid + 3 * K16_THREADS] = p3;     \
+    if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;             \
+  } while (0)
+  K16_LOAD(R4);
+  K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) {
+      const float4* src = R4 + (size_t)(t + 1) * TILE_V4;
+      K16_LOAD(src);
+    }
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      // tile layout [kb][h][plane][i][8 halves]: lane reads 16 B at ((kb*2+h)*2+plane)*TS + i
+      const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[cur]) + sub * 32 + jq;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
+        const f16x8 alo = a8[((kb * 2 + h) * 2 + 1) * K16_TS];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[0][kb], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[1][kb], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[0][kb], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[1][kb], acc1, 0, 0, 0);
+      }
+
+      const int ref_base = t * K16_TS + sub * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x16 acc = g ? acc1 : acc0;
+        const float m01 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+        const float m23 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
+        const float m45 = fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11]));
+        const float m67 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
+        const float m = fminf(fminf(m01, m23), fminf(m45, m67));
+        if (__any(m < thr[g])) {
+          int* cntp = &lds_cnt[wave][g * 32 + jq];
+          const size_t rowoff = (size_t)(q_base + g * 32 + jq) * cap;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const int ref = ref_base + (r & 3) + 8 * (r >> 2);
+            if (v < thr[g] && ref < n_ref) {
+              const int pos = atomicAdd(cntp, 1);
+              if (pos < cap) {
+                cand_d2[rowoff + pos] = v;
+                cand_idx[rowoff + pos] = ref;
+              }
+            }
+          }
+          const int c = __hip_atomic_load(cntp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          unsigned long long need = __ballot(h == 0 && c > cap - 32);
+          while (need) {
+            const int j = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            int* cj = &lds_cnt[wave][g * 32 + j];
+            const int n = min(__hip_atomic_load(cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
+            const size_t ro = (size_t)(q_base + g * 32 + j) * cap;
+            int n_new;
+            float nt = knn16_squeeze_row(n, ksel, cap, cand_d2 + ro, cand_idx + ro, lane, &n_new);
+            if (n_new > cap - 32) {
+              // pathological ties at the threshold: rank the row down to exactly ksel entries
+              knn16_rank_row(n_new, ksel, 1.0f, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
+              n_new = min(n_new, ksel);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              nt = ld_sc1_f(cand_d2 + ro + n_new - 1);
+            }
+            if (lane == 0) *cj = n_new;
+            if (jq == j) thr[g] = (n >= ksel) ? nt : INFINITY;
+          }
+        }
+      }
+    }
+
+    if (t + 1 < n_tiles) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    __syncthreads();
+  }
+
+  // final: sort every row, convert back to input units, publish its length
+  const float out_scale = scale_info[1];  // 1 / s^2
+  for (int j = 0; j < 64; ++j) {
+    const int n = min(__hip_atomic_load(&lds_cnt[wave][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
+    const int qr = q_base + j;
+    const size_t ro = (size_t)qr * cap;
+    knn16_rank_row(n, ksel, out_scale, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
+    if (lane == 0) cand_cnt[qr] = min(n, ksel);
+  }
+#undef K16_LOAD
+#undef K16_STORE
+}
+
+// ---------------------------------------------------------------------------------------------
+// operand preparation: centre, scale into [-1, 1], augment, split into fp16 hi / lo planes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_centered_kernel(const double* __restrict__ X, int64_t total, int d,
+                                                              const double* __restrict__ mean,
+                                                              float* __restrict__ scale_info) {
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf((float)(X[i] - mean[i % d])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(scale_info + 2), __float_as_int(m));
+}
+
+// scale_info: [0] = s (multiply centred data by s), [1] = 1/s^2, [2] = absmax (input of this kernel)
+__global__ void finish_scale_kernel(float* scale_info) {
+  const float a = scale_info[2];
+  const float s = (a > 0.0f) ? 1.0f / a : 1.0f;
+  scale_info[0] = s;
+  scale_info[1] = 1.0f / (s * s);
+}
+
+__device__ __forceinline__ void split_store(_Float16* dst_hi, _Float16* dst_lo, float v) {
+  const _Float16 hi = (_Float16)v;
+  *dst_hi = hi;
+  *dst_lo = (_Float16)(v - (float)hi);
+}
+
+// element c of the augmented vectors of one row, c in [0, KP16)
+__device__ __forceinline__ float aug_ref(const double* xrow, const double* mean, float s, int d, float n, int c) {
+  return (c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : (c == d ? 1.0f : (c == d + 1 ? n : 0.0f));
+}
+__device__ __forceinline__ float aug_query(const double* xrow, const double* mean, float s, int d, float n, int c) {
+  return (c < d) ? s * (float)(xrow[c] - mean[c]) : (c == d ? n : (c == d + 1 ? 1.0f : 0.0f));
+}
+__device__ __forceinline__ float scaled_norm2(const double* xrow, const double* mean, float s, int d) {
+  float n = 0.0f;
+  for (int k = 0; k < d; ++k) {
+    const float v = s * (float)(xrow[k] - mean[k]);
+    n = fmaf(v, v, n);
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(256) void prepare_refs16_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                             const double* __restrict__ mean,
+                                                             const float* __restrict__ scale_info, int KB,
+                                                             int64_t n_pad, _Float16* __restrict__ Rt16,
+                                                             float* __restrict__ norm2, float* __restrict__ norm2_max) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float s = scale_info[0];
+  float n_orig = 0.0f;
+  if (i < n_pad) {
+    const int64_t t = i / K16_TS;
+    const int ii = (int)(i % K16_TS);
+    _Float16* tile = Rt16 + (size_t)t * (KB * 2 * 2 * K16_TS * 8);
+    const bool real = i < N;
+    const double* xrow = X + (real ? i : 0) * d;
+    const float n = real ? scaled_norm2(xrow, mean, s, d) : 0.0f;
+    if (real) {
+      n_orig = n * scale_info[1];
+      norm2[i] = n_orig;
+    }
+    for (int c = 0; c < KB * 16; ++c) {
+      const float v = real ? aug_ref(xrow, mean, s, d, n, c) : (c == d + 1 ? K16_BIG : 0.0f);
+      const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
+      _Float16* base = tile + ((size_t)((kb * 2 + hh) * 2) * K16_TS + ii) * 8 + e;
+      split_store(base, base + (size_t)K16_TS * 8, v);
+    }
+  }
+  float m = n_orig;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(norm2_max), __float_as_int(m));
+}
+
+__global__ __launch_bounds__(256) void prepare_queries16_kernel(const double* __restrict__ X, int d,
+                                                                const double* __restrict__ mean,
+                                                                const float* __restrict__ scale_info, int KB,
+                                                                int64_t q_begin, int64_t q_count, int64_t q_pad,
+                                                                _Float16* __restrict__ Q16) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= q_pad) return;
+  const float s = scale_info[0];
+  const int64_t src = q_begin + (q < q_count ? q : q_count - 1);
+  const double* xrow = X + src * d;
+  const float n = scaled_norm2(xrow, mean, s, d);
+  _Float16* row = Q16 + (size_t)q * (KB * 32);
+  for (int c = 0; c < KB * 16; ++c) {
+    const float v = aug_query(xrow, mean, s, d, n, c);
+    const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
+    _Float16* base = row + ((kb * 2 + hh) * 2) * 8 + e;
+    split_store(base, base + 8, v);
+  }
+}
+
+}  // namespace meld
+
+using namespace meld;
+
+extern "C" int meld_knn16_kblocks(int d) {
+  if (d < 1) return MELD_ERR_INVALID;
+  const int kb = (d + 2 + 15) / 16;
+  if (kb > 8) {
+    set_err("meld_knn16_kblocks: d=%d exceeds the largest instantiated distance kernel (d <= 126)", d);
+    return MELD_ERR_UNSUPPORTED;
+  }
+  return kb;
+}
+extern "C" int meld_knn16_tile_refs(void) { return K16_TS; }
+extern "C" int meld_knn16_block_queries(void) { return K16_BQ; }
+extern "C" int meld_knn16_row_capacity(int ksel) {
+  if (ksel < 1 || ksel > K16_CAPMAX - K16_SLACK) {
+    set_err("meld_knn16_row_capacity: ksel=%d outside [1, %d]", ksel, K16_CAPMAX - K16_SLACK);
+    return MELD_ERR_UNSUPPORTED;
+  }
+  return ksel + K16_SLACK;
+}
+// bound on |d2_approx - d2_exact| / max_i |x~_i|^2 that meld_knn_refine budgets for
+extern "C" double meld_knn16_error_coef(void) { return 1.52587890625e-05; /* 2^-16 */ }
+
+extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
+                                  int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
+                                  float* scale_info, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && Rt16 && Q16 && norm2 && norm2_max && scale_info && N > 0, "meld_knn16_prepare: null/empty argument");
+  MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N, "meld_knn16_prepare: bad query range");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  hipStream_t st = S(stream);
+  MELD_HIP_CALL(hipMemsetAsync(scale_info, 0, 4 * sizeof(float), st));
+  MELD_HIP_CALL(hipMemsetAsync(norm2_max, 0, sizeof(float), st));
+  hipLaunchKernelGGL(absmax_centered_kernel, dim3(2048), dim3(256), 0, st, X, N * (int64_t)d, d, mean, scale_info);
+  hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
+  const int64_t n_pad = ceil_div(N, K16_TS) * K16_TS;
+  hipLaunchKernelGGL(prepare_refs16_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, st, X, N, d, mean,
+                     scale_info, KB, n_pad, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
+  const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
+  hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, st, X, d, mean,
+                     scale_info, KB, q_begin, q_count, q_pad, reinterpret_cast<_Float16*>(Q16));
+  MELD_LAUNCH_CHECK("meld_knn16_prepare");
+  return MELD_OK;
+}
+
+extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
+                               int64_t q_count, int ksel, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                               meld_stream_t stream) {
+  MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
+  MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
+  const int cap = meld_knn16_row_capacity(ksel);
+  if (cap < 0) return cap;
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int n_tiles = (int)ceil_div(n_ref, K16_TS);
+  const unsigned grid = (unsigned)ceil_div(q_count, K16_BQ);
+  const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
+  const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
+#define K16_CASE(KBV)                                                                                              \
+  case KBV:                                                                                                        \
+    hipLaunchKernelGGL(knn16_topk_kernel<KBV>, dim3(grid), dim3(K16_THREADS), 0, S(stream), q, r, scale_info,      \
+                       (int)n_ref, n_tiles, ksel, cap, cand_idx, cand_d2, cand_cnt);                               \
+    break;
+  switch (KB) {
+    K16_CASE(1)
+    K16_CASE(2)
+    K16_CASE(3)
+    K16_CASE(4)
+    K16_CASE(5)
+    K16_CASE(6)
+    K16_CASE(7)
+    K16_CASE(8)
+    default:
+      set_err("meld_knn16_topk: KB=%d is not an instantiated size", KB);
+      return MELD_ERR_UNSUPPORTED;
+  }
+#undef K16_CASE
+  MELD_LAUNCH_CHECK("knn16_topk_kernel");
+  return MELD_OK;
+}

@@ -11,7 +11,7 @@
 //
 // Completeness proof per row (why a fixed-size candidate list is enough).  Let tau be the fp32
 // squared distance of the ksel-th (last) candidate and E a bound on |d2_fp32 - d2_exact| (fp32
-// FMA-chain bound, E = KP * 2^-21 * max_i |x~_i|^2).  Every reference that is NOT a candidate
+// FMA-chain bound E = KP * 2^-21 * max_i |x~_i|^2, or the split-fp16 bound 2^-16 * max |x~|^2).  Every reference that is NOT a candidate
 // has d2_fp32 >= tau, hence exact d2 >= tau - E.  If radius^2 + E <= tau, no reference inside
 // the radius (and therefore none of the knn+1 nearest, since radius >= bw) was missed, so bw
 // and the row of K computed from the candidates are exact.  Rows that fail the test are
@@ -204,7 +204,8 @@ using namespace meld;
 
 extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                                const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                               int knn, double decay, double thresh, const float* norm2_max, double* bw,
+                               int knn, double decay, double thresh, const float* norm2_max, double err_coef,
+                               double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                                meld_stream_t stream) {
   MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
@@ -214,10 +215,8 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
   const int cap = meld_knn_row_capacity(ksel);
   if (cap < 0) return cap;
-  const int KP = meld_knn_padded_dim(d);
-  if (KP < 0) return KP;
+  MELD_CHECK_ARG(err_coef >= 0, "meld_knn_refine: err_coef must be non-negative");
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
-  const double err_coef = (double)KP * ldexp(1.0, -21);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
                      q_count, cand_idx, cand_d2, cand_cnt, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
                      err_coef, bw, cand_val, keep_cnt, flag_rows, n_flag);

@@ -10,6 +10,7 @@ kernels of ``libmeld_hip.so``; torch only owns the device memory and the stream.
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import numpy as np
@@ -211,8 +212,12 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, search=None):
         self.lib = get_lib()
+        # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
+        self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
+        if self.search not in ("f16x3", "f32"):
+            raise ValueError("unknown search kernel {!r}".format(self.search))
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -224,36 +229,57 @@ class HipOps:
         lib, st, dev = self.lib, _stream(), X.device
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
-        KP = lib.meld_knn_padded_dim(d)
-        if KP < 0:
-            check(KP, "meld_knn_padded_dim")
-        TS = lib.meld_knn_tile_refs()
-        BQ = lib.meld_knn_block_queries()
-        cap = lib.meld_knn_row_capacity(ksel)
-        if cap < 0:
-            check(cap, "meld_knn_row_capacity")
-
-        # operands of the distance GEMM
         tm.start()
         sums = torch.empty(d, dtype=torch.float64, device=dev)
         check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
         mean = sums / N
-        n_tiles = (N + TS - 1) // TS
-        Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
         norm2 = torch.empty(N, dtype=torch.float32, device=dev)
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
-        check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
-        q_pad = ((q_count + BQ - 1) // BQ) * BQ
-        Q = torch.empty(q_pad * KP, dtype=torch.float32, device=dev)
-        check(lib.meld_knn_prepare_queries(ptr(X), N, d, ptr(mean), KP, q_begin, q_count, ptr(Q), st), "meld_knn_prepare_queries")
-        tm.stop("prepare")
-
-        # candidate search on the matrix cores
-        cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
-        cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
-        cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
-        with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-            check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
+        if self.search == "f16x3":
+            # split-fp16 operands on v_mfma_f32_32x32x16_f16 (knn16.hip)
+            KB = lib.meld_knn16_kblocks(d)
+            if KB < 0:
+                check(KB, "meld_knn16_kblocks")
+            TS, BQ = lib.meld_knn16_tile_refs(), lib.meld_knn16_block_queries()
+            cap = lib.meld_knn16_row_capacity(ksel)
+            if cap < 0:
+                check(cap, "meld_knn16_row_capacity")
+            err_coef = lib.meld_knn16_error_coef()
+            n_tiles = (N + TS - 1) // TS
+            q_pad = ((q_count + BQ - 1) // BQ) * BQ
+            Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device=dev)
+            Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device=dev)
+            scale_info = torch.empty(4, dtype=torch.float32, device=dev)
+            check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
+            tm.stop("prepare")
+            cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
+            cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
+            cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+            with _EventSpan("knn_topk", N=N, d=d, q=q_count):
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+            KP = 16 * KB
+        else:
+            # fp32 operands on v_mfma_f32_32x32x2_f32 (knn.hip)
+            KP = lib.meld_knn_padded_dim(d)
+            if KP < 0:
+                check(KP, "meld_knn_padded_dim")
+            TS, BQ = lib.meld_knn_tile_refs(), lib.meld_knn_block_queries()
+            cap = lib.meld_knn_row_capacity(ksel)
+            if cap < 0:
+                check(cap, "meld_knn_row_capacity")
+            err_coef = lib.meld_knn_error_coef(d)
+            n_tiles = (N + TS - 1) // TS
+            Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
+            check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
+            q_pad = ((q_count + BQ - 1) // BQ) * BQ
+            Q = torch.empty(q_pad * KP, dtype=torch.float32, device=dev)
+            check(lib.meld_knn_prepare_queries(ptr(X), N, d, ptr(mean), KP, q_begin, q_count, ptr(Q), st), "meld_knn_prepare_queries")
+            tm.stop("prepare")
+            cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
+            cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
+            cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+            with _EventSpan("knn_topk", N=N, d=d, q=q_count):
+                check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
         tm.stop("knn_topk")
         del Q, Rt
 
@@ -269,7 +295,7 @@ class HipOps:
         check(
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, knn, float(decay),
-                float(thresh), ptr(nmax_used), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
+                float(thresh), ptr(nmax_used), float(err_coef), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
             ),
             "meld_knn_refine",
         )
@@ -323,7 +349,7 @@ class HipOps:
                 "meld_coo_emit",
             )
         tm.stop("coo_emit")
-        info = dict(ksel=int(ksel), KP=int(KP), n_flagged_rows=n_flag_h, nnz_directed=M)
+        info = dict(ksel=int(ksel), KP=int(KP), search=self.search, n_flagged_rows=n_flag_h, nnz_directed=M)
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------

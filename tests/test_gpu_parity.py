@@ -254,3 +254,74 @@ print("SHARDED_OK")
 """ % root
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "SHARDED_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n,d", [(3000, 50), (1500, 100), (2000, 3)])
+def test_knn16_candidates_contain_true_neighbours(n, d):
+    """A2, split-fp16 search: superset of the 32 nearest of every row, rows sorted, d2 within the
+    error budget that refine's completeness test assumes (meld_knn16_error_coef * max |x~|^2)."""
+    mo = _oracle()
+    from scipy.spatial.distance import cdist
+
+    from meld_amd._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    X, _ = mo.synthetic_cells(n, n_dims=d, seed=3)
+    X = X * 37.5 + 11.0  # arbitrary units and offset: the kernel centres and rescales internally
+    N = n
+    Xd = torch.from_numpy(X).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    KB, TS, BQ = lib.meld_knn16_kblocks(d), lib.meld_knn16_tile_refs(), lib.meld_knn16_block_queries()
+    ksel = 64
+    cap = lib.meld_knn16_row_capacity(ksel)
+    sums = torch.empty(d, dtype=torch.float64, device="cuda")
+    check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st))
+    mean = sums / N
+    n_tiles = (N + TS - 1) // TS
+    q_pad = ((N + BQ - 1) // BQ) * BQ
+    Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device="cuda")
+    Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device="cuda")
+    norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+    ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
+    cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
+    cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, ptr(ci), ptr(cd), ptr(cc), st))
+    torch.cuda.synchronize()
+    Xc = X - X.mean(0)
+    n2 = (Xc**2).sum(1)
+    np.testing.assert_allclose(norm2.cpu().numpy(), n2, rtol=1e-5)
+    assert abs(float(sinfo[2].item()) - np.abs(Xc).max()) < 1e-5 * np.abs(Xc).max()
+    ci = ci.cpu().numpy().reshape(q_pad, cap)[:N, :ksel]
+    cd = cd.cpu().numpy().reshape(q_pad, cap)[:N, :ksel]
+    assert np.all(cc.cpu().numpy()[:N] == ksel)
+    D = cdist(X, X, "sqeuclidean")
+    true32 = np.argsort(D, axis=1, kind="stable")[:, :32]
+    for i in range(N):
+        assert set(true32[i]).issubset(set(ci[i])), i
+        assert len(set(ci[i])) == ksel
+    assert np.all(np.diff(cd, axis=1) >= 0)
+    exact = np.take_along_axis(D, ci.astype(np.int64), axis=1)
+    err = np.abs(cd - exact).max() / n2.max()
+    print("knn16 max |d2 - exact| / max|x|^2 = %.3e (budget %.3e)" % (err, lib.meld_knn16_error_coef()))
+    assert err < 0.25 * lib.meld_knn16_error_coef()
+
+
+def test_both_search_kernels_build_the_same_graph():
+    import meld_amd
+    from meld_amd.graph import HipOps
+
+    mo = _oracle()
+    X, _ = mo.synthetic_cells(4000, n_dims=50, seed=12)
+    Xd = torch.from_numpy(X).cuda()
+    graphs = {}
+    for search in ("f32", "f16x3"):
+        ops = HipOps(search=search)
+        keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, 4000, 15, 40, 1e-4, 64)
+        rowptr, col, val = ops.assemble_rows(keys, vals, 0, 4000, 4000)
+        graphs[search] = (rowptr, col, val, bw)
+        assert info["search"] == search
+    for a, b in zip(graphs["f32"], graphs["f16x3"]):
+        assert torch.equal(a, b)
