@@ -225,7 +225,8 @@ def test_normalize_densities_kernel():
 
 def test_sharded_driver_on_one_gpu_matches_single_gpu_path(tmp_path):
     """The row-sharded driver with HipOps over NCCL (=RCCL) and a 1-rank group must reproduce
-    the single-GPU path bit for bit (same kernels, same order)."""
+    the single-GPU path: identical graph (same kernels), lmax / densities to rounding (the
+    reductions go through all-reduce instead of a local sum)."""
     import os
     import subprocess
     import sys
@@ -247,8 +248,8 @@ b = meld_amd.MELD(knn=15, chebyshev_order=30)
 db = b.fit_transform(X, labels)
 assert a.graph.nnz == b.graph.nnz and a.graph.info["nnz_global"] == b.graph.nnz
 assert torch.equal(a.graph.val, b.graph.val) and torch.equal(a.graph.col, b.graph.col)
-assert a.graph.lmax == b.graph.lmax, (a.graph.lmax, b.graph.lmax)
-assert np.array_equal(da.values, db.values)
+assert abs(a.graph.lmax - b.graph.lmax) <= 1e-13 * b.graph.lmax, (a.graph.lmax, b.graph.lmax)
+assert np.abs(da.values - db.values).max() <= 1e-11 * np.abs(db.values).max()
 dist.destroy_process_group()
 print("SHARDED_OK")
 """ % root
