@@ -104,7 +104,7 @@ int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, 
  *   n_flag[1]               : atomic counter, zeroed by the caller */
 int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                     const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                    int knn, double decay, double thresh, const float* norm2_max, double err_coef, double* bw,
+                    int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh, const float* norm2_max, double err_coef, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                     meld_stream_t stream);
 
@@ -130,7 +130,7 @@ int meld_exclusive_scan_i32_i64(const int32_t* in, int64_t* out, int64_t n, void
  * transposed (j,i,v/2) into slot M + e, keys = (row << 32) | col.  keep_off = exclusive scan of
  * keep_cnt; flagged rows take their entries from the fallback arrays at fb_base + fb_off[f]. */
 int meld_coo_emit(int64_t q_begin, int64_t q_count, const int32_t* cand_idx, const double* cand_val,
-                  const int32_t* cand_cnt, int ksel, const int64_t* keep_off, const int32_t* flag_rows,
+                  const int32_t* cand_cnt, int ksel, int cap, const int64_t* keep_off, const int32_t* flag_rows,
                   int32_t n_flag, const int64_t* fb_off, const int32_t* fb_col, const double* fb_val,
                   int64_t fb_base, int64_t M, uint64_t* keys, double* vals, meld_stream_t stream);
 

@@ -29,7 +29,7 @@ SIGNATURES = {
     "meld_knn_topk": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_refine": (
         _i32,
-        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     ),
     "meld_knn_error_coef": (_f64, [_i32]),
     "meld_knn16_kblocks": (_i32, [_i32]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     "meld_exclusive_scan_i32_i64": (_i32, [_ptr, _ptr, _i64, _ptr, _sz, _ptr]),
     "meld_coo_emit": (
         _i32,
-        [_i64, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+        [_i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     ),
     "meld_sort_temp_bytes": (_sz, [_i64]),
     "meld_sort_pairs_u64_f64": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _ptr, _sz, _ptr]),

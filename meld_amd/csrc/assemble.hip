@@ -170,13 +170,13 @@ extern "C" int meld_exclusive_scan_i32_i64(const int32_t* in, int64_t* out, int6
 }
 
 extern "C" int meld_coo_emit(int64_t q_begin, int64_t q_count, const int32_t* cand_idx, const double* cand_val,
-                             const int32_t* cand_cnt, int ksel, const int64_t* keep_off, const int32_t* flag_rows,
+                             const int32_t* cand_cnt, int ksel, int cap, const int64_t* keep_off,
+                             const int32_t* flag_rows,
                              int32_t n_flag, const int64_t* fb_off, const int32_t* fb_col, const double* fb_val,
                              int64_t fb_base, int64_t M, uint64_t* keys, double* vals, meld_stream_t stream) {
   (void)cand_cnt;
   MELD_CHECK_ARG(cand_idx && cand_val && keep_off && keys && vals && q_count > 0, "meld_coo_emit: bad arguments");
-  const int cap = meld_knn_row_capacity(ksel);
-  if (cap < 0) return cap;
+  MELD_CHECK_ARG(cap >= ksel, "meld_coo_emit: row stride cap=%d smaller than ksel=%d", cap, ksel);
   hipLaunchKernelGGL(coo_emit_rows_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), q_begin,
                      q_count, cand_idx, cand_val, ksel, cap, keep_off, M,
                      reinterpret_cast<unsigned long long*>(keys), vals);

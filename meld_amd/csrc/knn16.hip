@@ -12,11 +12,14 @@
 // matrix-pipe time for an error of a few 1e-6 |x|^2, which refine.hip's completeness test
 // budgets for (err_coef below).
 //
-// Decomposition: workgroup = 8 waves = 512 queries (each wave: 2 groups of 32 queries held as
-// B fragments, 64 VGPRs); all waves share the reference tile stream (64 refs, 16 KiB: hi and lo
+// Decomposition: workgroup = 4 waves = 256 queries (each wave: 2 groups of 32 queries held as
+// B fragments, 64 VGPRs); the waves share the reference tile stream (64 refs, 16 KiB: hi and lo
 // planes) double-buffered in LDS.  One A fragment (ds_read_b128 x2) feeds two MFMA chains
-// (the two query groups), so the matrix pipe never waits on a dependent accumulator.  HBM/L2:
-// each tile is read once per workgroup: 16 KiB per 1536 matrix-pipe cycles ~ 11 B/clk/CU.
+// (the two query groups), so the matrix pipe never waits on a dependent accumulator.  Three
+// workgroups are resident per CU (157 VGPRs, 47 KiB LDS): a selection slow path in one
+// workgroup stalls its four waves at the tile barrier, and the other workgroups keep the matrix
+// pipe fed (measured: 8-wave workgroups, one per CU, left the pipe 65 % idle).  L2 -> LDS: each
+// tile is read once per workgroup: 16 KiB per 1536 matrix-pipe cycles x 3 ~ 32 B/clk/CU.
 //
 // Selection: as in knn.hip (threshold per query, append to the row buffer, compact when full),
 // but compaction finds the new threshold by a 32-step radix select on the ordered float bits and
@@ -30,10 +33,12 @@
 namespace meld {
 
 constexpr int K16_TS = 64;         // references per LDS tile
-constexpr int K16_BQ = 512;        // queries per workgroup
-constexpr int K16_THREADS = 512;   // 8 waves
-constexpr int K16_SLACK = 64;      // CAP = ksel + slack
-constexpr int K16_CAPMAX = 192;
+constexpr int K16_BQ = 256;        // queries per workgroup
+constexpr int K16_THREADS = 256;   // 4 waves (64 queries each); 2-3 workgroups resident per CU
+constexpr int K16_NWAVE = K16_THREADS / 64;
+constexpr int K16_SLACK = 128;     // CAP = ksel + slack
+constexpr int K16_CAPMAX = 256;
+constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
 constexpr float K16_BIG = 30000.0f;  // fp16-representable "infinitely far" squared norm (scaled space: |x|^2 <= d)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,11 +61,11 @@ __device__ __forceinline__ int ld_sc1_i(const int* p) {
 __device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__ d2row, int* __restrict__ idxrow,
                                    int lane, int* n_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's append stores have reached L2
-  float d[3];
-  int ix[3];
-  unsigned key[3];
+  float d[K16_SLOTS];
+  int ix[K16_SLOTS];
+  unsigned key[K16_SLOTS];
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
+  for (int e = 0; e < K16_SLOTS; ++e) {
     const int p = lane + 64 * e;
     if (p < n) {
       d[e] = ld_sc1_f(d2row + p);
@@ -79,14 +84,14 @@ __device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__
     const unsigned trial = T | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) c += __popcll(__ballot(key[e] < trial));
+    for (int e = 0; e < K16_SLOTS; ++e) c += __popcll(__ballot(key[e] < trial));
     if (c < ksel) T = trial;
   }
   // survivors: key <= T (ties at T all stay; if that overflows the row the caller re-ranks)
   int base = 0;
   float thr = INFINITY;
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
+  for (int e = 0; e < K16_SLOTS; ++e) {
     const bool keep = key[e] <= T && (lane + 64 * e) < n;
     const unsigned long long b = __ballot(keep);
     if (keep) {
@@ -108,10 +113,10 @@ __device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__
 __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restrict__ d2row, int* __restrict__ idxrow,
                                float* sd, int* si, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float d[3];
-  int ix[3];
+  float d[K16_SLOTS];
+  int ix[K16_SLOTS];
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
+  for (int e = 0; e < K16_SLOTS; ++e) {
     const int p = lane + 64 * e;
     if (p < n) {
       d[e] = ld_sc1_f(d2row + p);
@@ -124,15 +129,17 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
     si[p] = ix[e];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int rk[3] = {0, 0, 0};
+  int rk[K16_SLOTS];
+#pragma unroll
+  for (int q = 0; q < K16_SLOTS; ++q) rk[q] = 0;
   for (int e = 0; e < n; ++e) {
     const float de = sd[e];
     const int ie = si[e];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) rk[q] += (de < d[q] || (de == d[q] && ie < ix[q])) ? 1 : 0;
+    for (int q = 0; q < K16_SLOTS; ++q) rk[q] += (de < d[q] || (de == d[q] && ie < ix[q])) ? 1 : 0;
   }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < K16_SLOTS; ++q) {
     const int p = lane + 64 * q;
     if (p < n && rk[q] < ksel) {
       d2row[rk[q]] = d[q] * out_scale;
@@ -143,7 +150,7 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
 }
 
 template <int KB>  // 16-deep K blocks: KP16 = 16 * KB >= d + 2
-__global__ __launch_bounds__(K16_THREADS, 2) void knn16_topk_kernel(
+__global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_kernel(
     const _Float16* __restrict__ Q16, const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
     int n_ref, int n_tiles, int ksel, int cap, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
     int* __restrict__ cand_cnt) {
@@ -151,12 +158,12 @@ __global__ __launch_bounds__(K16_THREADS, 2) void knn16_topk_kernel(
   constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
   constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (KB / 2, or 0 + tail)
   constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;
-  static_assert(NV <= 4, "tile too large for the staging registers");
+  static_assert(NV <= 8, "tile too large for the staging registers");
 
   __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
-  __shared__ int lds_cnt[8][64];
-  __shared__ float lds_sd[8][K16_CAPMAX];
-  __shared__ int lds_si[8][K16_CAPMAX];
+  __shared__ int lds_cnt[K16_NWAVE][64];
+  __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
+  __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -182,14 +189,18 @@ __global__ __launch_bounds__(K16_THREADS, 2) void knn16_topk_kernel(
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   const bool tail_ok = HAS_TAIL && (NV * K16_THREADS + tid < TILE_V4);
-  float4 p0, p1, p2, p3, pt;
-  p0 = p1 = p2 = p3 = pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 p0, p1, p2, p3, p4, p5, p6, p7, pt;
+  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = pt = make_float4(0.f, 0.f, 0.f, 0.f);
 #define K16_LOAD(SRC)                                            \
   do {                                                           \
     if constexpr (NV > 0) p0 = (SRC)[tid + 0 * K16_THREADS];     \
     if constexpr (NV > 1) p1 = (SRC)[tid + 1 * K16_THREADS];     \
     if constexpr (NV > 2) p2 = (SRC)[tid + 2 * K16_THREADS];     \
     if constexpr (NV > 3) p3 = (SRC)[tid + 3 * K16_THREADS];     \
+    if constexpr (NV > 4) p4 = (SRC)[tid + 4 * K16_THREADS];     \
+    if constexpr (NV > 5) p5 = (SRC)[tid + 5 * K16_THREADS];     \
+    if constexpr (NV > 6) p6 = (SRC)[tid + 6 * K16_THREADS];     \
+    if constexpr (NV > 7) p7 = (SRC)[tid + 7 * K16_THREADS];     \
     if (tail_ok) pt = (SRC)[tid + NV * K16_THREADS];             \
   } while (0)
 #define K16_STORE(DST)                                           \
@@ -198,6 +209,10 @@ __global__ __launch_bounds__(K16_THREADS, 2) void knn16_topk_kernel(
     if constexpr (NV > 1) (DST)[tid + 1 * K16_THREADS] = p1;     \
     if constexpr (NV > 2) (DST)[tid + 2 * K16_THREADS] = p2;     \
     if constexpr (NV > 3) (DST)[tid + 3 * K16_THREADS] = p3;     \
+    if constexpr (NV > 4) (DST)[tid + 4 * K16_THREADS] = p4;     \
+    if constexpr (NV > 5) (DST)[tid + 5 * K16_THREADS] = p5;     \
+    if constexpr (NV > 6) (DST)[tid + 6 * K16_THREADS] = p6;     \
+    if constexpr (NV > 7) (DST)[tid + 7 * K16_THREADS] = p7;     \
     if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;             \
   } while (0)
   K16_LOAD(R4);

@@ -204,7 +204,7 @@ using namespace meld;
 
 extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                                const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                               int knn, double decay, double thresh, const float* norm2_max, double err_coef,
+                               int cap, int knn, double decay, double thresh, const float* norm2_max, double err_coef,
                                double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                                meld_stream_t stream) {
@@ -213,8 +213,7 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N && d > 0, "meld_knn_refine: bad sizes");
   MELD_CHECK_ARG(ksel >= 1 && ksel <= 128, "meld_knn_refine: ksel=%d outside [1,128]", ksel);
   MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
-  const int cap = meld_knn_row_capacity(ksel);
-  if (cap < 0) return cap;
+  MELD_CHECK_ARG(cap >= ksel, "meld_knn_refine: row stride cap=%d smaller than ksel=%d", cap, ksel);
   MELD_CHECK_ARG(err_coef >= 0, "meld_knn_refine: err_coef must be non-negative");
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,

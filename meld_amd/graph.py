@@ -294,7 +294,7 @@ class HipOps:
             nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
         check(
             lib.meld_knn_refine(
-                ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, knn, float(decay),
+                ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, cap, knn, float(decay),
                 float(thresh), ptr(nmax_used), float(err_coef), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
             ),
             "meld_knn_refine",
@@ -343,7 +343,7 @@ class HipOps:
         if M > 0:
             check(
                 lib.meld_coo_emit(
-                    q_begin, q_count, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, ptr(keep_off), ptr(flag_rows),
+                    q_begin, q_count, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, cap, ptr(keep_off), ptr(flag_rows),
                     n_flag_h, ptr(fb_off), ptr(fb_col), ptr(fb_val), m_main, M, ptr(keys), ptr(vals), st,
                 ),
                 "meld_coo_emit",
