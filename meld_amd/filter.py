@@ -190,9 +190,12 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
         if chebyshev_order is None:
             chebyshev_order = 30  # pygsp's default order
         c = chebyshev_coefficients(h, graph.lmax, chebyshev_order)
-        full = np.zeros((graph.n_pad, sig.shape[1]))
-        full[: graph.N] = sig
-        s_dev = torch.from_numpy(full).to(dev)
+        if graph.n_pad == graph.N:
+            s_dev = torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+        else:  # sharded graph: isolated padding rows at the end
+            full = np.zeros((graph.n_pad, sig.shape[1]))
+            full[: graph.N] = sig
+            s_dev = torch.from_numpy(full).to(dev)
         r = chebyshev_apply(graph, s_dev, c, graph.lmax)
         comm = getattr(graph, "comm", None)
         if comm is not None:
