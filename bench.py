@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA peak
+PEAK_MFMA_F16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured-achievable)
 
 
@@ -172,24 +173,37 @@ def main():
     }
     if "knn_topk" in ev:
         t_knn = float(np.mean(ev["knn_topk"])) * 1e-3
-        rows = N // world if world > 1 else N
+        rows = G.info.get("rows_local", N)
         flops = 2.0 * rows * N * d
+        search = G.info.get("search", "f16x3")
+        if search == "f16x3":
+            kp = 16 * ((d + 2 + 15) // 16)
+            executed = 3 * 2.0 * rows * N * kp  # three split products on the K-padded operands
+            peak, kname = PEAK_MFMA_F16_TFLOPS, "knn16_topk_kernel (split-fp16 hi/lo distance GEMM on v_mfma_f32_32x32x16_f16 + streaming top-k)"
+        else:
+            kp = int(G.info.get("KP", d + 2))
+            executed = 2.0 * rows * N * kp
+            peak, kname = PEAK_MFMA_F32_TFLOPS, "knn_topk_kernel (fp32 MFMA distance GEMM + streaming top-k)"
         out["roofline"] = {
-            "kernel": "knn_topk_kernel (fp32 MFMA distance GEMM + streaming top-k)",
+            "kernel": kname,
             "bound": "mfma",
             "achieved": flops / t_knn / 1e12,
-            "peak": PEAK_MFMA_F32_TFLOPS,
+            "peak": peak,
             "unit": "TFLOP/s",
-            "frac": flops / t_knn / 1e12 / PEAK_MFMA_F32_TFLOPS,
+            "frac": flops / t_knn / 1e12 / peak,
             "traffic": None,
             "algorithmic": "2*Nq*N*d = {:.3e} flop per launch".format(flops),
+            "executed_tflops": executed / t_knn / 1e12,
+            "executed_frac_of_peak": executed / t_knn / 1e12 / peak,
+            "note": "executed = flops issued to the matrix pipe (K padded to {}{}); algorithmic rate is {:.2f}x the "
+            "157.3 TF fp32-MFMA peak".format(kp, ", 3 split-fp16 products" if search == "f16x3" else "", flops / t_knn / 1e12 / PEAK_MFMA_F32_TFLOPS),
             "ms": 1e3 * t_knn,
         }
     if "cheby_steps" in ev:
         t_ch = float(np.mean(ev["cheby_steps"])) * 1e-3
         steps = args.order - 1
-        rows = N // world if world > 1 else N
-        byts = cheby_bytes_per_step(nnz // world if world > 1 else nnz, rows, p)
+        rows = G.info.get("rows_local", N)
+        byts = cheby_bytes_per_step(G.nnz, rows, p)
         out["roofline_cheby"] = {
             "kernel": "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence), {} launches".format(steps),
             "bound": "hbm",
