@@ -186,6 +186,12 @@ int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_
 int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, double* nrm2,
                    meld_stream_t stream);
 
+/* ---- cache-locality ordering helper (no reference counterpart; csrc/reorder.hip) ---------- */
+/* out[i] = index (within its group) of the centroid nearest to X[i]; cents holds n_per_group
+ * centroids per group, group[i] selects the group of point i (NULL = one group). */
+int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
+                        const int32_t* group, int32_t* out, meld_stream_t stream);
+
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */
 int meld_normalize_rows_l1(const double* in, double* out, int64_t n_rows, int p, meld_stream_t stream);

@@ -69,7 +69,14 @@ __global__ __launch_bounds__(256) void cheby_step_kernel(
   __shared__ double s_dot[2][4];
   constexpr int TPR = 256 / RB;
   const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
+  // XCD-contiguous row blocks: workgroup b is dispatched to XCD b % 8 (observed placement; used for
+  // locality only), so XCD x takes the x-th contiguous eighth of the rows and its private 4 MiB L2
+  // keeps the slice of the iterate its rows gather from.
+  const int nb = gridDim.x;
+  const int per = (nb + 7) >> 3;
+  int64_t rb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (rb >= nb) rb = nb;  // padding workgroup of the last XCD: owns no rows
+  const int64_t row0 = min(rb * RB, n_rows);
   if (tid <= RB) s_rowptr[tid] = rowptr[min(row0 + tid, n_rows)];
 
   const int rr = tid / TPR;
@@ -209,7 +216,7 @@ static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double*
                         int ld, int colofs, const double* x_full, int64_t x_row_offset, const double* z, double* y,
                         double* r, double alpha, double beta, double gamma, double coef, double* dots, int chunk,
                         hipStream_t st) {
-  const unsigned grid = (unsigned)ceil_div(n_rows, RB);
+  const unsigned grid = (unsigned)(ceil_div(ceil_div(n_rows, RB), 8) * 8);  // multiple of 8: bijective XCD remap
   const size_t lds = sizeof(double) * (size_t)chunk * P;
   hipLaunchKernelGGL((cheby_step_kernel<P, RB>), dim3(grid), dim3(256), lds, st, rowptr, col, val, dw, n_rows, ld,
                      colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma, coef, dots, chunk);

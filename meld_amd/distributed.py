@@ -81,10 +81,19 @@ def shard_range(N, world, rank):
     return R, begin, end - begin
 
 
-def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None):
-    """Every rank holds the full ``X`` [N, d] (fp64, on its device) and builds the rows it owns."""
+def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, reorder=True):
+    """Every rank holds the full ``X`` [N, d] (fp64, on its device) and builds the rows it owns.
+    With ``reorder`` every rank computes the same (deterministic) locality permutation and shards
+    the permuted cells, so a rank's rows are spatially coherent."""
     N, d = int(X.shape[0]), int(X.shape[1])
     knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
+    perm = None
+    if reorder and X.is_cuda:
+        from .reorder import locality_permutation
+
+        perm = locality_permutation(X)
+        if perm is not None:
+            X = X.index_select(0, perm)
     R, r0, n_loc = shard_range(N, comm.world, comm.rank)
     dev = X.device
 
@@ -128,6 +137,7 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
     G.comm = comm
     G.ops = ops
     G.bandwidth = bw
+    G.perm = perm
     return G
 
 

@@ -190,19 +190,24 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
         if chebyshev_order is None:
             chebyshev_order = 30  # pygsp's default order
         c = chebyshev_coefficients(h, graph.lmax, chebyshev_order)
-        if graph.n_pad == graph.N:
-            s_dev = torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
-        else:  # sharded graph: isolated padding rows at the end
-            full = np.zeros((graph.n_pad, sig.shape[1]))
-            full[: graph.N] = sig
-            s_dev = torch.from_numpy(full).to(dev)
+        s_dev = torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+        perm = getattr(graph, "perm", None)
+        if perm is not None:  # device arrays live in the locality order
+            s_dev = s_dev.index_select(0, perm)
+        if graph.n_pad != graph.N:  # sharded graph: isolated padding rows at the end
+            s_dev = torch.cat([s_dev, torch.zeros(graph.n_pad - graph.N, s_dev.shape[1], dtype=s_dev.dtype, device=dev)])
         r = chebyshev_apply(graph, s_dev, c, graph.lmax)
         comm = getattr(graph, "comm", None)
         if comm is not None:
             r_full = torch.empty_like(s_dev)
             comm.all_gather_rows(r_full, r)
             r = r_full
-        out = r.cpu().numpy()[: graph.N]
+        r = r[: graph.N]
+        if perm is not None:
+            r_orig = torch.empty_like(r)
+            r_orig[perm] = r
+            r = r_orig
+        out = r.cpu().numpy()
     elif solver == "exact":
         from .dense import exact_filter
 

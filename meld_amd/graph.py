@@ -116,6 +116,11 @@ class DeviceGraph:
         self.n_pad = self.N  # global rows incl. padding
         self.comm = None
         self.ops = None
+        # cache-locality permutation (device int64, new -> old index) or None: the device arrays are
+        # in the permuted order, every host-facing export and the filter input/output use the
+        # caller's original order
+        self.perm = None
+        self.bandwidth = None
 
     @classmethod
     def from_scipy(cls, W, device="cuda"):
@@ -160,13 +165,31 @@ class DeviceGraph:
         self.lmax_info = info
         return self._lmax
 
-    # -- host exports (tests / inspection; not used by the hot path) -----------------------------
+    # -- host exports in the caller's cell order (tests / inspection; not used by the hot path) -----
+    def _inv_perm_host(self):
+        if self.perm is None:
+            return None
+        p = self.perm.cpu().numpy()
+        inv = np.empty_like(p)
+        inv[p] = np.arange(p.shape[0])
+        return inv
+
     def _scipy(self, vals):
         from scipy import sparse
 
-        return sparse.csr_matrix(
-            (vals, self.col.cpu().numpy(), self.rowptr.cpu().numpy()), shape=(self.n_rows, self.N)
-        )
+        M = sparse.csr_matrix((vals, self.col.cpu().numpy(), self.rowptr.cpu().numpy()[: self.n_rows + 1]), shape=(self.n_rows, self.N))
+        inv = self._inv_perm_host()
+        if inv is not None:
+            if self.n_rows != self.N:
+                raise ValueError("host export of a sharded, permuted graph is not supported")
+            M = M[inv][:, inv].tocsr()
+            M.sort_indices()
+        return M
+
+    def _vec_host(self, t):
+        v = t.cpu().numpy()
+        inv = self._inv_perm_host()
+        return v if inv is None or v.shape[0] != inv.shape[0] else v[inv]
 
     @property
     def W(self):
@@ -174,7 +197,11 @@ class DeviceGraph:
 
     @property
     def dw(self):
-        return self.dw_dev.cpu().numpy()
+        return self._vec_host(self.dw_dev)
+
+    @property
+    def bandwidth_host(self):
+        return None if self.bandwidth is None else self._vec_host(self.bandwidth)
 
     @property
     def L(self):
@@ -191,7 +218,7 @@ class DeviceGraph:
 
         if self.n_rows != self.N:
             raise ValueError("K is only defined for an unsharded graph")
-        ks = self.ksum.cpu().numpy()
+        ks = self._vec_host(self.ksum)
         diag = 1.0 / (ks * ks) ** self.anisotropy
         return (self.W + sparse.diags(diag, 0)).tocsr()
 
@@ -426,7 +453,8 @@ def resolve_graph_params(N, knn, thresh, ksel):
     return int(knn), thresh, int(ksel)
 
 
-def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False):
+def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
+                    reorder=True):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -441,6 +469,16 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     ops = HipOps(X.device)
     tm = _Timer(profile)
     knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
+
+    perm = None
+    if reorder:
+        from .reorder import locality_permutation
+
+        tm.start()
+        perm = locality_permutation(X)
+        if perm is not None:
+            X = X.index_select(0, perm)
+        tm.stop("reorder")
 
     keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback)
     if keys.shape[0] == 0:
@@ -458,4 +496,6 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     info.update(N=N, d=d, knn=knn, nnz=nnz, mean_degree=nnz / N, stage_seconds=dict(tm.t))
     G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=info)
     G.bandwidth = bw
+    G.perm = perm
+    G.ops = ops
     return G

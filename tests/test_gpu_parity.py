@@ -131,7 +131,7 @@ def test_graph_matches_oracle(n, d, knn):
     _csr_close(DG.W, G.W, rtol=1e-9)
     np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
     _csr_close(DG.K, G.K, rtol=1e-9)
-    np.testing.assert_allclose(DG.bandwidth.cpu().numpy(), G.info["bandwidth"], rtol=1e-12)
+    np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
 
 
 def test_graph_exact_sweep_path_matches_main_path():
@@ -179,6 +179,11 @@ def test_fit_transform_parity_50k_config_scaled():
     op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, lmax=G.lmax)
     out = op.fit_transform(X, labels)
     assert out.shape == dens.shape
+    # N >= 8192: the device arrays are in the cache-locality order; exports come back in input order
+    assert op.graph.perm is not None and sorted(op.graph.perm.cpu().tolist()) == list(range(20000))
+    _csr_close(op.graph.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
     for c in range(dens.shape[1]):
         assert np.abs(out.values[:, c] - dens[:, c]).max() / np.abs(dens[:, c]).max() < 1e-5
     np.testing.assert_allclose(out.values, dens, rtol=1e-5, atol=1e-5 * dens.max())
@@ -326,3 +331,24 @@ def test_both_search_kernels_build_the_same_graph():
         assert info["search"] == search
     for a, b in zip(graphs["f32"], graphs["f16x3"]):
         assert torch.equal(a, b)
+
+
+def test_locality_reordering_does_not_change_results():
+    """The permutation is a memory-layout decision only: identical graph and densities (to
+    rounding: summation order inside a row changes) with and without it."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(12000, n_dims=50, seed=21)
+    Xd = torch.from_numpy(X).cuda()
+    A = meld_amd.build_knn_graph(Xd, knn=15, reorder=True)
+    B = meld_amd.build_knn_graph(Xd, knn=15, reorder=False)
+    assert A.perm is not None and B.perm is None
+    _csr_close(A.W, B.W, rtol=1e-13)
+    A.lmax = B.lmax = 0.11
+    samples, ind = mo.sample_indicators(labels)
+    from meld_amd.filter import filter as mfilter
+
+    da = mfilter(ind, A, "heat", 60, chebyshev_order=30)
+    db = mfilter(ind, B, "heat", 60, chebyshev_order=30)
+    assert np.abs(da - db).max() / np.abs(db).max() < 1e-12
