@@ -188,9 +188,11 @@ int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, do
 
 /* ---- cache-locality ordering helper (no reference counterpart; csrc/reorder.hip) ---------- */
 /* out[i] = index (within its group) of the centroid nearest to X[i]; cents holds n_per_group
- * centroids per group, group[i] selects the group of point i (NULL = one group). */
+ * centroids per group, group[i] selects the group of point i (NULL = one shared set).  order
+ * (optional, grouped form only) = the points sorted by group: the traversal order that keeps a
+ * wave inside one group. */
 int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
-                        const int32_t* group, int32_t* out, meld_stream_t stream);
+                        const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream);
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */

@@ -64,7 +64,7 @@ SIGNATURES = {
     "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
     "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
-    "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr]),
+    "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
 }
 
 _lib = None

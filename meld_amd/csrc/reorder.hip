@@ -57,13 +57,17 @@ __global__ __launch_bounds__(256) void assign_nearest_shared_kernel(const double
   if (i < N) out[i] = arg;
 }
 
-// out[i] = argmin over the n_per_group centroids of point i's own group (small sets, read through L2)
+// out[i] = argmin over the n_per_group centroids of point i's own group.  Threads walk the points
+// in `order` (points sorted by group), so a wave reads one group's centroids -- a broadcast the L1
+// serves -- and only the point rows themselves are gathered.
 __global__ __launch_bounds__(256) void assign_nearest_grouped_kernel(const double* __restrict__ X, int64_t N, int d,
                                                                      const double* __restrict__ cents, int n_per_group,
                                                                      const int* __restrict__ group,
+                                                                     const int64_t* __restrict__ order,
                                                                      int* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int64_t i = order ? order[t] : t;
   const double* xi = X + i * d;
   const double* cb = cents + (int64_t)group[i] * n_per_group * d;
   float best = INFINITY;
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(256) void assign_nearest_grouped_kernel(const doubl
     const double* cc = cb + (int64_t)c * d;
     float s = 0.0f;
     for (int k = 0; k < d; ++k) {
-      const float t = (float)(xi[k] - cc[k]);
-      s = fmaf(t, t, s);
+      const float t2 = (float)(xi[k] - cc[k]);
+      s = fmaf(t2, t2, s);
     }
     if (s < best) {
       best = s;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void assign_nearest_grouped_kernel(const doubl
 using namespace meld;
 
 extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
-                                   const int32_t* group, int32_t* out, meld_stream_t stream) {
+                                   const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cents && out && N > 0 && d > 0 && n_per_group > 0, "meld_assign_nearest: bad arguments");
   if (group == nullptr) {
     MELD_CHECK_ARG(d <= AS_DMAX, "meld_assign_nearest: d=%d exceeds %d", d, AS_DMAX);
@@ -96,7 +100,7 @@ extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const doub
                        d, cents, n_per_group, out);
   } else {
     hipLaunchKernelGGL(assign_nearest_grouped_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, S(stream), X, N,
-                       d, cents, n_per_group, group, out);
+                       d, cents, n_per_group, group, order, out);
   }
   MELD_LAUNCH_CHECK("assign_nearest_kernel");
   return MELD_OK;

@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void cheby_step_kernel(
       for (int u = 0; u < 4; ++u) {
         const int64_t e = eb + u * 256;
         const bool ok = e < ce;
-        v[u] = ok ? val[e] : 0.0;
-        j[u] = ok ? col[e] : 0;
+        // streamed once: non-temporal loads keep the CSR arrays out of the L1 the gathers live in
+        v[u] = ok ? __builtin_nontemporal_load(val + e) : 0.0;
+        j[u] = ok ? __builtin_nontemporal_load(col + e) : 0;
       }
       Vec<P> xj[4];
 #pragma unroll

@@ -19,22 +19,24 @@ __all__ = ["locality_permutation"]
 
 
 def _chain_order_batched(P):
-    """Greedy nearest-neighbour chain over the rows of every P[b] ([B, m, d]) -> rank [B, m]
-    (rank of each row along its chain).  Vectorised over the batch: m numpy steps."""
+    """Greedy nearest-neighbour chain over the rows of every P[b] (torch [B, m, d], any device)
+    -> rank [B, m] int64: position of each row along its chain.  m vectorised steps, no host sync."""
     B, m, _ = P.shape
-    rank = np.zeros((B, m), dtype=np.int64)
+    dev = P.device
+    rank = torch.zeros(B, m, dtype=torch.int64, device=dev)
     if m <= 2:
-        rank[:] = np.arange(m)
+        rank[:] = torch.arange(m, device=dev)
         return rank
-    D = ((P[:, :, None, :] - P[:, None, :, :]) ** 2).sum(-1)  # [B, m, m]
-    ar = np.arange(B)
-    cur = np.argmin(P[:, :, 0], axis=1)  # start from an extreme point along the first coordinate
-    used = np.zeros((B, m), dtype=bool)
+    Pf = P.to(torch.float32)
+    D = torch.cdist(Pf, Pf)  # [B, m, m]
+    ar = torch.arange(B, device=dev)
+    cur = torch.argmin(Pf[:, :, 0], dim=1)  # start from an extreme point along the first coordinate
+    used = torch.zeros(B, m, dtype=torch.bool, device=dev)
     used[ar, cur] = True
-    rank[ar, cur] = 0
+    inf = torch.full((), float("inf"), device=dev)
     for step in range(1, m):
-        row = np.where(used, np.inf, D[ar, cur])
-        cur = np.argmin(row, axis=1)
+        row = torch.where(used, inf, D[ar, cur])
+        cur = torch.argmin(row, dim=1)
         used[ar, cur] = True
         rank[ar, cur] = step
     return rank
@@ -44,37 +46,61 @@ def _chain_order(P):
     return _chain_order_batched(P[None])[0]
 
 
-def locality_permutation(X, c1=None, c2=16, seed=0):
-    """X: CUDA fp64 [N, d].  Returns perm (device int64 [N]) or None when N is too small to matter."""
+def _split_level(X, lib, st, group, n_groups, fanout):
+    """One refinement level: every group of cells gets `fanout` sub-centroids (evenly spaced
+    members), every cell its nearest one.  Returns (child id within group [N] int64, rank of each
+    child along its group's chain [n_groups, fanout])."""
+    N, d = int(X.shape[0]), int(X.shape[1])
+    dev = X.device
+    order = torch.argsort(group, stable=True)
+    counts = torch.bincount(group, minlength=n_groups)
+    starts = torch.cumsum(counts, 0) - counts
+    frac = (torch.arange(fanout, device=dev, dtype=torch.float64) + 0.5) / fanout
+    pick = starts[:, None] + (frac[None, :] * counts[:, None].to(torch.float64)).to(torch.int64)
+    pick = torch.minimum(pick, (starts + torch.clamp(counts - 1, min=0))[:, None]).clamp_(0, N - 1)
+    cents = X.index_select(0, order[pick.reshape(-1)]).contiguous()  # [n_groups * fanout, d]
+    child = torch.empty(N, dtype=torch.int32, device=dev)
+    g32 = group.to(torch.int32)
+    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
+    rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
+    return child.to(torch.int64), rank
+
+
+def locality_permutation(X, c1=None, fanouts=(16,), seed=0):
+    """X: CUDA fp64 [N, d].  Returns perm (device int64 [N]) or None when N is too small to matter.
+
+    Level 0: nearest of c1 (<= 64) random cells (coarse cells, ordered by a chain); each further
+    level splits every group into `fanout` children by nearest sub-centroid, while leaves keep >= 4
+    cells on average.  Measured at 1M cells (Chebyshev step / cost of building the permutation):
+    (64;16) 226 us / 12 ms, (64;16,16) 209 us / 19 ms, (16;16,16,16) 204 us / 24 ms, none 580 us --
+    finer leaves buy little in a 10-d intrinsic geometry, so the default stops at ~1000-cell leaves: consecutive rows are mutual near neighbours, and a
+    128-byte line of the iterate (8 rows) holds cells that the same row block gathers again."""
     lib = get_lib()
     N, d = int(X.shape[0]), int(X.shape[1])
     if N < 8192:
         return None
+    import os
+
+    if os.environ.get("MELD_REORDER"):  # tuning hook: "c1,f1,f2,..."
+        parts = [int(v) for v in os.environ["MELD_REORDER"].split(",")]
+        c1, fanouts = parts[0], tuple(parts[1:])
     st = torch.cuda.current_stream().cuda_stream
     dev = X.device
     if c1 is None:
-        c1 = int(min(1024, max(16, N // 4096)))  # ~256 leaves' worth of cells per coarse cell at most
+        c1 = int(min(64, max(8, N // 4096)))
     rng = np.random.default_rng(seed)
     idx1 = torch.from_numpy(np.sort(rng.choice(N, size=c1, replace=False))).to(dev)
     cents1 = X.index_select(0, idx1).contiguous()
     a1 = torch.empty(N, dtype=torch.int32, device=dev)
-    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents1), c1, None, ptr(a1), st), "meld_assign_nearest")
-    rank1 = torch.from_numpy(_chain_order(cents1.cpu().numpy())).to(dev)
-
-    # sub-centroids: c2 evenly spaced members of every coarse cell (cells sorted by coarse id)
-    order1 = torch.argsort(a1.to(torch.int64), stable=True)
-    counts = torch.bincount(a1.to(torch.int64), minlength=c1)
-    starts = torch.cumsum(counts, 0) - counts
-    frac = (torch.arange(c2, device=dev, dtype=torch.float64) + 0.5) / c2
-    pick = starts[:, None] + torch.clamp((frac[None, :] * counts[:, None].to(torch.float64)).to(torch.int64), max=N - 1)
-    pick = torch.minimum(pick, (starts + torch.clamp(counts - 1, min=0))[:, None])  # empty cells cannot occur (own centroid)
-    sub_idx = order1[pick.reshape(-1)]
-    cents2 = X.index_select(0, sub_idx).contiguous()  # [c1 * c2, d]
-    a2 = torch.empty(N, dtype=torch.int32, device=dev)
-    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents2), c2, ptr(a1), ptr(a2), st), "meld_assign_nearest")
-    c2h = cents2.cpu().numpy().reshape(c1, c2, d)
-    rank2 = torch.from_numpy(_chain_order_batched(c2h)).to(dev)  # [c1, c2]
-
-    a1l, a2l = a1.to(torch.int64), a2.to(torch.int64)
-    key = rank1[a1l] * c2 + rank2[a1l, a2l]
+    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents1), c1, None, None, ptr(a1), st), "meld_assign_nearest")
+    key = _chain_order(cents1)[a1.to(torch.int64)]  # order of the coarse cell of every point
+    group = a1.to(torch.int64)
+    n_groups = c1
+    for f in fanouts:
+        if N // (n_groups * f) < 4:
+            break
+        child, rank = _split_level(X, lib, st, group, n_groups, f)
+        key = key * f + rank[group, child]
+        group = group * f + child
+        n_groups *= f
     return torch.argsort(key, stable=True)
