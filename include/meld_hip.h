@@ -86,9 +86,21 @@ double meld_knn16_error_coef(void);
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
+/* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_workgroups][n_tiles] with a lower
+ * bound (bounding spheres + triangle inequality, scaled space) on the squared distance between
+ * any query of a workgroup (BQ consecutive queries) and any reference of a tile (TS consecutive
+ * references).  meld_knn16_topk skips -- without loading it -- every tile whose bound exceeds all
+ * thresholds of the workgroup plus the search-error allowance, which cannot change the result.
+ * It pays when consecutive cells are spatially close (meld_assign_nearest ordering).
+ * lb2 = NULL disables pruning.  q_begin = global index of query 0 (the scan of every workgroup
+ * starts at its own position among the references and wraps around). */
+size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
+size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
+int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                      int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream);
 int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                    int64_t q_count, int ksel, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                    meld_stream_t stream);
+                    int64_t q_count, int ksel, const float* lb2, const float* norm2_max, int64_t q_begin,
+                    int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
 
 /* ---- exact re-evaluation + alpha-decay kernel (replaces [UPSTREAM graphtools
  *      kNNGraph.build_kernel_to_data, "affinities" block]) ---------------------------------- */

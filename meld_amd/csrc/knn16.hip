@@ -152,11 +152,12 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
 template <int KB>  // 16-deep K blocks: KP16 = 16 * KB >= d + 2
 __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_kernel(
     const _Float16* __restrict__ Q16, const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
-    int n_ref, int n_tiles, int ksel, int cap, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
+    int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
+    float err_coef, int tile_origin, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
     int* __restrict__ cand_cnt) {
   constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
   constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
-  constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (KB / 2, or 0 + tail)
+  constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (= KB)
   constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;
   static_assert(NV <= 8, "tile too large for the staging registers");
 
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   __shared__ int lds_cnt[K16_NWAVE][64];
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
+  __shared__ float lds_wthr[2][K16_NWAVE];  // per-wave max threshold, double-buffered by step parity
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -185,7 +187,34 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   }
 
   lds_cnt[wave][lane] = 0;
+  if (lane == 0) lds_wthr[0][wave] = lds_wthr[1][wave] = INFINITY;
   float thr[2] = {INFINITY, INFINITY};
+  float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
+
+  // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
+  // the cells are in locality order) and wrapping around: step s -> tile (t0 + s) mod n_tiles.
+  // lb2 (optional) holds, per (workgroup, tile), a lower bound on the squared distance between
+  // any query of the workgroup and any reference of the tile; a tile whose bound exceeds every
+  // threshold of the workgroup cannot contribute a candidate and is skipped without being loaded.
+  // search-error allowance in the scaled space: a skipped tile must fail `d2_approx < thr` for sure
+  const float prune_margin = lb2 ? err_coef * norm2_max[0] * scale_info[0] * scale_info[0] : 0.0f;
+  const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_tiles);
+  const float* my_lb = lb2 ? lb2 + (size_t)blockIdx.x * n_tiles : nullptr;
+  auto tile_of = [&](int s) {
+    const int t = t0 + s;
+    return t >= n_tiles ? t - n_tiles : t;
+  };
+  // first step >= s whose tile may hold a candidate given the block-wide threshold bound
+  auto next_live = [&](int s, float bound) {
+    if (my_lb == nullptr) return s;
+    for (int base = s; base < n_tiles; base += 64) {
+      const int ss = base + lane;
+      const bool live = ss < n_tiles && my_lb[tile_of(ss)] <= bound;
+      const unsigned long long b = __ballot(live);
+      if (b) return base + (int)__ffsll((long long)b) - 1;
+    }
+    return n_tiles;
+  };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   const bool tail_ok = HAS_TAIL && (NV * K16_THREADS + tid < TILE_V4);
@@ -215,16 +244,26 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
     if constexpr (NV > 7) (DST)[tid + 7 * K16_THREADS] = p7;     \
     if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;             \
   } while (0)
-  K16_LOAD(R4);
+  {
+    const float4* src = R4 + (size_t)tile_of(0) * TILE_V4;
+    K16_LOAD(src);
+  }
   K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
   __syncthreads();
 
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) {
-      const float4* src = R4 + (size_t)(t + 1) * TILE_V4;
+  int s_cur = 0;
+  int cur = 0;
+  int par = 0;
+  while (s_cur < n_tiles) {
+    // block-uniform bound: every wave reads the values published before the last barrier
+    float bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3]));
+    bound += prune_margin;
+    const int s_next = next_live(s_cur + 1, bound);
+    if (s_next < n_tiles) {
+      const float4* src = R4 + (size_t)tile_of(s_next) * TILE_V4;
       K16_LOAD(src);
     }
+    const int t = tile_of(s_cur);
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -271,30 +310,40 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
           }
           const int c = __hip_atomic_load(cntp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           unsigned long long need = __ballot(h == 0 && c > cap - 32);
-          while (need) {
-            const int j = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            int* cj = &lds_cnt[wave][g * 32 + j];
-            const int n = min(__hip_atomic_load(cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
-            const size_t ro = (size_t)(q_base + g * 32 + j) * cap;
-            int n_new;
-            float nt = knn16_squeeze_row(n, ksel, cap, cand_d2 + ro, cand_idx + ro, lane, &n_new);
-            if (n_new > cap - 32) {
-              // pathological ties at the threshold: rank the row down to exactly ksel entries
-              knn16_rank_row(n_new, ksel, 1.0f, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
-              n_new = min(n_new, ksel);
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              nt = ld_sc1_f(cand_d2 + ro + n_new - 1);
+          if (need) {
+            while (need) {
+              const int j = __ffsll((long long)need) - 1;
+              need &= need - 1;
+              int* cj = &lds_cnt[wave][g * 32 + j];
+              const int n = min(__hip_atomic_load(cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
+              const size_t ro = (size_t)(q_base + g * 32 + j) * cap;
+              int n_new;
+              float nt = knn16_squeeze_row(n, ksel, cap, cand_d2 + ro, cand_idx + ro, lane, &n_new);
+              if (n_new > cap - 32) {
+                // pathological ties at the threshold: rank the row down to exactly ksel entries
+                knn16_rank_row(n_new, ksel, 1.0f, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
+                n_new = min(n_new, ksel);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                nt = ld_sc1_f(cand_d2 + ro + n_new - 1);
+              }
+              if (lane == 0) *cj = n_new;
+              if (jq == j) thr[g] = (n >= ksel) ? nt : INFINITY;
             }
-            if (lane == 0) *cj = n_new;
-            if (jq == j) thr[g] = (n >= ksel) ? nt : INFINITY;
+            float w = fmaxf(thr[0], thr[1]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
+            wmax = w;
           }
         }
       }
     }
 
-    if (t + 1 < n_tiles) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    if (s_next < n_tiles) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    if (lane == 0) lds_wthr[par ^ 1][wave] = wmax;
     __syncthreads();
+    s_cur = s_next;
+    cur ^= 1;
+    par ^= 1;
   }
 
   // final: sort every row, convert back to input units, publish its length
@@ -308,6 +357,72 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   }
 #undef K16_LOAD
 #undef K16_STORE
+}
+
+// ---------------------------------------------------------------------------------------------
+// pruning bounds: bounding spheres of reference tiles / query workgroups in the scaled space
+// ---------------------------------------------------------------------------------------------
+// One wave per group of `gsize` (<= 256, multiple of 64 or the 64-ref tile) consecutive points
+// [first + g*gsize, ...) clipped to [0, n_pts): centre = mean, radius = max distance to it.
+// centres are written transposed ([k][group]) so that the table kernel reads them coalesced.
+__global__ __launch_bounds__(64) void group_spheres_kernel(const double* __restrict__ X, int64_t n_pts, int d,
+                                                           const double* __restrict__ mean,
+                                                           const float* __restrict__ scale_info, int64_t first,
+                                                           int gsize, int n_groups, float* __restrict__ centre_t,
+                                                           float* __restrict__ radius) {
+  const int g = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float s = scale_info[0];
+  const int64_t b = first + (int64_t)g * gsize;
+  const int64_t e = min(b + gsize, n_pts);
+  const int cnt = (int)max((int64_t)0, e - b);
+  // pass 1: centre
+  for (int k = 0; k < d; ++k) {
+    float acc = 0.0f;
+    for (int64_t i = b + lane; i < e; i += 64) acc += s * (float)(X[i * d + k] - mean[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) centre_t[(size_t)k * n_groups + g] = cnt ? acc / (float)cnt : 0.0f;
+  }
+  __syncthreads();
+  // pass 2: radius
+  float r2 = 0.0f;
+  for (int64_t i = b + lane; i < e; i += 64) {
+    float acc = 0.0f;
+    for (int k = 0; k < d; ++k) {
+      const float t = s * (float)(X[i * d + k] - mean[k]) - centre_t[(size_t)k * n_groups + g];
+      acc = fmaf(t, t, acc);
+    }
+    r2 = fmaxf(r2, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+  if (lane == 0) radius[g] = cnt ? sqrtf(r2) * 1.0001f + 1e-30f : -1.0f;  // -1: empty group
+}
+
+// lb2[qb][t] = max(0, |cq - ct| (1 - eps) - rq - rt)^2 ; empty tiles get +inf (always pruned)
+__global__ __launch_bounds__(256) void bounds_table_kernel(const float* __restrict__ cq_t, const float* __restrict__ rq,
+                                                           int n_qb, const float* __restrict__ ct_t,
+                                                           const float* __restrict__ rt, int n_tiles, int d,
+                                                           float* __restrict__ lb2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int qb = blockIdx.y;
+  if (t >= n_tiles) return;
+  float acc = 0.0f;
+  for (int k = 0; k < d; ++k) {
+    const float df = cq_t[(size_t)k * n_qb + qb] - ct_t[(size_t)k * n_tiles + t];
+    acc = fmaf(df, df, acc);
+  }
+  float out;
+  if (rt[t] < 0.0f) {
+    out = INFINITY;
+  } else if (rq[qb] < 0.0f) {
+    out = 0.0f;
+  } else {
+    const float lb = sqrtf(acc) * 0.9999f - rq[qb] - rt[t];
+    out = lb > 0.0f ? lb * lb : 0.0f;
+  }
+  lb2[(size_t)qb * n_tiles + t] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,10 +568,40 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
   return MELD_OK;
 }
 
+extern "C" size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count) {
+  return (size_t)ceil_div(q_count, K16_BQ) * (size_t)ceil_div(n_ref, K16_TS) * sizeof(float);
+}
+extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count) {
+  const size_t n_t = (size_t)ceil_div(n_ref, K16_TS), n_q = (size_t)ceil_div(q_count, K16_BQ);
+  return sizeof(float) * ((n_t + n_q) * (size_t)(d + 1)) + 256;
+}
+
+extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                 int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && scale_info && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 && q_begin + q_count <= N,
+                 "meld_knn16_bounds: bad arguments");
+  const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(q_count, K16_BQ);
+  float* ct = reinterpret_cast<float*>(temp);
+  float* rt = ct + (size_t)n_t * d;
+  float* cq = rt + n_t;
+  float* rq = cq + (size_t)n_q * d;
+  hipStream_t st = S(stream);
+  hipLaunchKernelGGL(group_spheres_kernel, dim3(n_t), dim3(64), 0, st, X, N, d, mean, scale_info, (int64_t)0, K16_TS, n_t,
+                     ct, rt);
+  hipLaunchKernelGGL(group_spheres_kernel, dim3(n_q), dim3(64), 0, st, X, q_begin + q_count, d, mean, scale_info, q_begin,
+                     K16_BQ, n_q, cq, rq);
+  hipLaunchKernelGGL(bounds_table_kernel, dim3((unsigned)ceil_div(n_t, 256), n_q), dim3(256), 0, st, cq, rq, n_q, ct, rt,
+                     n_t, d, lb2);
+  MELD_LAUNCH_CHECK("meld_knn16_bounds");
+  return MELD_OK;
+}
+
 extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                               int64_t q_count, int ksel, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                               int64_t q_count, int ksel, const float* lb2, const float* norm2_max,
+                               int64_t q_begin, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
                                meld_stream_t stream) {
   MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
+  MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
   const int cap = meld_knn16_row_capacity(ksel);
   if (cap < 0) return cap;
@@ -464,12 +609,14 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   if (KB < 0) return KB;
   const int n_tiles = (int)ceil_div(n_ref, K16_TS);
   const unsigned grid = (unsigned)ceil_div(q_count, K16_BQ);
+  const int tile_origin = (int)((q_begin / K16_TS) % n_tiles);  // the scan starts at the queries' own position
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
 #define K16_CASE(KBV)                                                                                              \
   case KBV:                                                                                                        \
     hipLaunchKernelGGL(knn16_topk_kernel<KBV>, dim3(grid), dim3(K16_THREADS), 0, S(stream), q, r, scale_info,      \
-                       (int)n_ref, n_tiles, ksel, cap, cand_idx, cand_d2, cand_cnt);                               \
+                       (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(), tile_origin, \
+                       cand_idx, cand_d2, cand_cnt);                                                               \
     break;
   switch (KB) {
     K16_CASE(1)

@@ -239,8 +239,10 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device=None, search=None):
+    def __init__(self, device=None, search=None, prune=None):
         self.lib = get_lib()
+        # exact tile pruning in the f16x3 search (only effective when cells are in locality order)
+        self.prune = (os.environ.get("MELD_KNN_PRUNE", "1") != "0") if prune is None else bool(prune)
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
         self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
@@ -282,8 +284,16 @@ class HipOps:
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
             cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+            lb2 = None
+            if self.prune:
+                tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
+                tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
+                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count) // 4, dtype=torch.float32, device=dev)
+                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+            del lb2
             KP = 16 * KB
         else:
             # fp32 operands on v_mfma_f32_32x32x2_f32 (knn.hip)

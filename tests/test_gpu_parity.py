@@ -294,7 +294,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, ptr(ci), ptr(cd), ptr(cc), st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -352,3 +352,25 @@ def test_locality_reordering_does_not_change_results():
     da = mfilter(ind, A, "heat", 60, chebyshev_order=30)
     db = mfilter(ind, B, "heat", 60, chebyshev_order=30)
     assert np.abs(da - db).max() / np.abs(db).max() < 1e-12
+
+
+def test_tile_pruning_is_exact():
+    """Skipping reference tiles by the bounding-sphere lower bound must not change a single
+    candidate: identical graph with and without pruning, on clustered data in locality order
+    (where most tiles are skipped) and on unordered data (where almost none are)."""
+    mo = _oracle()
+    import meld_amd
+    from meld_amd.graph import HipOps
+    from meld_amd.reorder import locality_permutation
+
+    X, _ = mo.synthetic_cells(30000, n_dims=50, seed=31)
+    Xd = torch.from_numpy(X).cuda()
+    for ordered in (True, False):
+        Xs = Xd.index_select(0, locality_permutation(Xd)) if ordered else Xd
+        outs = []
+        for prune in (False, True):
+            ops = HipOps(prune=prune)
+            keys, vals, bw, info = ops.directed_kernel_coo(Xs, 0, 30000, 15, 40, 1e-4, 64)
+            outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
