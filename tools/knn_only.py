@@ -10,6 +10,8 @@ reps = 2
 for n in [int(a) for a in sys.argv[1].split(",")]:
     X, _ = mo.synthetic_cells(n, n_dims=50, seed=0)
     Xd = torch.from_numpy(X).cuda()
+    if os.environ.get('ZERO'):
+        Xd = torch.zeros_like(Xd); Xd[0, 0] = 1.0
     ops = HipOps()
     for r in range(reps):
         mg.record_events(True)
