@@ -1,0 +1,93 @@
+"""Small-N dense side paths of the reference, on the GPU: the ``thresh=0`` "exact" graph and
+``solver="exact"``.
+
+These are O(N^2) memory / O(N^3) time in the reference as well (it uses them at N = 1000 in its
+only known-answer test, ``test/test_meld.py:43-81``); they are not the accelerated hot path.  They
+run on dense PyTorch-ROCm linear algebra (rocBLAS / rocSOLVER ``eigh``) rather than hand-written
+kernels, and exist so that the reference's known-answer test can be replayed through the product.
+
+* ``build_dense_graph``: [UPSTREAM graphtools ``TraditionalGraph.build_kernel``] -- pairwise
+  distances, bandwidth = (knn+1)-th smallest per row (self counted), K = exp(-(d/bw)^decay),
+  NaN -> 1, no threshold; then the same symmetrise / anisotropy / zero-diagonal steps.
+* ``exact_filter``: [UPSTREAM pygsp ``Filter.filter(method='exact')``] -- e, U = eigh(L);
+  lmax <- e[-1] (pygsp overwrites the Lanczos estimate, and the reference's kernel closure reads
+  ``graph.lmax`` afterwards, ``meld/filter.py:45,50``); r = U diag(h(e)) U^T s.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import DeviceGraph
+
+__all__ = ["build_dense_graph", "exact_filter", "DENSE_MAX_N"]
+
+DENSE_MAX_N = 16384
+
+
+def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
+    N = int(X.shape[0])
+    if N > DENSE_MAX_N:
+        raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
+    if knn > N - 2:
+        knn = N - 2
+    X = X.to(torch.float64)
+    D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    D.fill_diagonal_(0.0)
+    bw = torch.kthvalue(D, knn + 1, dim=1).values
+    K = torch.exp(-torch.pow(D / bw[:, None], decay))
+    K = torch.where(torch.isnan(K), torch.ones_like(K), K)
+    K = (K + K.T) / 2
+    if anisotropy != 0:
+        dsum = K.sum(1)
+        K = K / torch.pow(dsum[:, None] * dsum[None, :], anisotropy)
+        ksum = dsum
+    else:
+        ksum = K.sum(1)
+    W = K.clone()
+    W.fill_diagonal_(0.0)
+    nz = W != 0
+    counts = nz.sum(1)
+    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=X.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    idx = torch.nonzero(nz)  # row-major order = CSR order with sorted columns
+    col = idx[:, 1].to(torch.int32).contiguous()
+    val = W[nz].contiguous()
+    dw = W.sum(1).contiguous()
+    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy,
+                    info=dict(N=N, knn=int(knn), dense=True, nnz=int(col.shape[0]), n_flagged_rows=0))
+    G.bandwidth = bw
+    G._kdiag = torch.diagonal(K).clone()
+    return G
+
+
+def exact_filter(graph, sig, kernel_of_lmax):
+    """sig: ndarray [N, p].  Returns ndarray [N, p].  Sets ``graph.lmax`` to the exact e[-1]."""
+    if graph.n_rows != graph.N:
+        raise NotImplementedError("solver='exact' is not available on a sharded graph")
+    N = graph.N
+    if N > DENSE_MAX_N:
+        raise ValueError("solver='exact' needs a dense eigendecomposition; the limit is N <= {}".format(DENSE_MAX_N))
+    dev = graph.val.device
+    rows = torch.repeat_interleave(torch.arange(N, device=dev), graph.rowptr[1 : N + 1] - graph.rowptr[:N])
+    W = torch.zeros(N, N, dtype=torch.float64, device=dev)
+    W[rows, graph.col.to(torch.int64)] = graph.val
+    L = torch.diag(graph.dw_dev) - W
+    e, U = torch.linalg.eigh(L)
+    e = e.clone()
+    if abs(float(e[0])) < 1e-10:
+        e[0] = 0.0
+    lmax = float(e[-1])
+    graph.lmax = lmax
+    h = kernel_of_lmax(lmax)
+    he = torch.from_numpy(np.asarray(h(e.cpu().numpy()), dtype=np.float64)).to(dev)
+    s = torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float64)).to(dev)
+    perm = getattr(graph, "perm", None)
+    if perm is not None:
+        s = s.index_select(0, perm)
+    r = U @ (he[:, None] * (U.T @ s))
+    if perm is not None:
+        out = torch.empty_like(r)
+        out[perm] = r
+        r = out
+    return r.cpu().numpy()

@@ -218,6 +218,8 @@ class DeviceGraph:
 
         if self.n_rows != self.N:
             raise ValueError("K is only defined for an unsharded graph")
+        if getattr(self, "_kdiag", None) is not None:  # dense graph: the diagonal was computed explicitly
+            return (self.W + sparse.diags(self._vec_host(self._kdiag), 0)).tocsr()
         ks = self._vec_host(self.ksum)
         diag = 1.0 / (ks * ks) ** self.anisotropy
         return (self.W + sparse.diags(diag, 0)).tocsr()

@@ -182,3 +182,42 @@ def test_golden_c2_mini():
     out2 = op2.fit_transform(X, labels)
     assert abs(op2.graph.lmax - float(g["lmax"])) / float(g["lmax"]) < 5e-3
     _close(out2.values, g["dens"], tol=2e-3)
+
+
+@pytest.mark.parametrize("filt", ["heat", "laplacian"])
+def test_reference_known_answer_532_through_the_product(filt):
+    """The reference's only known-answer test on this path (test/test_meld.py:43-81), replayed
+    through meld_amd on the GPU: thresh=0 dense graph + solver='exact' -> sum(density['treat'])
+    == 532; plus pointwise agreement with the oracle fixture G1."""
+    meld = _meld()
+    from tests.golden.make_golden import g1_inputs
+
+    data, sample_labels = g1_inputs()
+    op = meld.MELD(verbose=0, knn=20, decay=10, thresh=0, anisotropy=0, filter=filt, solver="exact", sample_normalize=False)
+    densities = op.fit_transform(data, sample_labels)
+    expt_density = densities.iloc[:, 1]
+    assert list(densities.columns) == ["ctrl", "treat"]
+    np.testing.assert_allclose(np.sum(expt_density), 532)
+    g = load("g1_exact_1000x2.npz")
+    _close(densities.values, g["dens_" + filt], tol=1e-8)
+    # reset semantics of the same reference test (:83-93)
+    op.set_params(beta=op.beta + 1)
+    assert op.sample_densities is None
+    op.fit_transform(data, sample_labels)
+    assert op.sample_densities is not None
+    op.set_params(knn=op.knn + 1)
+    assert op.graph is None and op.sample_densities is None
+
+
+def test_exact_solver_on_sparse_graph_matches_chebyshev():
+    meld = _meld()
+    from oracle import meld_oracle as mo
+
+    X, labels = mo.synthetic_cells(1500, n_dims=10, seed=8)
+    op = meld.MELD(knn=8, beta=20, solver="exact")
+    a = op.fit_transform(X, labels)
+    lmax_exact = op.graph.lmax  # the exact solver replaces lmax by the true top eigenvalue, like pygsp
+    lam = float(__import__("scipy.sparse.linalg", fromlist=["eigsh"]).eigsh(op.graph.L, k=1, tol=1e-12, return_eigenvectors=False)[0])
+    assert abs(lmax_exact - lam) / lam < 1e-10
+    b = meld.MELD(knn=8, beta=20, solver="chebyshev", chebyshev_order=120, lmax=lmax_exact).fit_transform(X, labels)
+    assert np.abs(a.values - b.values).max() / np.abs(a.values).max() < 1e-6
