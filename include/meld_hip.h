@@ -82,7 +82,7 @@ int meld_knn16_kblocks(int d);           /* KB = ceil((d+2)/16); <0 if d unsuppo
 int meld_knn16_tile_refs(void);          /* TS */
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
-double meld_knn16_error_coef(void);
+double meld_knn16_error_coef(int nprod);
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
@@ -98,9 +98,19 @@ size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                       int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream);
+/* nprod selects the precision of the coordinate K blocks: 3 = hi.hi + hi.lo + lo.hi (error bound
+ * 2^-16 max|x~|^2), 1 = hi.hi only (half the MFMAs, bound 2^-9 max|x~|^2; rows the looser bound
+ * cannot certify go through meld_knn_radius_exact, so results are identical).  The norm block is
+ * always evaluated with the full split. */
+/* query operands for a list of local rows (rows[i] + q_begin = global index): the re-search of the
+ * rows a reduced-precision first pass could not certify */
+int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                            int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16,
+                            meld_stream_t stream);
 int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                    int64_t q_count, int ksel, const float* lb2, const float* norm2_max, int64_t q_begin,
-                    int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
+                    int64_t q_count, int ksel, int nprod, const float* lb2, const float* norm2_max,
+                    int64_t q_begin, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                    meld_stream_t stream);
 
 /* ---- exact re-evaluation + alpha-decay kernel (replaces [UPSTREAM graphtools
  *      kNNGraph.build_kernel_to_data, "affinities" block]) ---------------------------------- */
@@ -113,12 +123,16 @@ int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, 
  *   keep_cnt[q_count]       : number of kept OFF-DIAGONAL entries (0 for flagged rows)
  *   err_coef                : bound on |d2_search - d2_exact| / norm2_max of the search kernel used
  *                             (meld_knn_error_coef(d) for meld_knn_topk, meld_knn16_error_coef())
- *   n_flag[1]               : atomic counter, zeroed by the caller */
+ *   n_flag[1]               : atomic counter, zeroed by the caller
+ *   rows (optional)         : second-stage form -- candidate row q belongs to local row rows[q]:
+ *                             bw / cand_val / keep_cnt are written at that row, the candidate indices
+ *                             are copied to cand_idx_out (row stride out_cap) and flag_rows receives
+ *                             the local row.  NULL = row q is local row q. */
 int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                     const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
                     int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh, const float* norm2_max, double err_coef, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
-                    meld_stream_t stream);
+                    const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream);
 
 /* Exact fp64 radius search for the flagged rows (the analogue of graphtools' re-search /
  * radius_neighbors fallback).  mode 0: fb_cnt[f] = number of off-diagonal references with

@@ -171,7 +171,8 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <int KB, int ABL>  // KP16 = 16 * KB >= d + 2; ABL: 0 = product, 1 / 3 = profiling ablations
+template <int KB, int ABL, int NPROD>  // KP16 = 16 * KB >= d + 2; ABL: 0 = product, 1 / 3 = profiling ablations;
+                                      // NPROD: split products on the coordinate K blocks (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
 __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_kernel(
     const _Float16* __restrict__ Q16, const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
     int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
-      blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
+      if (NPROD == 3 || kb == KB - 1) blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
     }
   }
 
@@ -296,14 +297,20 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
       const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[cur]) + sub * 32 + jq;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
+        // The last K block carries the norm terms (|x|^2 * 1 + 1 * |y|^2), which cancel against
+        // the cross term and always get the full hi/lo treatment; the coordinate blocks may run
+        // on the hi parts alone (NPROD == 1): error <= 2^-9 max|x~|^2, see meld_knn16_error_coef.
+        const bool full = (NPROD == 3) || (kb == KB - 1);
         const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
-        const f16x8 alo = a8[((kb * 2 + h) * 2 + 1) * K16_TS];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[0][kb], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[1][kb], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[0][kb], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[1][kb], acc1, 0, 0, 0);
+        if (full) {
+          const f16x8 alo = a8[((kb * 2 + h) * 2 + 1) * K16_TS];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[0][kb], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[1][kb], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[0][kb], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[1][kb], acc1, 0, 0, 0);
+        }
       }
 
       const int ref_base = t * K16_TS + sub * 32 + 4 * h;
@@ -532,11 +539,13 @@ __global__ __launch_bounds__(256) void prepare_queries16_kernel(const double* __
                                                                 const double* __restrict__ mean,
                                                                 const float* __restrict__ scale_info, int KB,
                                                                 int64_t q_begin, int64_t q_count, int64_t q_pad,
+                                                                const int* __restrict__ rows,
                                                                 _Float16* __restrict__ Q16) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= q_pad) return;
   const float s = scale_info[0];
-  const int64_t src = q_begin + (q < q_count ? q : q_count - 1);
+  const int64_t qq = q < q_count ? q : q_count - 1;
+  const int64_t src = q_begin + (rows ? (int64_t)rows[qq] : qq);
   const double* xrow = X + src * d;
   const float n = scaled_norm2(xrow, mean, s, d);
   _Float16* row = Q16 + (size_t)q * (KB * 32);
@@ -570,8 +579,18 @@ extern "C" int meld_knn16_row_capacity(int ksel) {
   }
   return ksel + K16_SLACK;
 }
-// bound on |d2_approx - d2_exact| / max_i |x~_i|^2 that meld_knn_refine budgets for
-extern "C" double meld_knn16_error_coef(void) { return 1.52587890625e-05; /* 2^-16 */ }
+// Bound on |d2_approx - d2_exact| / max_i |x~_i|^2 (n_max) that meld_knn_refine budgets for.
+// d2 = sum_c q_c r_c with sum |q_c r_c| <= |x~_q|^2 + |x~_r|^2 + 2 |x~_q||x~_r| <= 4 n_max.
+//   fp32 accumulation of <= 64 products per chain: gamma_64 * 4 n_max = 2^-16 n_max;
+//   nprod = 3: every operand is hi + lo (|v - hi - lo| <= 2^-22 |v|), dropped lo.lo terms
+//              <= 3 * 2^-22 * 4 n_max: total < 2^-15 n_max            (measured: 7.6e-7 n_max)
+//   nprod = 1: coordinate blocks on the fp16 hi parts only:
+//              |q.r - qhi.rhi| <= |qlo.r| + |qhi.rlo| <= 2 * 2^-11 |x~_q| |2 x~_r| <= 2^-9 n_max
+//              (Cauchy-Schwarz); the norm block keeps the full split      (measured: 5.4e-4 n_max)
+extern "C" double meld_knn16_error_coef(int nprod) {
+  const double full = 3.0517578125e-05;  // 2^-15
+  return nprod == 1 ? (0.001953125 + full) : full;
+}
 
 extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                                   int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
@@ -590,8 +609,23 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
                      scale_info, KB, n_pad, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
   const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, st, X, d, mean,
-                     scale_info, KB, q_begin, q_count, q_pad, reinterpret_cast<_Float16*>(Q16));
+                     scale_info, KB, q_begin, q_count, q_pad, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16));
   MELD_LAUNCH_CHECK("meld_knn16_prepare");
+  return MELD_OK;
+}
+
+// Query operands for a list of rows (second search stage); scale_info / mean as produced by
+// meld_knn16_prepare for the same X.
+extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                       int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16,
+                                       meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && scale_info && rows && Q16 && n_rows > 0 && N > 0, "meld_knn16_prepare_rows: bad arguments");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int64_t q_pad = ceil_div(n_rows, K16_BQ) * K16_BQ;
+  hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, S(stream), X, d, mean,
+                     scale_info, KB, q_begin, n_rows, q_pad, rows, reinterpret_cast<_Float16*>(Q16));
+  MELD_LAUNCH_CHECK("meld_knn16_prepare_rows");
   return MELD_OK;
 }
 
@@ -624,9 +658,10 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 }
 
 extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                               int64_t q_count, int ksel, const float* lb2, const float* norm2_max,
+                               int64_t q_count, int ksel, int nprod, const float* lb2, const float* norm2_max,
                                int64_t q_begin, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
                                meld_stream_t stream) {
+  MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
@@ -645,10 +680,17 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   const size_t pad_lds = pad_env ? (size_t)atoi(pad_env) : 0;
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
-#define K16_LAUNCH(KBV, ABLV)                                                                                 \
-  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV>), dim3(grid), dim3(K16_THREADS), pad_lds, S(stream), q, r,  \
-                     scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(), \
+#define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
+  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), dim3(grid), dim3(K16_THREADS), pad_lds, S(stream), q, r,  \
+                     scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
                      tile_origin, cand_idx, cand_d2, cand_cnt)
+#define K16_LAUNCH(KBV, ABLV)        \
+  do {                               \
+    if (nprod == 1)                  \
+      K16_LAUNCH2(KBV, ABLV, 1);     \
+    else                             \
+      K16_LAUNCH2(KBV, ABLV, 3);     \
+  } while (0)
 #define K16_CASE(KBV)                  \
   case KBV:                            \
     if (abl == 1)                      \
@@ -673,6 +715,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   }
 #undef K16_CASE
 #undef K16_LAUNCH
+#undef K16_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_topk_kernel");
   return MELD_OK;
 }

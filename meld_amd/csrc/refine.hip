@@ -37,11 +37,15 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, int ksel, int cap, int knn,
     double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
     double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
-    int* __restrict__ flag_rows, int* __restrict__ n_flag) {
+    int* __restrict__ flag_rows, int* __restrict__ n_flag, const int* __restrict__ rows, int out_cap,
+    int* __restrict__ cand_idx_out) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_count) return;
-  const int64_t gi = q_begin + q;
+  // second-stage call: candidate row q belongs to local row rows[q]; results go to that row and the
+  // candidate indices are copied into the first-stage index array so that later stages see one list
+  const int64_t orow = rows ? (int64_t)rows[q] : q;
+  const int64_t gi = q_begin + orow;
   const int n = min(cand_cnt[q], ksel);
   const double* xi = X + gi * d;
   const size_t ro = (size_t)q * cap;
@@ -105,15 +109,18 @@ __global__ __launch_bounds__(256) void refine_kernel(
       v = decay_kernel(dist[e], bw, decay);
       if (v < thresh || (int64_t)idx[e] == gi) v = 0.0;  // diagonal handled analytically (K_ii = 1)
     }
-    if (c < ksel) cand_val[(size_t)q * ksel + c] = v;
+    if (c < ksel) {
+      cand_val[(size_t)orow * ksel + c] = v;
+      if (cand_idx_out) cand_idx_out[(size_t)orow * out_cap + c] = (c < n) ? idx[e] : 0;
+    }
     kept += __popcll(__ballot(v > 0.0));
   }
   if (lane == 0) {
-    bw_out[q] = bw;
-    keep_cnt[q] = complete ? kept : 0;
+    bw_out[orow] = bw;
+    keep_cnt[orow] = complete ? kept : 0;
     if (!complete) {
       const int pos = atomicAdd(n_flag, 1);
-      flag_rows[pos] = (int)q;
+      flag_rows[pos] = (int)orow;
     }
   }
 }
@@ -207,10 +214,13 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
                                int cap, int knn, double decay, double thresh, const float* norm2_max, double err_coef,
                                double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
-                               meld_stream_t stream) {
+                               const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
                  "meld_knn_refine: null pointer");
-  MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N && d > 0, "meld_knn_refine: bad sizes");
+  MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && d > 0 && (rows != nullptr || q_begin + q_count <= N),
+                 "meld_knn_refine: bad sizes");
+  MELD_CHECK_ARG(rows == nullptr || (cand_idx_out != nullptr && out_cap >= ksel),
+                 "meld_knn_refine: a row list needs cand_idx_out with row stride >= ksel");
   MELD_CHECK_ARG(ksel >= 1 && ksel <= 128, "meld_knn_refine: ksel=%d outside [1,128]", ksel);
   MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
   MELD_CHECK_ARG(cap >= ksel, "meld_knn_refine: row stride cap=%d smaller than ksel=%d", cap, ksel);
@@ -218,7 +228,7 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
                      q_count, cand_idx, cand_d2, cand_cnt, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
-                     err_coef, bw, cand_val, keep_cnt, flag_rows, n_flag);
+                     err_coef, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap, cand_idx_out);
   MELD_LAUNCH_CHECK("refine_kernel");
   return MELD_OK;
 }

@@ -241,8 +241,12 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device=None, search=None, prune=None):
+    def __init__(self, device=None, search=None, prune=None, nprod=None):
         self.lib = get_lib()
+        # precision of the f16x3 search on the coordinate K blocks: 1 = fp16 hi parts only (half the MFMAs,
+        # error bound 2^-9 max|x|^2), 3 = full hi/lo split (2^-16).  Either way the result is exact: rows
+        # the bound cannot certify go through the exact sweep.
+        self.nprod = int(os.environ.get("MELD_KNN_NPROD", "1")) if nprod is None else int(nprod)
         # exact tile pruning in the f16x3 search: off by default -- on the 10-d-intrinsic benchmark mixture
         # the bounding spheres of 64-cell tiles (radius 0.72) dwarf the neighbour radius (0.63), 98 % of
         # the (workgroup, tile) pairs stay live and the table costs 3 ms; it pays on low-dimensional or
@@ -278,7 +282,7 @@ class HipOps:
             cap = lib.meld_knn16_row_capacity(ksel)
             if cap < 0:
                 check(cap, "meld_knn16_row_capacity")
-            err_coef = lib.meld_knn16_error_coef()
+            err_coef = lib.meld_knn16_error_coef(self.nprod)
             n_tiles = (N + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
             Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device=dev)
@@ -297,10 +301,12 @@ class HipOps:
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
             del lb2
             KP = 16 * KB
+            research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if self.nprod == 1 else None
         else:
+            research = None
             # fp32 operands on v_mfma_f32_32x32x2_f32 (knn.hip)
             KP = lib.meld_knn_padded_dim(d)
             if KP < 0:
@@ -323,7 +329,9 @@ class HipOps:
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 check(lib.meld_knn_topk(ptr(Q), ptr(Rt), N, KP, q_count, ksel, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn_topk")
         tm.stop("knn_topk")
-        del Q, Rt
+        del Q
+        if research is None:
+            del Rt
 
         # exact refinement + alpha-decay kernel
         bw = torch.empty(q_count, dtype=torch.float64, device=dev)
@@ -337,14 +345,45 @@ class HipOps:
         check(
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, cap, knn, float(decay),
-                float(thresh), ptr(nmax_used), float(err_coef), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag), st,
+                float(thresh), ptr(nmax_used), float(err_coef), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag),
+                None, 0, None, st,
             ),
             "meld_knn_refine",
         )
-        keep_off = _scan_i32(lib, keep_cnt, st)
         n_flag_h = int(n_flag.item())
-        m_main = int(keep_off[q_count].item())
+        n_flag_stage1 = n_flag_h
         tm.stop("refine")
+
+        # second search stage: rows the reduced-precision pass could not certify are searched again with
+        # the full hi/lo split (a few % of the rows); only what that cannot certify either goes to the
+        # exact sweep
+        if research is not None and n_flag_h > 0 and not force_fallback:
+            rows2 = torch.sort(flag_rows[:n_flag_h]).values.contiguous()
+            KB, BQ2 = research["KB"], research["BQ"]
+            q2_pad = ((n_flag_h + BQ2 - 1) // BQ2) * BQ2
+            Q2 = torch.empty(q2_pad * KB * 64, dtype=torch.uint8, device=dev)
+            check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), st), "meld_knn16_prepare_rows")
+            c2_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
+            c2_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
+            c2_cnt = torch.empty(q2_pad, dtype=torch.int32, device=dev)
+            with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+            n_flag.zero_()
+            check(
+                lib.meld_knn_refine(
+                    ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), ksel, cap, knn, float(decay),
+                    float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3)), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag),
+                    ptr(rows2), cap, ptr(cand_idx), st,
+                ),
+                "meld_knn_refine(stage 2)",
+            )
+            n_flag_h = int(n_flag.item())
+            del Q2, c2_idx, c2_d2, c2_cnt
+            tm.stop("knn_stage2")
+        research = None
+        Rt = None
+        keep_off = _scan_i32(lib, keep_cnt, st)
+        m_main = int(keep_off[q_count].item())
 
         # exact sweep for rows the candidate list could not certify
         fb_total = 0
@@ -391,7 +430,8 @@ class HipOps:
                 "meld_coo_emit",
             )
         tm.stop("coo_emit")
-        info = dict(ksel=int(ksel), KP=int(KP), search=self.search, n_flagged_rows=n_flag_h, nnz_directed=M)
+        info = dict(ksel=int(ksel), KP=int(KP), search=self.search, nprod=self.nprod, n_flagged_rows=n_flag_h,
+                    n_researched_rows=n_flag_stage1 if self.search == 'f16x3' and self.nprod == 1 else 0, nnz_directed=M)
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------
