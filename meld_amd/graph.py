@@ -150,7 +150,7 @@ class DeviceGraph:
     def lmax(self, value):
         self._lmax = None if value is None else float(value)
 
-    def estimate_lmax(self, recompute=False, tol=1e-5, max_iter=300):
+    def estimate_lmax(self, recompute=False, tol=1e-4, max_iter=300):
         """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
         ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
         tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos

@@ -182,10 +182,29 @@ class MELD(GraphEstimator):
         self.sample_labels_ = sample_labels
         labels = self._flatten_labels(sample_labels)
         codes, self.samples = _factorized if _factorized is not None else self._factorize(labels)
-        onehot = np.zeros((labels.shape[0], self.samples.shape[0]), dtype=np.int64)
-        onehot[np.arange(labels.shape[0]), codes] = 1
-        self.sample_indicators = pd.DataFrame(onehot, index=getattr(self, "_labels_index", None), columns=self.samples)
+        self._codes = codes
+        self._indicator_scale = None  # 0/1 indicators
+        self._sample_indicators = None
         return self.sample_indicators
+
+    @property
+    def sample_indicators(self):
+        """DataFrame [N, p] of the (optionally column-normalised) sample indicators.  Built on
+        first access from the label codes: the filter itself assembles the signal on the device."""
+        if getattr(self, "_sample_indicators", None) is None and getattr(self, "_codes", None) is not None:
+            n, p = self._codes.shape[0], self.samples.shape[0]
+            if self._indicator_scale is None:
+                arr = np.zeros((n, p), dtype=np.int64)
+                arr[np.arange(n), self._codes] = 1
+            else:
+                arr = np.zeros((n, p), dtype=np.float64)
+                arr[np.arange(n), self._codes] = self._indicator_scale[self._codes]
+            self._sample_indicators = pd.DataFrame(arr, index=getattr(self, "_labels_index", None), columns=self.samples)
+        return getattr(self, "_sample_indicators", None)
+
+    @sample_indicators.setter
+    def sample_indicators(self, value):
+        self._sample_indicators = value
 
     # -- transform (reference meld/meld.py:193-250) -------------------------------------------------
     def transform(self, sample_labels):
@@ -214,14 +233,19 @@ class MELD(GraphEstimator):
 
         self._create_sample_indicators(sample_labels, _factorized=factorized)
         if self.sample_normalize:
-            ind = self.sample_indicators.values
-            signal = ind / ind.sum(axis=0)
-            self.sample_indicators = pd.DataFrame(signal, index=self.sample_indicators.index, columns=self.samples, copy=False)
+            # each indicator column divided by its sum (reference meld/meld.py:229-232): the column sums
+            # are the label counts, so the normalised signal is 1/count at the cell's own label
+            counts = np.bincount(self._codes, minlength=self.samples.shape[0]).astype(np.float64)
+            self._indicator_scale = 1.0 / counts
+            self._sample_indicators = None
 
         if self._lmax_override is not None:
             self.graph.lmax = self._lmax_override
+        # the signal is a scaled one-hot: hand the filter the label codes (4 B per cell over PCIe instead
+        # of 8p) and let it assemble the [N, p] matrix on the device
+        signal = _filter.IndicatorSignal(self._codes, self.samples.shape[0], self._indicator_scale)
         densities = _filter.filter(
-            signal=self.sample_indicators,
+            signal=signal,
             graph=self.graph,
             filter=self.filter,
             beta=self.beta,
@@ -230,9 +254,7 @@ class MELD(GraphEstimator):
             solver=self.solver,
             chebyshev_order=self.chebyshev_order,
         )
-        self.sample_densities = pd.DataFrame(
-            densities, index=self._labels_index, columns=self.sample_indicators.columns
-        )
+        self.sample_densities = pd.DataFrame(densities, index=self._labels_index, columns=self.samples)
         return self.sample_densities
 
     def fit_transform(self, X, sample_labels, **kwargs):
