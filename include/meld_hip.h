@@ -107,10 +107,16 @@ int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, con
 int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                             int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16,
                             meld_stream_t stream);
+/* n_slices > 1 (small query sets): the references are cut into n_slices ranges, each scanned by its
+ * own workgroups into its own candidate rows (buffers of n_slices * roundup(q_count, BQ) rows);
+ * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
 int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                    int64_t q_count, int ksel, int nprod, const float* lb2, const float* norm2_max,
-                    int64_t q_begin, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                    meld_stream_t stream);
+                    int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
+                    const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
+                    int32_t* cand_cnt, meld_stream_t stream);
+int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32_t* s_cnt, int64_t q_count,
+                            int ksel, int n_slices, int32_t* out_idx, float* out_d2, int32_t* out_cnt,
+                            meld_stream_t stream);
 
 /* ---- exact re-evaluation + alpha-decay kernel (replaces [UPSTREAM graphtools
  *      kNNGraph.build_kernel_to_data, "affinities" block]) ---------------------------------- */

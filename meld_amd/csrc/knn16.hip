@@ -196,6 +196,12 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   const int jq = lane & 31;
   const int h = lane >> 5;
   const int q_base = blockIdx.x * K16_BQ + wave * 64;  // first query of this wave
+  // reference slices (gridDim.y > 1): slice y scans tiles [tile_lo, tile_lo + n_scan) and writes its
+  // own candidate rows; meld_knn16_merge_slices combines them.  Used to spread a small query set
+  // (the second-stage re-search) over the whole chip.
+  const int tile_lo = (int)((long long)n_tiles * blockIdx.y / gridDim.y);
+  const int n_scan = (int)((long long)n_tiles * (blockIdx.y + 1) / gridDim.y) - tile_lo;
+  const int row_base = (int)(blockIdx.y * (gridDim.x * K16_BQ)) + q_base;  // first candidate row of this wave
 
   // B fragments of both query groups: [g][kb] hi / lo, 8 halves each
   f16x8 bhi[2][KB], blo[2][KB];
@@ -221,22 +227,22 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   // threshold of the workgroup cannot contribute a candidate and is skipped without being loaded.
   // search-error allowance in the scaled space: a skipped tile must fail `d2_approx < thr` for sure
   const float prune_margin = lb2 ? err_coef * norm2_max[0] * scale_info[0] * scale_info[0] : 0.0f;
-  const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_tiles);
+  const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
   const float* my_lb = lb2 ? lb2 + (size_t)blockIdx.x * n_tiles : nullptr;
   auto tile_of = [&](int s) {
     const int t = t0 + s;
-    return t >= n_tiles ? t - n_tiles : t;
+    return tile_lo + (t >= n_scan ? t - n_scan : t);
   };
   // first step >= s whose tile may hold a candidate given the block-wide threshold bound
   auto next_live = [&](int s, float bound) {
     if (my_lb == nullptr) return s;
-    for (int base = s; base < n_tiles; base += 64) {
+    for (int base = s; base < n_scan; base += 64) {
       const int ss = base + lane;
-      const bool live = ss < n_tiles && my_lb[tile_of(ss)] <= bound;
+      const bool live = ss < n_scan && my_lb[tile_of(ss)] <= bound;
       const unsigned long long b = __ballot(live);
       if (b) return base + (int)__ffsll((long long)b) - 1;
     }
-    return n_tiles;
+    return n_scan;
   };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
@@ -277,12 +283,12 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   int s_cur = 0;
   int cur = 0;
   int par = 0;
-  while (s_cur < n_tiles) {
+  while (s_cur < n_scan) {
     // block-uniform bound: every wave reads the values published before the last barrier
     float bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3]));
     bound += prune_margin;
     const int s_next = next_live(s_cur + 1, bound);
-    if (s_next < n_tiles) {
+    if (s_next < n_scan) {
       const float4* src = R4 + (size_t)tile_of(s_next) * TILE_V4;
       K16_LOAD(src);
     }
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
           asm volatile("" ::"v"(m));  // profiling ablation: distances + minimum, selection removed
         } else if (__any(m < thr[g])) {
           int* cntp = &lds_cnt[wave][g * 32 + jq];
-          const size_t rowoff = (size_t)(q_base + g * 32 + jq) * cap;
+          const size_t rowoff = (size_t)(row_base + g * 32 + jq) * cap;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[r];
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
               need &= need - 1;
               int* cj = &lds_cnt[wave][g * 32 + j];
               const int n = min(__hip_atomic_load(cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
-              const size_t ro = (size_t)(q_base + g * 32 + j) * cap;
+              const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
               int n_new;
               float nt = knn16_squeeze_row(n, ksel, cap, cand_d2 + ro, cand_idx + ro, lane, &n_new);
               if (n_new > cap - 32) {
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
       }
     }
 
-    if (s_next < n_tiles) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    if (s_next < n_scan) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
     if (lane == 0) lds_wthr[par ^ 1][wave] = wmax;
     __syncthreads();
     s_cur = s_next;
@@ -384,13 +390,67 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   const float out_scale = scale_info[1];  // 1 / s^2
   for (int j = 0; j < 64; ++j) {
     const int n = min(__hip_atomic_load(&lds_cnt[wave][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
-    const int qr = q_base + j;
+    const int qr = row_base + j;
     const size_t ro = (size_t)qr * cap;
     knn16_rank_row(n, ksel, out_scale, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
     if (lane == 0) cand_cnt[qr] = min(n, ksel);
   }
 #undef K16_LOAD
 #undef K16_STORE
+}
+
+// Merge the per-slice candidate rows of one query (n_slices * q_pad rows of stride cap) into its
+// final row: the ksel smallest of the union, sorted by (d2, idx).  One wave per query; at most
+// K16_CAPMAX entries in the union.
+__global__ __launch_bounds__(256) void knn16_merge_slices_kernel(const int* __restrict__ s_idx,
+                                                                 const float* __restrict__ s_d2,
+                                                                 const int* __restrict__ s_cnt, int q_count, int q_pad,
+                                                                 int ksel, int cap, int n_slices,
+                                                                 int* __restrict__ out_idx, float* __restrict__ out_d2,
+                                                                 int* __restrict__ out_cnt) {
+  __shared__ float sd[4][K16_CAPMAX];
+  __shared__ int si[4][K16_CAPMAX];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + w;
+  if (q >= q_count) return;
+  // gather the union into LDS (slice lists are short: <= ksel each)
+  int n = 0;
+  for (int s = 0; s < n_slices; ++s) {
+    const int row = s * q_pad + q;
+    const int c = min(s_cnt[row], ksel);
+    for (int e = lane; e < c; e += 64) {
+      sd[w][n + e] = s_d2[(size_t)row * cap + e];
+      si[w][n + e] = s_idx[(size_t)row * cap + e];
+    }
+    n += c;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float d[K16_SLOTS];
+  int ix[K16_SLOTS];
+#pragma unroll
+  for (int e = 0; e < K16_SLOTS; ++e) {
+    const int p = lane + 64 * e;
+    d[e] = p < n ? sd[w][p] : INFINITY;
+    ix[e] = p < n ? si[w][p] : 0x7fffffff;
+  }
+  int rk[K16_SLOTS];
+#pragma unroll
+  for (int e = 0; e < K16_SLOTS; ++e) rk[e] = 0;
+  for (int e = 0; e < n; ++e) {
+    const float de = sd[w][e];
+    const int ie = si[w][e];
+#pragma unroll
+    for (int k = 0; k < K16_SLOTS; ++k) rk[k] += (de < d[k] || (de == d[k] && ie < ix[k])) ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < K16_SLOTS; ++k) {
+    if (lane + 64 * k < n && rk[k] < ksel) {
+      out_d2[(size_t)q * cap + rk[k]] = d[k];
+      out_idx[(size_t)q * cap + rk[k]] = ix[k];
+    }
+  }
+  if (lane == 0) out_cnt[q] = min(n, ksel);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -658,10 +718,13 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 }
 
 extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                               int64_t q_count, int ksel, int nprod, const float* lb2, const float* norm2_max,
-                               int64_t q_begin, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                               meld_stream_t stream) {
+                               int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
+                               const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
+                               int32_t* cand_cnt, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
+  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_CAPMAX && (n_slices == 1 || lb2 == nullptr),
+                 "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
+                 K16_CAPMAX);
   MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
@@ -670,7 +733,8 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
   const int n_tiles = (int)ceil_div(n_ref, K16_TS);
-  const unsigned grid = (unsigned)ceil_div(q_count, K16_BQ);
+  const dim3 grid((unsigned)ceil_div(q_count, K16_BQ), (unsigned)n_slices);
+  MELD_CHECK_ARG(n_slices <= ceil_div(n_ref, K16_TS), "meld_knn16_topk: more slices than reference tiles");
   const int tile_origin = (int)((q_begin / K16_TS) % n_tiles);  // the scan starts at the queries' own position
   // profiling hooks (never set in production): MELD_KNN16_ABLATION=1 distances without selection,
   // =3 MFMAs only; MELD_KNN16_PADLDS=<bytes> extra dynamic LDS to lower the workgroups per CU
@@ -681,7 +745,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
 #define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
-  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), dim3(grid), dim3(K16_THREADS), pad_lds, S(stream), q, r,  \
+  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, r,  \
                      scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
                      tile_origin, cand_idx, cand_d2, cand_cnt)
 #define K16_LAUNCH(KBV, ABLV)        \
@@ -717,5 +781,19 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
 #undef K16_LAUNCH
 #undef K16_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_topk_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32_t* s_cnt, int64_t q_count,
+                                       int ksel, int n_slices, int32_t* out_idx, float* out_d2, int32_t* out_cnt,
+                                       meld_stream_t stream) {
+  MELD_CHECK_ARG(s_idx && s_d2 && s_cnt && out_idx && out_d2 && out_cnt && q_count > 0, "meld_knn16_merge_slices: null");
+  const int cap = meld_knn16_row_capacity(ksel);
+  if (cap < 0) return cap;
+  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_CAPMAX, "meld_knn16_merge_slices: too many slices");
+  const int q_pad = (int)(ceil_div(q_count, K16_BQ) * K16_BQ);
+  hipLaunchKernelGGL(knn16_merge_slices_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), s_idx, s_d2,
+                     s_cnt, (int)q_count, q_pad, ksel, cap, n_slices, out_idx, out_d2, out_cnt);
+  MELD_LAUNCH_CHECK("knn16_merge_slices_kernel");
   return MELD_OK;
 }

@@ -301,7 +301,7 @@ class HipOps:
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if self.nprod == 1 else None
@@ -363,11 +363,20 @@ class HipOps:
             q2_pad = ((n_flag_h + BQ2 - 1) // BQ2) * BQ2
             Q2 = torch.empty(q2_pad * KB * 64, dtype=torch.uint8, device=dev)
             check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), st), "meld_knn16_prepare_rows")
-            c2_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
-            c2_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
-            c2_cnt = torch.empty(q2_pad, dtype=torch.int32, device=dev)
+            # few queries: cut the references into slices so that the re-search fills the chip
+            n_blocks2 = q2_pad // BQ2
+            n_slices = int(max(1, min(256 // ksel, 768 // max(n_blocks2, 1), n_tiles)))
+            c2_idx = torch.empty(n_slices * q2_pad * cap, dtype=torch.int32, device=dev)
+            c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
+            c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+                if n_slices > 1:
+                    m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
+                    m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
+                    m_cnt = torch.empty(q2_pad, dtype=torch.int32, device=dev)
+                    check(lib.meld_knn16_merge_slices(ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), n_flag_h, ksel, n_slices, ptr(m_idx), ptr(m_d2), ptr(m_cnt), st), "meld_knn16_merge_slices")
+                    c2_idx, c2_d2, c2_cnt = m_idx, m_d2, m_cnt
             n_flag.zero_()
             check(
                 lib.meld_knn_refine(

@@ -295,7 +295,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -377,3 +377,51 @@ def test_tile_pruning_is_exact():
             outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+def test_knn16_reference_slices_merge_to_the_same_rows():
+    """Cutting the references into slices + meld_knn16_merge_slices == one full scan."""
+    mo = _oracle()
+    from meld_amd._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    X, _ = mo.synthetic_cells(2500, n_dims=50, seed=17)
+    N, d = X.shape
+    Xd = torch.from_numpy(X).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    KB, TS, BQ = lib.meld_knn16_kblocks(d), lib.meld_knn16_tile_refs(), lib.meld_knn16_block_queries()
+    ksel = 64
+    cap = lib.meld_knn16_row_capacity(ksel)
+    sums = torch.empty(d, dtype=torch.float64, device="cuda")
+    check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st))
+    mean = sums / N
+    n_tiles = (N + TS - 1) // TS
+    nq = 700  # a subset of the rows as queries, through the row-list form
+    rows = torch.arange(100, 100 + nq, dtype=torch.int32, device="cuda")
+    q_pad = ((nq + BQ - 1) // BQ) * BQ
+    Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device="cuda")
+    Qall = torch.empty(((N + BQ - 1) // BQ) * BQ * KB * 64, dtype=torch.uint8, device="cuda")
+    norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Qall), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+    Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device="cuda")
+    check(lib.meld_knn16_prepare_rows(ptr(Xd), N, d, ptr(mean), ptr(sinfo), 0, ptr(rows), nq, ptr(Q), st))
+    res = {}
+    for S in (1, 3):
+        ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
+        cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
+        cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, ptr(ci), ptr(cd), ptr(cc), st))
+        if S > 1:
+            mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
+            md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")
+            mc = torch.zeros(q_pad, dtype=torch.int32, device="cuda")
+            check(lib.meld_knn16_merge_slices(ptr(ci), ptr(cd), ptr(cc), nq, ksel, S, ptr(mi), ptr(md), ptr(mc), st))
+            ci, cd, cc = mi, md, mc
+        torch.cuda.synchronize()
+        res[S] = (ci.view(-1, cap)[:nq, :ksel].clone(), cd.view(-1, cap)[:nq, :ksel].clone(), cc[:nq].clone())
+    for a, b in zip(res[1], res[3]):
+        assert torch.equal(a, b)
+    # row 0 of the subset is global row 100: its nearest candidate is itself
+    assert int(res[1][0][0, 0]) == 100
