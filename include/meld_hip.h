@@ -82,7 +82,9 @@ int meld_knn16_kblocks(int d);           /* KB = ceil((d+2)/16); <0 if d unsuppo
 int meld_knn16_tile_refs(void);          /* TS */
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
-double meld_knn16_error_coef(int nprod);
+double meld_knn16_error_coef(int nprod);       /* worst case: E <= coef * max|x~|^2 */
+double meld_knn16_error_coef_const(int nprod); /* per-row form: E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~| */
+double meld_knn16_error_coef_lin(int nprod);
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
@@ -127,8 +129,10 @@ int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32
  * is appended to flag_rows (its keep_cnt is set to 0) and must go through meld_knn_radius_exact.
  *   cand_val[q_count][ksel] : kernel value or 0
  *   keep_cnt[q_count]       : number of kept OFF-DIAGONAL entries (0 for flagged rows)
- *   err_coef                : bound on |d2_search - d2_exact| / norm2_max of the search kernel used
- *                             (meld_knn_error_coef(d) for meld_knn_topk, meld_knn16_error_coef())
+ *   err_coef, err_coef_lin  : search-error allowance of the kernel that produced the candidates,
+ *                             E_i = err_coef * norm2_max + err_coef_lin * sqrt(norm2[i] * norm2_max)
+ *                             (meld_knn_error_coef(d) / 0 for meld_knn_topk; meld_knn16_error_coef_const /
+ *                             _lin for meld_knn16_topk, or the worst case meld_knn16_error_coef with norm2 = NULL)
  *   n_flag[1]               : atomic counter, zeroed by the caller
  *   rows (optional)         : second-stage form -- candidate row q belongs to local row rows[q]:
  *                             bw / cand_val / keep_cnt are written at that row, the candidate indices
@@ -136,7 +140,9 @@ int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32
  *                             the local row.  NULL = row q is local row q. */
 int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                     const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                    int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh, const float* norm2_max, double err_coef, double* bw,
+                    int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh,
+                    const float* norm2_max, double err_coef,
+                    const float* norm2 /* [N] per-row |x~|^2 or NULL */, double err_coef_lin, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                     const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream);
 

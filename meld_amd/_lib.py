@@ -29,8 +29,8 @@ SIGNATURES = {
     "meld_knn_topk": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_refine": (
         _i32,
-        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _ptr, _ptr, _ptr, _ptr,
-         _ptr, _i32, _ptr, _ptr],
+        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _f64, _ptr, _ptr, _ptr,
+         _ptr, _ptr, _ptr, _i32, _ptr, _ptr],
     ),
     "meld_knn_error_coef": (_f64, [_i32]),
     "meld_knn16_kblocks": (_i32, [_i32]),
@@ -38,6 +38,8 @@ SIGNATURES = {
     "meld_knn16_block_queries": (_i32, []),
     "meld_knn16_row_capacity": (_i32, [_i32]),
     "meld_knn16_error_coef": (_f64, [_i32]),
+    "meld_knn16_error_coef_const": (_f64, [_i32]),
+    "meld_knn16_error_coef_lin": (_f64, [_i32]),
     "meld_knn16_prepare": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_rows": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr]),
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (= KB)
   constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;
   static_assert(NV <= 8, "tile too large for the staging registers");
+  static_assert(K16_THREADS == 256 && K16_TS == 64 && NV == KB, "the plane-skipping staging assumes vector u*256+tid = K block u");
 
   __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
   __shared__ int lds_cnt[K16_NWAVE][64];
@@ -249,29 +250,34 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   const bool tail_ok = HAS_TAIL && (NV * K16_THREADS + tid < TILE_V4);
   float4 p0, p1, p2, p3, p4, p5, p6, p7, pt;
   p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = pt = make_float4(0.f, 0.f, 0.f, 0.f);
-#define K16_LOAD(SRC)                                            \
-  do {                                                           \
-    if constexpr (NV > 0) p0 = (SRC)[tid + 0 * K16_THREADS];     \
-    if constexpr (NV > 1) p1 = (SRC)[tid + 1 * K16_THREADS];     \
-    if constexpr (NV > 2) p2 = (SRC)[tid + 2 * K16_THREADS];     \
-    if constexpr (NV > 3) p3 = (SRC)[tid + 3 * K16_THREADS];     \
-    if constexpr (NV > 4) p4 = (SRC)[tid + 4 * K16_THREADS];     \
-    if constexpr (NV > 5) p5 = (SRC)[tid + 5 * K16_THREADS];     \
-    if constexpr (NV > 6) p6 = (SRC)[tid + 6 * K16_THREADS];     \
-    if constexpr (NV > 7) p7 = (SRC)[tid + 7 * K16_THREADS];     \
-    if (tail_ok) pt = (SRC)[tid + NV * K16_THREADS];             \
+  // Vector v = tid + u * 256 of a tile is (kb = u, k-half, plane, ref) = (u, tid >> 7, (tid >> 6) & 1, tid & 63):
+  // a wave copies one plane.  With NPROD == 1 the lo planes of the coordinate blocks are never read,
+  // so the two waves that own them skip those copies (3/8 of the staging traffic).
+  const bool lo_wave = ((tid >> 6) & 1) != 0;
+#define K16_NEED(U) (NPROD == 3 || (U) == KB - 1 || !lo_wave)
+#define K16_LOAD(SRC)                                                            \
+  do {                                                                           \
+    if constexpr (NV > 0) if (K16_NEED(0)) p0 = (SRC)[tid + 0 * K16_THREADS];    \
+    if constexpr (NV > 1) if (K16_NEED(1)) p1 = (SRC)[tid + 1 * K16_THREADS];    \
+    if constexpr (NV > 2) if (K16_NEED(2)) p2 = (SRC)[tid + 2 * K16_THREADS];    \
+    if constexpr (NV > 3) if (K16_NEED(3)) p3 = (SRC)[tid + 3 * K16_THREADS];    \
+    if constexpr (NV > 4) if (K16_NEED(4)) p4 = (SRC)[tid + 4 * K16_THREADS];    \
+    if constexpr (NV > 5) if (K16_NEED(5)) p5 = (SRC)[tid + 5 * K16_THREADS];    \
+    if constexpr (NV > 6) if (K16_NEED(6)) p6 = (SRC)[tid + 6 * K16_THREADS];    \
+    if constexpr (NV > 7) if (K16_NEED(7)) p7 = (SRC)[tid + 7 * K16_THREADS];    \
+    if (tail_ok) pt = (SRC)[tid + NV * K16_THREADS];                             \
   } while (0)
-#define K16_STORE(DST)                                           \
-  do {                                                           \
-    if constexpr (NV > 0) (DST)[tid + 0 * K16_THREADS] = p0;     \
-    if constexpr (NV > 1) (DST)[tid + 1 * K16_THREADS] = p1;     \
-    if constexpr (NV > 2) (DST)[tid + 2 * K16_THREADS] = p2;     \
-    if constexpr (NV > 3) (DST)[tid + 3 * K16_THREADS] = p3;     \
-    if constexpr (NV > 4) (DST)[tid + 4 * K16_THREADS] = p4;     \
-    if constexpr (NV > 5) (DST)[tid + 5 * K16_THREADS] = p5;     \
-    if constexpr (NV > 6) (DST)[tid + 6 * K16_THREADS] = p6;     \
-    if constexpr (NV > 7) (DST)[tid + 7 * K16_THREADS] = p7;     \
-    if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;             \
+#define K16_STORE(DST)                                                           \
+  do {                                                                           \
+    if constexpr (NV > 0) if (K16_NEED(0)) (DST)[tid + 0 * K16_THREADS] = p0;    \
+    if constexpr (NV > 1) if (K16_NEED(1)) (DST)[tid + 1 * K16_THREADS] = p1;    \
+    if constexpr (NV > 2) if (K16_NEED(2)) (DST)[tid + 2 * K16_THREADS] = p2;    \
+    if constexpr (NV > 3) if (K16_NEED(3)) (DST)[tid + 3 * K16_THREADS] = p3;    \
+    if constexpr (NV > 4) if (K16_NEED(4)) (DST)[tid + 4 * K16_THREADS] = p4;    \
+    if constexpr (NV > 5) if (K16_NEED(5)) (DST)[tid + 5 * K16_THREADS] = p5;    \
+    if constexpr (NV > 6) if (K16_NEED(6)) (DST)[tid + 6 * K16_THREADS] = p6;    \
+    if constexpr (NV > 7) if (K16_NEED(7)) (DST)[tid + 7 * K16_THREADS] = p7;    \
+    if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;                             \
   } while (0)
   {
     const float4* src = R4 + (size_t)tile_of(0) * TILE_V4;
@@ -397,22 +403,25 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   }
 #undef K16_LOAD
 #undef K16_STORE
+#undef K16_NEED
 }
 
 // Merge the per-slice candidate rows of one query (n_slices * q_pad rows of stride cap) into its
 // final row: the ksel smallest of the union, sorted by (d2, idx).  One wave per query; at most
 // K16_CAPMAX entries in the union.
-__global__ __launch_bounds__(256) void knn16_merge_slices_kernel(const int* __restrict__ s_idx,
-                                                                 const float* __restrict__ s_d2,
-                                                                 const int* __restrict__ s_cnt, int q_count, int q_pad,
-                                                                 int ksel, int cap, int n_slices,
-                                                                 int* __restrict__ out_idx, float* __restrict__ out_d2,
-                                                                 int* __restrict__ out_cnt) {
-  __shared__ float sd[4][K16_CAPMAX];
-  __shared__ int si[4][K16_CAPMAX];
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  const int q = blockIdx.x * 4 + w;
+constexpr int K16_MERGE_MAX = 1024;                 // entries in the union of the slice lists of one query
+constexpr int K16_MERGE_SLOTS = K16_MERGE_MAX / 64;  // per lane
+
+__global__ __launch_bounds__(64) void knn16_merge_slices_kernel(const int* __restrict__ s_idx,
+                                                                const float* __restrict__ s_d2,
+                                                                const int* __restrict__ s_cnt, int q_count, int q_pad,
+                                                                int ksel, int cap, int n_slices,
+                                                                int* __restrict__ out_idx, float* __restrict__ out_d2,
+                                                                int* __restrict__ out_cnt) {
+  __shared__ float sd[K16_MERGE_MAX];
+  __shared__ int si[K16_MERGE_MAX];
+  const int lane = threadIdx.x;
+  const int q = blockIdx.x;
   if (q >= q_count) return;
   // gather the union into LDS (slice lists are short: <= ksel each)
   int n = 0;
@@ -420,34 +429,21 @@ __global__ __launch_bounds__(256) void knn16_merge_slices_kernel(const int* __re
     const int row = s * q_pad + q;
     const int c = min(s_cnt[row], ksel);
     for (int e = lane; e < c; e += 64) {
-      sd[w][n + e] = s_d2[(size_t)row * cap + e];
-      si[w][n + e] = s_idx[(size_t)row * cap + e];
+      sd[n + e] = s_d2[(size_t)row * cap + e];
+      si[n + e] = s_idx[(size_t)row * cap + e];
     }
     n += c;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  float d[K16_SLOTS];
-  int ix[K16_SLOTS];
-#pragma unroll
-  for (int e = 0; e < K16_SLOTS; ++e) {
-    const int p = lane + 64 * e;
-    d[e] = p < n ? sd[w][p] : INFINITY;
-    ix[e] = p < n ? si[w][p] : 0x7fffffff;
-  }
-  int rk[K16_SLOTS];
-#pragma unroll
-  for (int e = 0; e < K16_SLOTS; ++e) rk[e] = 0;
-  for (int e = 0; e < n; ++e) {
-    const float de = sd[w][e];
-    const int ie = si[w][e];
-#pragma unroll
-    for (int k = 0; k < K16_SLOTS; ++k) rk[k] += (de < d[k] || (de == d[k] && ie < ix[k])) ? 1 : 0;
-  }
-#pragma unroll
-  for (int k = 0; k < K16_SLOTS; ++k) {
-    if (lane + 64 * k < n && rk[k] < ksel) {
-      out_d2[(size_t)q * cap + rk[k]] = d[k];
-      out_idx[(size_t)q * cap + rk[k]] = ix[k];
+  __syncthreads();
+  // rank every entry by (d2, idx) against the whole union; the ksel smallest go out sorted
+  for (int p = lane; p < n; p += 64) {
+    const float dp = sd[p];
+    const int ip = si[p];
+    int rk = 0;
+    for (int e = 0; e < n; ++e) rk += (sd[e] < dp || (sd[e] == dp && si[e] < ip)) ? 1 : 0;
+    if (rk < ksel) {
+      out_d2[(size_t)q * cap + rk] = dp;
+      out_idx[(size_t)q * cap + rk] = ip;
     }
   }
   if (lane == 0) out_cnt[q] = min(n, ksel);
@@ -651,6 +647,14 @@ extern "C" double meld_knn16_error_coef(int nprod) {
   const double full = 3.0517578125e-05;  // 2^-15
   return nprod == 1 ? (0.001953125 + full) : full;
 }
+// The same bound split for a per-row allowance  E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~|
+// (the nprod = 1 term is |qlo.r| + |qhi.rlo| <= 2^-9 |x~_q| |x~_r|): rows near the centre of
+// the data get a tighter allowance than the global worst case.
+extern "C" double meld_knn16_error_coef_const(int nprod) {
+  (void)nprod;
+  return 3.0517578125e-05;
+}
+extern "C" double meld_knn16_error_coef_lin(int nprod) { return nprod == 1 ? 0.001953125 : 0.0; }
 
 extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                                   int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
@@ -722,9 +726,9 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
                                const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
                                int32_t* cand_cnt, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
-  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_CAPMAX && (n_slices == 1 || lb2 == nullptr),
+  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
-                 K16_CAPMAX);
+                 K16_MERGE_MAX);
   MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
@@ -790,9 +794,9 @@ extern "C" int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, 
   MELD_CHECK_ARG(s_idx && s_d2 && s_cnt && out_idx && out_d2 && out_cnt && q_count > 0, "meld_knn16_merge_slices: null");
   const int cap = meld_knn16_row_capacity(ksel);
   if (cap < 0) return cap;
-  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_CAPMAX, "meld_knn16_merge_slices: too many slices");
+  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX, "meld_knn16_merge_slices: too many slices");
   const int q_pad = (int)(ceil_div(q_count, K16_BQ) * K16_BQ);
-  hipLaunchKernelGGL(knn16_merge_slices_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), s_idx, s_d2,
+  hipLaunchKernelGGL(knn16_merge_slices_kernel, dim3((unsigned)q_count), dim3(64), 0, S(stream), s_idx, s_d2,
                      s_cnt, (int)q_count, q_pad, ksel, cap, n_slices, out_idx, out_d2, out_cnt);
   MELD_LAUNCH_CHECK("knn16_merge_slices_kernel");
   return MELD_OK;

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
     const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, int ksel, int cap, int knn,
     double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
+    const float* __restrict__ norm2, double err_coef_lin,
     double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
     int* __restrict__ flag_rows, int* __restrict__ n_flag, const int* __restrict__ rows, int out_cap,
     int* __restrict__ cand_idx_out) {
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(256) void refine_kernel(
 
   // completeness test in squared-distance space
   const double radius = bw * radius_factor;
-  const double E = err_coef * (double)norm2_max[0];
+  // search-error allowance: constant part + the part that scales with this row's own norm
+  // (|q.r - q~.r~| <= c_lin |x_q| max|x_r|, the per-row form of the Cauchy-Schwarz bound)
+  double E = err_coef * (double)norm2_max[0];
+  if (norm2 != nullptr) E += err_coef_lin * sqrt((double)norm2[gi] * (double)norm2_max[0]);
   bool complete = true;
   if (cand_cnt[q] >= ksel) {
     const double tau = (double)cand_d2[ro + ksel - 1];
@@ -212,7 +216,7 @@ using namespace meld;
 extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
                                const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
                                int cap, int knn, double decay, double thresh, const float* norm2_max, double err_coef,
-                               double* bw,
+                               const float* norm2, double err_coef_lin, double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                                const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
@@ -224,11 +228,12 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(ksel >= 1 && ksel <= 128, "meld_knn_refine: ksel=%d outside [1,128]", ksel);
   MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
   MELD_CHECK_ARG(cap >= ksel, "meld_knn_refine: row stride cap=%d smaller than ksel=%d", cap, ksel);
-  MELD_CHECK_ARG(err_coef >= 0, "meld_knn_refine: err_coef must be non-negative");
+  MELD_CHECK_ARG(err_coef >= 0 && err_coef_lin >= 0, "meld_knn_refine: error coefficients must be non-negative");
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
                      q_count, cand_idx, cand_d2, cand_cnt, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
-                     err_coef, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap, cand_idx_out);
+                     err_coef, norm2, err_coef_lin, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
+                     cand_idx_out);
   MELD_LAUNCH_CHECK("refine_kernel");
   return MELD_OK;
 }

@@ -282,7 +282,8 @@ class HipOps:
             cap = lib.meld_knn16_row_capacity(ksel)
             if cap < 0:
                 check(cap, "meld_knn16_row_capacity")
-            err_coef = lib.meld_knn16_error_coef(self.nprod)
+            err_coef = lib.meld_knn16_error_coef_const(self.nprod)
+            err_lin = lib.meld_knn16_error_coef_lin(self.nprod)
             n_tiles = (N + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
             Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device=dev)
@@ -316,6 +317,7 @@ class HipOps:
             if cap < 0:
                 check(cap, "meld_knn_row_capacity")
             err_coef = lib.meld_knn_error_coef(d)
+            err_lin = 0.0
             n_tiles = (N + TS - 1) // TS
             Rt = torch.empty(n_tiles * KP * TS, dtype=torch.float32, device=dev)
             check(lib.meld_knn_prepare_refs(ptr(X), N, d, ptr(mean), KP, ptr(Rt), ptr(norm2), ptr(nmax), st), "meld_knn_prepare_refs")
@@ -345,8 +347,8 @@ class HipOps:
         check(
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, cap, knn, float(decay),
-                float(thresh), ptr(nmax_used), float(err_coef), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag),
-                None, 0, None, st,
+                float(thresh), ptr(nmax_used), float(err_coef), ptr(norm2), float(err_lin), ptr(bw), ptr(cand_val), ptr(keep_cnt),
+                ptr(flag_rows), ptr(n_flag), None, 0, None, st,
             ),
             "meld_knn_refine",
         )
@@ -365,7 +367,7 @@ class HipOps:
             check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), st), "meld_knn16_prepare_rows")
             # few queries: cut the references into slices so that the re-search fills the chip
             n_blocks2 = q2_pad // BQ2
-            n_slices = int(max(1, min(256 // ksel, 768 // max(n_blocks2, 1), n_tiles)))
+            n_slices = int(max(1, min(1024 // ksel, 768 // max(n_blocks2, 1), n_tiles)))
             c2_idx = torch.empty(n_slices * q2_pad * cap, dtype=torch.int32, device=dev)
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
@@ -381,8 +383,8 @@ class HipOps:
             check(
                 lib.meld_knn_refine(
                     ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), ksel, cap, knn, float(decay),
-                    float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3)), ptr(bw), ptr(cand_val), ptr(keep_cnt), ptr(flag_rows), ptr(n_flag),
-                    ptr(rows2), cap, ptr(cand_idx), st,
+                    float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
+                    ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), st,
                 ),
                 "meld_knn_refine(stage 2)",
             )
