@@ -60,9 +60,30 @@ __global__ __launch_bounds__(256) void refine_kernel(
       idx[e] = cand_idx[ro + c];
       const double* xj = X + (int64_t)idx[e] * d;
       double s = 0.0;
-      for (int k = 0; k < d; ++k) {
-        const double t = xi[k] - xj[k];
+      if ((d & 1) == 0) {
+        // rows are 16-byte aligned when d is even: 16-byte loads.  Summation order (shared with the
+        // exact sweep below, which must reproduce these distances bit for bit): even coordinates in
+        // one FMA chain, odd coordinates in another, then the sum of the two.
+        const double2* xi2 = reinterpret_cast<const double2*>(xi);
+        const double2* xj2 = reinterpret_cast<const double2*>(xj);
+        double s1 = 0.0;
+        for (int k = 0; k < d / 2; ++k) {
+          const double2 a = xi2[k], b = xj2[k];
+          const double t0 = a.x - b.x, t1 = a.y - b.y;
+          s = fma(t0, t0, s);
+          s1 = fma(t1, t1, s1);
+        }
+        s += s1;
+      } else {
+        double s1 = 0.0;
+        for (int k = 0; k + 1 < d; k += 2) {
+          const double t0 = xi[k] - xj[k], t1 = xi[k + 1] - xj[k + 1];
+          s = fma(t0, t0, s);
+          s1 = fma(t1, t1, s1);
+        }
+        const double t = xi[d - 1] - xj[d - 1];
         s = fma(t, t, s);
+        s += s1;
       }
       dist[e] = sqrt(s);
     } else {
@@ -165,17 +186,28 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
 
   for (int64_t ref = threadIdx.x; ref < N; ref += blockDim.x) {
     const double* xr = X + ref * d;
-    double s[RB_FALL];
+    // same summation order as refine_kernel: even / odd coordinate chains, then their sum
+    double s[RB_FALL], s1[RB_FALL];
 #pragma unroll
-    for (int f = 0; f < RB_FALL; ++f) s[f] = 0.0;
+    for (int f = 0; f < RB_FALL; ++f) s[f] = s1[f] = 0.0;
     for (int k = 0; k < d; ++k) {
       const double xv = xr[k];
+      if ((k & 1) == 0) {
 #pragma unroll
-      for (int f = 0; f < RB_FALL; ++f) {
-        const double t = xq[f * d + k] - xv;
-        s[f] = fma(t, t, s[f]);
+        for (int f = 0; f < RB_FALL; ++f) {
+          const double t = xq[f * d + k] - xv;
+          s[f] = fma(t, t, s[f]);
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < RB_FALL; ++f) {
+          const double t = xq[f * d + k] - xv;
+          s1[f] = fma(t, t, s1[f]);
+        }
       }
     }
+#pragma unroll
+    for (int f = 0; f < RB_FALL; ++f) s[f] += s1[f];
 #pragma unroll
     for (int f = 0; f < RB_FALL; ++f) {
       if (f < nf) {
