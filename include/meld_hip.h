@@ -73,20 +73,24 @@ int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_
 /* ---- second-generation search: split-fp16 operands on v_mfma_f32_32x32x16_f16 (knn16.hip).
  * Same role and output contract as meld_knn_topk (ksel smallest approximate squared distances,
  * rows of stride CAP sorted by (d2, idx), d2 in input units); ~4x less matrix-pipe time.
- *   meld_knn16_prepare: centre by mean[d], scale into [-1,1], augment, split hi/lo:
- *       Rt16  : roundup(N, TS) * KB * 64 bytes   (tile-major [tile][kb][half][plane][ref][8 x fp16])
- *       Q16   : roundup(q_count, BQ) * KB * 64 bytes
+ *   meld_knn16_prepare: centre by mean[d], scale into [-1,1], split hi/lo (d2 = |q|^2 + |r|^2 - 2 q.r:
+ *       the cross term runs on the matrix cores, the fp32 norms are added in the epilogue):
+ *       Rt16  : ceil(N / TS) * meld_knn16_tile_bytes(d)   (per tile: [kb][half][plane][ref][8 x fp16]
+ *               of -2 x, then the TS fp32 squared norms)
+ *       Q16   : roundup(q_count, BQ) * meld_knn16_query_bytes(d);  Qn : roundup(q_count, BQ) fp32 norms
  *       norm2[N], norm2_max[1] (input units), scale_info[4] floats (s, 1/s^2, absmax, pad)
  *   meld_knn16_error_coef: E / max|x~|^2 to pass to meld_knn_refine for this search. */
-int meld_knn16_kblocks(int d);           /* KB = ceil((d+2)/16); <0 if d unsupported (d <= 126) */
+int meld_knn16_kblocks(int d);           /* KB = ceil(d/16); <0 if d unsupported (d <= 128) */
 int meld_knn16_tile_refs(void);          /* TS */
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
 double meld_knn16_error_coef(int nprod);       /* worst case: E <= coef * max|x~|^2 */
 double meld_knn16_error_coef_const(int nprod); /* per-row form: E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~| */
 double meld_knn16_error_coef_lin(int nprod);
+size_t meld_knn16_tile_bytes(int d);     /* bytes of one reference tile (coordinate planes + 64 fp32 norms) */
+size_t meld_knn16_query_bytes(int d);    /* bytes of one query row of Q16 */
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
-                       int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
+                       int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
 /* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_workgroups][n_tiles] with a lower
  * bound (bounding spheres + triangle inequality, scaled space) on the squared distance between
@@ -107,13 +111,13 @@ int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, con
 /* query operands for a list of local rows (rows[i] + q_begin = global index): the re-search of the
  * rows a reduced-precision first pass could not certify */
 int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                            int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16,
+                            int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16, float* Qn,
                             meld_stream_t stream);
 /* n_slices > 1 (small query sets): the references are cut into n_slices ranges, each scanned by its
  * own workgroups into its own candidate rows (buffers of n_slices * roundup(q_count, BQ) rows);
  * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
-int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
-                    int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
+int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
+                    int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
                     const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
                     int32_t* cand_cnt, meld_stream_t stream);
 int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32_t* s_cnt, int64_t q_count,

@@ -40,7 +40,7 @@ constexpr int K16_NWAVE = K16_THREADS / 64;
 constexpr int K16_SLACK = 128;     // CAP = ksel + slack
 constexpr int K16_CAPMAX = 256;
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
-constexpr float K16_BIG = 30000.0f;  // fp16-representable "infinitely far" squared norm (scaled space: |x|^2 <= d)
+constexpr float K16_BIG = 1.0e30f;  // squared norm of the padding references ("infinitely far")
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -174,16 +174,19 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
 template <int KB, int ABL, int NPROD>  // KP16 = 16 * KB >= d + 2; ABL: 0 = product, 1 / 3 = profiling ablations;
                                       // NPROD: split products on the coordinate K blocks (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
 __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_kernel(
-    const _Float16* __restrict__ Q16, const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
-    int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
+    const _Float16* __restrict__ Q16, const float* __restrict__ Qn, const _Float16* __restrict__ Rt16,
+    const float* __restrict__ scale_info, int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
     float err_coef, int tile_origin, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
     int* __restrict__ cand_cnt) {
-  constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
-  constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
-  constexpr int NV = TILE_V4 / K16_THREADS;        // vectors per thread per tile (= KB)
-  constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;
+  // reference tile = KB coordinate blocks [kb][k-half][plane][ref][8 halves] followed by the 64
+  // squared norms (fp32): the norms are added in the epilogue instead of riding through the MFMAs
+  constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8 + 2 * K16_TS;  // halves per reference tile (a norm = 2 halves)
+  constexpr int TILE_V4 = TILE_H / 8;                           // 16-byte vectors per tile = KB * 256 + 16
+  constexpr int NV = TILE_V4 / K16_THREADS;                     // full rounds of the 256 threads = KB
+  constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;       // the 16 norm vectors
   static_assert(NV <= 8, "tile too large for the staging registers");
-  static_assert(K16_THREADS == 256 && K16_TS == 64 && NV == KB, "the plane-skipping staging assumes vector u*256+tid = K block u");
+  static_assert(K16_THREADS == 256 && K16_TS == 64 && NV == KB && HAS_TAIL,
+                "the plane-skipping staging assumes vector u*256+tid = K block u, followed by 16 norm vectors");
 
   __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
   __shared__ int lds_cnt[K16_NWAVE][64];
@@ -212,13 +215,17 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
-      if (NPROD == 3 || kb == KB - 1) blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
+      if (NPROD == 3) blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
     }
   }
+  float nq[2];
+  nq[0] = Qn[q_base + jq];
+  nq[1] = Qn[q_base + 32 + jq];
 
   lds_cnt[wave][lane] = 0;
   if (lane == 0) lds_wthr[0][wave] = lds_wthr[1][wave] = INFINITY;
   float thr[2] = {INFINITY, INFINITY};
+  float thrp[2] = {INFINITY, INFINITY};  // thr - |q|^2
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   // a wave copies one plane.  With NPROD == 1 the lo planes of the coordinate blocks are never read,
   // so the two waves that own them skip those copies (3/8 of the staging traffic).
   const bool lo_wave = ((tid >> 6) & 1) != 0;
-#define K16_NEED(U) (NPROD == 3 || (U) == KB - 1 || !lo_wave)
+#define K16_NEED(U) (NPROD == 3 || !lo_wave)
 #define K16_LOAD(SRC)                                                            \
   do {                                                                           \
     if constexpr (NV > 0) if (K16_NEED(0)) p0 = (SRC)[tid + 0 * K16_THREADS];    \
@@ -302,17 +309,26 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      // The accumulators start from |r|^2 of the lane's 16 references (rows 8m + 4h + (0..3)), the
+      // MFMAs add -2 q.r, and |q|^2 is folded into the threshold (thrp = thr - |q|^2): the epilogue
+      // needs no arithmetic before the vote.
+      const float4* nr4 = reinterpret_cast<const float4*>(lds_tile[cur] + KB * 2 * 2 * K16_TS * 8) + sub * 8 + h;
       f32x16 acc0, acc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+      for (int m4 = 0; m4 < 4; ++m4) {
+        const float4 v4 = nr4[2 * m4];
+        acc0[4 * m4 + 0] = acc1[4 * m4 + 0] = v4.x;
+        acc0[4 * m4 + 1] = acc1[4 * m4 + 1] = v4.y;
+        acc0[4 * m4 + 2] = acc1[4 * m4 + 2] = v4.z;
+        acc0[4 * m4 + 3] = acc1[4 * m4 + 3] = v4.w;
+      }
       // tile layout [kb][h][plane][i][8 halves]: lane reads 16 B at ((kb*2+h)*2+plane)*TS + i
       const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[cur]) + sub * 32 + jq;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        // The last K block carries the norm terms (|x|^2 * 1 + 1 * |y|^2), which cancel against
-        // the cross term and always get the full hi/lo treatment; the coordinate blocks may run
-        // on the hi parts alone (NPROD == 1): error <= 2^-9 max|x~|^2, see meld_knn16_error_coef.
-        const bool full = (NPROD == 3) || (kb == KB - 1);
+        // -2 x.y on the matrix pipe; the coordinate blocks run on the hi parts alone (NPROD == 1,
+        // error <= 2^-9 |x~||y~|, see meld_knn16_error_coef) or with the full hi/lo split
+        const bool full = (NPROD == 3);
         const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], acc1, 0, 0, 0);
@@ -326,6 +342,11 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
       }
 
       const int ref_base = t * K16_TS + sub * 32 + 4 * h;
+      // The vote below reads the accumulators from inline asm (v_min3_f32), which the hazard
+      // recognizer does not look into: the MFMA -> VALU-read wait states (up to 19 for a 16-pass
+      // XDL op) are inserted here by hand, tied to the accumulators so that no MFMA can be
+      // scheduled after them.  (Without this the first registers of a chain were read stale.)
+      asm volatile("s_nop 15\n\ts_nop 4" : "+v"(acc0), "+v"(acc1));
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const f32x16 acc = g ? acc1 : acc0;
@@ -333,23 +354,23 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
           asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
           continue;
         }
-        float av[16];
+        float av[16];  // |r|^2 - 2 q.r  (= d2 - |q|^2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) av[r] = acc[r];
         const float m = min16(av);
         if (ABL == 1) {
           asm volatile("" ::"v"(m));  // profiling ablation: distances + minimum, selection removed
-        } else if (__any(m < thr[g])) {
+        } else if (__any(m < thrp[g])) {
           int* cntp = &lds_cnt[wave][g * 32 + jq];
           const size_t rowoff = (size_t)(row_base + g * 32 + jq) * cap;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[r];
+            const float v = av[r];
             const int ref = ref_base + (r & 3) + 8 * (r >> 2);
-            if (v < thr[g] && ref < n_ref) {
+            if (v < thrp[g] && ref < n_ref) {
               const int pos = atomicAdd(cntp, 1);
               if (pos < cap) {
-                cand_d2[rowoff + pos] = v;
+                cand_d2[rowoff + pos] = v + nq[g];
                 cand_idx[rowoff + pos] = ref;
               }
             }
@@ -373,7 +394,10 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
                 nt = ld_sc1_f(cand_d2 + ro + n_new - 1);
               }
               if (lane == 0) *cj = n_new;
-              if (jq == j) thr[g] = (n >= ksel) ? nt : INFINITY;
+              if (jq == j) {
+                thr[g] = (n >= ksel) ? nt : INFINITY;
+                thrp[g] = thr[g] - nq[g];
+              }
             }
             float w = fmaxf(thr[0], thr[1]);
 #pragma unroll
@@ -543,13 +567,6 @@ __device__ __forceinline__ void split_store(_Float16* dst_hi, _Float16* dst_lo, 
   *dst_lo = (_Float16)(v - (float)hi);
 }
 
-// element c of the augmented vectors of one row, c in [0, KP16)
-__device__ __forceinline__ float aug_ref(const double* xrow, const double* mean, float s, int d, float n, int c) {
-  return (c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : (c == d ? 1.0f : (c == d + 1 ? n : 0.0f));
-}
-__device__ __forceinline__ float aug_query(const double* xrow, const double* mean, float s, int d, float n, int c) {
-  return (c < d) ? s * (float)(xrow[c] - mean[c]) : (c == d ? n : (c == d + 1 ? 1.0f : 0.0f));
-}
 __device__ __forceinline__ float scaled_norm2(const double* xrow, const double* mean, float s, int d) {
   float n = 0.0f;
   for (int k = 0; k < d; ++k) {
@@ -570,16 +587,18 @@ __global__ __launch_bounds__(256) void prepare_refs16_kernel(const double* __res
   if (i < n_pad) {
     const int64_t t = i / K16_TS;
     const int ii = (int)(i % K16_TS);
-    _Float16* tile = Rt16 + (size_t)t * (KB * 2 * 2 * K16_TS * 8);
+    const size_t tile_h = (size_t)KB * 2 * 2 * K16_TS * 8 + 2 * K16_TS;
+    _Float16* tile = Rt16 + (size_t)t * tile_h;
     const bool real = i < N;
     const double* xrow = X + (real ? i : 0) * d;
-    const float n = real ? scaled_norm2(xrow, mean, s, d) : 0.0f;
+    const float n = real ? scaled_norm2(xrow, mean, s, d) : K16_BIG;  // padding rows are infinitely far
     if (real) {
       n_orig = n * scale_info[1];
       norm2[i] = n_orig;
     }
+    reinterpret_cast<float*>(tile + (size_t)KB * 2 * 2 * K16_TS * 8)[ii] = n;
     for (int c = 0; c < KB * 16; ++c) {
-      const float v = real ? aug_ref(xrow, mean, s, d, n, c) : (c == d + 1 ? K16_BIG : 0.0f);
+      const float v = (real && c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : 0.0f;
       const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
       _Float16* base = tile + ((size_t)((kb * 2 + hh) * 2) * K16_TS + ii) * 8 + e;
       split_store(base, base + (size_t)K16_TS * 8, v);
@@ -596,17 +615,17 @@ __global__ __launch_bounds__(256) void prepare_queries16_kernel(const double* __
                                                                 const float* __restrict__ scale_info, int KB,
                                                                 int64_t q_begin, int64_t q_count, int64_t q_pad,
                                                                 const int* __restrict__ rows,
-                                                                _Float16* __restrict__ Q16) {
+                                                                _Float16* __restrict__ Q16, float* __restrict__ Qn) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= q_pad) return;
   const float s = scale_info[0];
   const int64_t qq = q < q_count ? q : q_count - 1;
   const int64_t src = q_begin + (rows ? (int64_t)rows[qq] : qq);
   const double* xrow = X + src * d;
-  const float n = scaled_norm2(xrow, mean, s, d);
+  Qn[q] = scaled_norm2(xrow, mean, s, d);
   _Float16* row = Q16 + (size_t)q * (KB * 32);
   for (int c = 0; c < KB * 16; ++c) {
-    const float v = aug_query(xrow, mean, s, d, n, c);
+    const float v = c < d ? s * (float)(xrow[c] - mean[c]) : 0.0f;
     const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
     _Float16* base = row + ((kb * 2 + hh) * 2) * 8 + e;
     split_store(base, base + 8, v);
@@ -619,12 +638,21 @@ using namespace meld;
 
 extern "C" int meld_knn16_kblocks(int d) {
   if (d < 1) return MELD_ERR_INVALID;
-  const int kb = (d + 2 + 15) / 16;
+  const int kb = (d + 15) / 16;
   if (kb > 8) {
-    set_err("meld_knn16_kblocks: d=%d exceeds the largest instantiated distance kernel (d <= 126)", d);
+    set_err("meld_knn16_kblocks: d=%d exceeds the largest instantiated distance kernel (d <= 128)", d);
     return MELD_ERR_UNSUPPORTED;
   }
   return kb;
+}
+// bytes of one reference tile / one query row of the fp16 operand arrays
+extern "C" size_t meld_knn16_tile_bytes(int d) {
+  const int kb = meld_knn16_kblocks(d);
+  return kb < 0 ? 0 : (size_t)kb * 2 * 2 * K16_TS * 16 + sizeof(float) * K16_TS;
+}
+extern "C" size_t meld_knn16_query_bytes(int d) {
+  const int kb = meld_knn16_kblocks(d);
+  return kb < 0 ? 0 : (size_t)kb * 64;
 }
 extern "C" int meld_knn16_tile_refs(void) { return K16_TS; }
 extern "C" int meld_knn16_block_queries(void) { return K16_BQ; }
@@ -642,7 +670,7 @@ extern "C" int meld_knn16_row_capacity(int ksel) {
 //              <= 3 * 2^-22 * 4 n_max: total < 2^-15 n_max            (measured: 7.6e-7 n_max)
 //   nprod = 1: coordinate blocks on the fp16 hi parts only:
 //              |q.r - qhi.rhi| <= |qlo.r| + |qhi.rlo| <= 2 * 2^-11 |x~_q| |2 x~_r| <= 2^-9 n_max
-//              (Cauchy-Schwarz); the norm block keeps the full split      (measured: 5.4e-4 n_max)
+//              (Cauchy-Schwarz); the norms are added in fp32 in the epilogue   (measured: 5.4e-4 n_max)
 extern "C" double meld_knn16_error_coef(int nprod) {
   const double full = 3.0517578125e-05;  // 2^-15
   return nprod == 1 ? (0.001953125 + full) : full;
@@ -657,9 +685,10 @@ extern "C" double meld_knn16_error_coef_const(int nprod) {
 extern "C" double meld_knn16_error_coef_lin(int nprod) { return nprod == 1 ? 0.001953125 : 0.0; }
 
 extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
-                                  int64_t q_count, void* Rt16, void* Q16, float* norm2, float* norm2_max,
+                                  int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
                                   float* scale_info, meld_stream_t stream) {
-  MELD_CHECK_ARG(X && mean && Rt16 && Q16 && norm2 && norm2_max && scale_info && N > 0, "meld_knn16_prepare: null/empty argument");
+  MELD_CHECK_ARG(X && mean && Rt16 && Q16 && Qn && norm2 && norm2_max && scale_info && N > 0,
+                 "meld_knn16_prepare: null/empty argument");
   MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N, "meld_knn16_prepare: bad query range");
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
@@ -673,7 +702,7 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
                      scale_info, KB, n_pad, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
   const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, st, X, d, mean,
-                     scale_info, KB, q_begin, q_count, q_pad, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16));
+                     scale_info, KB, q_begin, q_count, q_pad, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn);
   MELD_LAUNCH_CHECK("meld_knn16_prepare");
   return MELD_OK;
 }
@@ -681,14 +710,15 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
 // Query operands for a list of rows (second search stage); scale_info / mean as produced by
 // meld_knn16_prepare for the same X.
 extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                                       int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16,
+                                       int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16, float* Qn,
                                        meld_stream_t stream) {
-  MELD_CHECK_ARG(X && mean && scale_info && rows && Q16 && n_rows > 0 && N > 0, "meld_knn16_prepare_rows: bad arguments");
+  MELD_CHECK_ARG(X && mean && scale_info && rows && Q16 && Qn && n_rows > 0 && N > 0,
+                 "meld_knn16_prepare_rows: bad arguments");
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
   const int64_t q_pad = ceil_div(n_rows, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, S(stream), X, d, mean,
-                     scale_info, KB, q_begin, n_rows, q_pad, rows, reinterpret_cast<_Float16*>(Q16));
+                     scale_info, KB, q_begin, n_rows, q_pad, rows, reinterpret_cast<_Float16*>(Q16), Qn);
   MELD_LAUNCH_CHECK("meld_knn16_prepare_rows");
   return MELD_OK;
 }
@@ -721,7 +751,8 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   return MELD_OK;
 }
 
-extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
+extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
+                               int64_t n_ref, int d,
                                int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
                                const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
                                int32_t* cand_cnt, meld_stream_t stream) {
@@ -729,7 +760,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
                  K16_MERGE_MAX);
-  MELD_CHECK_ARG(Q16 && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
+  MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
   const int cap = meld_knn16_row_capacity(ksel);
@@ -749,7 +780,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const void* Rt16, const float* s
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
 #define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
-  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, r,  \
+  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, Qn, r,  \
                      scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
                      tile_origin, cand_idx, cand_d2, cand_cnt)
 #define K16_LAUNCH(KBV, ABLV)        \

@@ -286,10 +286,11 @@ class HipOps:
             err_lin = lib.meld_knn16_error_coef_lin(self.nprod)
             n_tiles = (N + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
-            Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device=dev)
-            Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device=dev)
+            Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device=dev)
+            Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device=dev)
+            Qn = torch.empty(q_pad, dtype=torch.float32, device=dev)
             scale_info = torch.empty(4, dtype=torch.float32, device=dev)
-            check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
+            check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
             tm.stop("prepare")
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
@@ -302,7 +303,7 @@ class HipOps:
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if self.nprod == 1 else None
@@ -363,8 +364,9 @@ class HipOps:
             rows2 = torch.sort(flag_rows[:n_flag_h]).values.contiguous()
             KB, BQ2 = research["KB"], research["BQ"]
             q2_pad = ((n_flag_h + BQ2 - 1) // BQ2) * BQ2
-            Q2 = torch.empty(q2_pad * KB * 64, dtype=torch.uint8, device=dev)
-            check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), st), "meld_knn16_prepare_rows")
+            Q2 = torch.empty(q2_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device=dev)
+            Qn2 = torch.empty(q2_pad, dtype=torch.float32, device=dev)
+            check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), ptr(Qn2), st), "meld_knn16_prepare_rows")
             # few queries: cut the references into slices so that the re-search fills the chip
             n_blocks2 = q2_pad // BQ2
             n_slices = int(max(1, min(1024 // ksel, 768 // max(n_blocks2, 1), n_tiles)))
@@ -372,7 +374,7 @@ class HipOps:
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)

@@ -286,16 +286,17 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     mean = sums / N
     n_tiles = (N + TS - 1) // TS
     q_pad = ((N + BQ - 1) // BQ) * BQ
-    Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device="cuda")
-    Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device="cuda")
+    Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda")
+    Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda")
+    Qn = torch.empty(q_pad, dtype=torch.float32, device="cuda")
     norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
     nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
     sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
-    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -399,20 +400,22 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
     nq = 700  # a subset of the rows as queries, through the row-list form
     rows = torch.arange(100, 100 + nq, dtype=torch.int32, device="cuda")
     q_pad = ((nq + BQ - 1) // BQ) * BQ
-    Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device="cuda")
-    Qall = torch.empty(((N + BQ - 1) // BQ) * BQ * KB * 64, dtype=torch.uint8, device="cuda")
+    Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda")
+    Qall = torch.empty(((N + BQ - 1) // BQ) * BQ * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda")
+    Qnall = torch.empty(((N + BQ - 1) // BQ) * BQ, dtype=torch.float32, device="cuda")
     norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
     nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
     sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
-    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Qall), ptr(norm2), ptr(nmax), ptr(sinfo), st))
-    Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device="cuda")
-    check(lib.meld_knn16_prepare_rows(ptr(Xd), N, d, ptr(mean), ptr(sinfo), 0, ptr(rows), nq, ptr(Q), st))
+    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Qall), ptr(Qnall), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+    Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda")
+    Qn = torch.empty(q_pad, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_prepare_rows(ptr(Xd), N, d, ptr(mean), ptr(sinfo), 0, ptr(rows), nq, ptr(Q), ptr(Qn), st))
     res = {}
     for S in (1, 3):
         ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
         cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
         cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
-        check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, ptr(ci), ptr(cd), ptr(cc), st))
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, ptr(ci), ptr(cd), ptr(cc), st))
         if S > 1:
             mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
             md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")

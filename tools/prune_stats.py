@@ -15,14 +15,14 @@ KB, TS, BQ = lib.meld_knn16_kblocks(d), lib.meld_knn16_tile_refs(), lib.meld_knn
 ksel = 64; cap = lib.meld_knn16_row_capacity(ksel)
 sums = torch.empty(d, dtype=torch.float64, device="cuda"); check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st)); mean = sums / N
 n_tiles = (N + TS - 1) // TS; q_pad = ((N + BQ - 1) // BQ) * BQ
-Rt = torch.empty(n_tiles * TS * KB * 64, dtype=torch.uint8, device="cuda"); Q = torch.empty(q_pad * KB * 64, dtype=torch.uint8, device="cuda")
+Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda"); Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda"); Qn = torch.empty(q_pad, dtype=torch.float32, device="cuda")
 norm2 = torch.empty(N, dtype=torch.float32, device="cuda"); nmax = torch.zeros(1, dtype=torch.float32, device="cuda"); sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
-check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
 tmpb = torch.empty(lib.meld_knn16_bounds_temp_bytes(N, d, N), dtype=torch.uint8, device="cuda")
 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, N) // 4, dtype=torch.float32, device="cuda")
 check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), 0, N, ptr(tmpb), ptr(lb2), st))
 ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-check(lib.meld_knn16_topk(ptr(Q), ptr(Rt), ptr(sinfo), N, d, N, ksel, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
+check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 3, 1, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
 torch.cuda.synchronize()
 s = float(sinfo[0]); 
 thr = cd.view(q_pad, cap)[:N, ksel - 1] * s * s          # final 64th d2 in scaled units
