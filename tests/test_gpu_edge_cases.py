@@ -1,0 +1,137 @@
+"""Edge cases of the hot path against the oracle (GPU): tiny and ragged sizes, extreme
+dimensions, duplicated points, badly scaled / offset data, far outliers (which blow up the
+search-error allowance and push rows through the re-search and exact-sweep paths), large knn."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, rtol=1e-9, algorithm="brute"):
+    from oracle import meld_oracle as mo
+
+    import meld_amd
+
+    G = mo.build_graph(np.asarray(X, dtype=np.float64), knn=knn, decay=decay, thresh=thresh, anisotropy=anisotropy, algorithm=algorithm)
+    DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).cuda(), knn=knn, decay=decay,
+                                  thresh=thresh, anisotropy=anisotropy)
+    A, B = sparse.csr_matrix(DG.W), sparse.csr_matrix(G.W)
+    A.sort_indices(); B.sort_indices()
+    assert A.nnz == B.nnz, (A.nnz, B.nnz)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    np.testing.assert_allclose(A.data, B.data, rtol=rtol)
+    np.testing.assert_allclose(DG.dw, G.dw, rtol=rtol)
+    return DG, G
+
+
+@pytest.mark.parametrize("n", [3, 4, 7, 10, 63, 64, 65, 129, 255, 257, 1000])
+def test_tiny_and_ragged_sizes(n):
+    rng = np.random.default_rng(n)
+    _check_graph(rng.normal(size=(n, 3)), knn=5)
+
+
+@pytest.mark.parametrize("d", [1, 2, 15, 16, 17, 47, 48, 49, 64, 100, 126, 128])
+def test_dimensions(d):
+    rng = np.random.default_rng(d)
+    X = rng.normal(size=(700, d))
+    if d > 20:  # keep the neighbourhoods finite-sized: low intrinsic dimension embedded in d
+        X = rng.normal(size=(700, 4)) @ rng.normal(size=(4, d)) + 0.01 * rng.normal(size=(700, d))
+    _check_graph(X, knn=7)
+
+
+def test_dimension_too_large_fails_loudly():
+    import meld_amd
+
+    X = torch.zeros(100, 200, dtype=torch.float64, device="cuda")
+    with pytest.raises(Exception, match="exceeds the largest"):
+        meld_amd.build_knn_graph(X)
+
+
+def test_duplicated_points():
+    rng = np.random.default_rng(0)
+    base = rng.normal(size=(300, 4))
+    X = np.concatenate([base, base[:40], base[:10]])  # 40 points twice, 10 of them three times
+    DG, G = _check_graph(X, knn=5)
+    assert np.isfinite(DG.dw).all()
+
+
+def test_offset_and_scale_invariance_of_the_search():
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(1500, 10))
+    # sklearn's brute-force distances use |x|^2 + |y|^2 - 2 x.y in fp64, which cancels badly under a
+    # large offset; the tree searches (and the GPU refinement) use direct differences
+    _check_graph(X * 1.0e4 + 3.0e6, knn=10, rtol=1e-6, algorithm="kd_tree")
+    _check_graph(X * 1.0e-6 - 5.0, knn=10, rtol=1e-6, algorithm="kd_tree")
+
+
+def test_far_outliers_go_through_the_fallback_paths():
+    """A few points 1000x farther out than the rest inflate max|x|^2, hence the search-error
+    allowance: most rows cannot be certified by the fast pass and take the re-search / exact sweep,
+    and the graph must still be exact."""
+    rng = np.random.default_rng(2)
+    X = rng.normal(size=(2000, 6))
+    X[:3] *= 1000.0
+    DG, G = _check_graph(X, knn=8)
+    assert DG.info["n_researched_rows"] + DG.info["n_flagged_rows"] > 0
+
+
+@pytest.mark.parametrize("knn", [1, 2, 30, 60])
+def test_knn_range(knn):
+    rng = np.random.default_rng(knn)
+    X = rng.normal(size=(900, 3))
+    _check_graph(X, knn=knn)
+
+
+def test_knn_beyond_the_candidate_list_is_rejected():
+    import meld_amd
+
+    X = torch.randn(2000, 3, dtype=torch.float64, device="cuda")
+    with pytest.raises(NotImplementedError):
+        meld_amd.build_knn_graph(X, knn=200)
+
+
+@pytest.mark.parametrize("decay,thresh,aniso", [(10, 1e-4, 1), (40, 1e-2, 0), (2, 1e-3, 0.5), (100, 1e-6, 1)])
+def test_kernel_parameters(decay, thresh, aniso):
+    rng = np.random.default_rng(5)
+    _check_graph(rng.normal(size=(800, 3)), knn=6, decay=decay, thresh=thresh, anisotropy=aniso, rtol=1e-8)
+
+
+def test_input_containers_and_dtypes():
+    import meld_amd
+
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(400, 5))
+    labels = rng.choice(["a", "b"], size=400)
+    ref = meld_amd.MELD(lmax=0.5).fit_transform(X, labels).values
+    for alt in (X.astype(np.float32), pd.DataFrame(X), torch.from_numpy(X), torch.from_numpy(X).cuda(), np.asfortranarray(X)):
+        out = meld_amd.MELD(lmax=0.5).fit_transform(alt, labels).values
+        tol = 1e-4 if getattr(alt, "dtype", None) in (np.float32,) else 1e-12
+        assert np.abs(out - ref).max() / np.abs(ref).max() < tol
+    with pytest.raises(ValueError):
+        meld_amd.MELD().fit(np.full((10, 2), np.nan))
+    with pytest.raises(ValueError):
+        meld_amd.MELD().fit(np.zeros(10))
+
+
+def test_repeated_transform_with_many_label_sets_and_betas():
+    """§8f row 3: graph and lmax stay resident; only the filter is re-run."""
+    from oracle import meld_oracle as mo
+
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(3000, n_dims=20, seed=6)
+    op = meld_amd.MELD(knn=10, chebyshev_order=30).fit(X)
+    G = mo.build_graph(X, knn=10, algorithm="brute")
+    lmax = op.graph.lmax
+    rng = np.random.default_rng(0)
+    for beta in (5, 60, 150):
+        lab = rng.choice(["x", "y", "z"], size=3000)
+        op.set_params(beta=beta)
+        out = op.transform(lab)
+        samples, ind = mo.sample_indicators(lab)
+        ref = mo.meld_filter(ind, G, beta=beta, chebyshev_order=30, lmax=lmax)
+        assert list(out.columns) == list(samples)
+        assert np.abs(out.values - ref).max() / np.abs(ref).max() < 1e-10
