@@ -178,12 +178,12 @@ def main():
         flops = 2.0 * rows * N * d
         search = G.info.get("search", "f16x3")
         if search == "f16x3":
-            kb = (d + 2 + 15) // 16
+            kb = (d + 15) // 16
             kp = 16 * kb
             nprod = int(G.info.get("nprod", 3))
-            # 16-deep K blocks issued per pair: every block x3 (hi.hi + hi.lo + lo.hi), or with nprod == 1
-            # the coordinate blocks once and only the norm block three times
-            blocks = 3 * kb if nprod == 3 else (kb - 1) + 3
+            # 16-deep K blocks issued per pair: x3 with the full split (hi.hi + hi.lo + lo.hi), x1 on the
+            # hi parts alone (the norms are added outside the MFMAs)
+            blocks = 3 * kb if nprod == 3 else kb
             executed = 2.0 * rows * N * 16 * blocks
             peak, kname = PEAK_MFMA_F16_TFLOPS, "knn16_topk_kernel (split-fp16 hi/lo distance GEMM on v_mfma_f32_32x32x16_f16 + streaming top-k)"
         else:
