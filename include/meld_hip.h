@@ -74,20 +74,21 @@ int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_
  * Same role and output contract as meld_knn_topk (ksel smallest approximate squared distances,
  * rows of stride CAP sorted by (d2, idx), d2 in input units); ~4x less matrix-pipe time.
  *   meld_knn16_prepare: centre by mean[d], scale into [-1,1], split hi/lo (d2 = |q|^2 + |r|^2 - 2 q.r:
- *       the cross term runs on the matrix cores, the fp32 norms are added in the epilogue):
+ *       |r|^2 - 2 q.r runs on the matrix cores -- |r|^2 as three exact fp16 pieces in K slots d .. d+2
+ *       against 1.0 on the query side -- and |q|^2 is folded into the selection threshold):
  *       Rt16  : ceil(N / TS) * meld_knn16_tile_bytes(d)   (per tile: [kb][half][plane][ref][8 x fp16]
- *               of -2 x, then the TS fp32 squared norms)
+ *               of [-2 x, |x|^2 pieces])
  *       Q16   : roundup(q_count, BQ) * meld_knn16_query_bytes(d);  Qn : roundup(q_count, BQ) fp32 norms
  *       norm2[N], norm2_max[1] (input units), scale_info[4] floats (s, 1/s^2, absmax, pad)
  *   meld_knn16_error_coef: E / max|x~|^2 to pass to meld_knn_refine for this search. */
-int meld_knn16_kblocks(int d);           /* KB = ceil(d/16); <0 if d unsupported (d <= 128) */
+int meld_knn16_kblocks(int d);           /* KB = ceil((d+3)/16); <0 if d unsupported (d <= 141) */
 int meld_knn16_tile_refs(void);          /* TS */
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
 double meld_knn16_error_coef(int nprod);       /* worst case: E <= coef * max|x~|^2 */
 double meld_knn16_error_coef_const(int nprod); /* per-row form: E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~| */
 double meld_knn16_error_coef_lin(int nprod);
-size_t meld_knn16_tile_bytes(int d);     /* bytes of one reference tile (coordinate planes + 64 fp32 norms) */
+size_t meld_knn16_tile_bytes(int d);     /* bytes of one reference tile (KB * 4096) */
 size_t meld_knn16_query_bytes(int d);    /* bytes of one query row of Q16 */
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
@@ -104,22 +105,30 @@ size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                       int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream);
-/* nprod selects the precision of the coordinate K blocks: 3 = hi.hi + hi.lo + lo.hi (error bound
- * 2^-16 max|x~|^2), 1 = hi.hi only (half the MFMAs, bound 2^-9 max|x~|^2; rows the looser bound
- * cannot certify go through meld_knn_radius_exact, so results are identical).  The norm block is
- * always evaluated with the full split. */
+/* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
+ * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
+ * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are
+ * identical).  The norm pieces live in the hi plane and are exact in either mode. */
 /* query operands for a list of local rows (rows[i] + q_begin = global index): the re-search of the
  * rows a reduced-precision first pass could not certify */
 int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                             int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16, float* Qn,
                             meld_stream_t stream);
-/* n_slices > 1 (small query sets): the references are cut into n_slices ranges, each scanned by its
+/* thr_init (optional, roundup(q_count, BQ) floats in the SCALED units of the search, i.e. input
+ * d2 * scale_info[0]^2): per query, a bound below which all wanted neighbours are known to lie; the
+ * selection thresholds start there instead of at +inf (the re-search passes the first pass's
+ * ksel-th distance plus both error allowances).  NULL = +inf.
+ * n_slices > 1 (small query sets): the references are cut into n_slices ranges, each scanned by its
  * own workgroups into its own candidate rows (buffers of n_slices * roundup(q_count, BQ) rows);
  * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
 int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                     int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
-                    const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
-                    int32_t* cand_cnt, meld_stream_t stream);
+                    const float* norm2_max, int64_t q_begin, const float* thr_init, int32_t* cand_idx,
+                    float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
+/* workgroups of meld_knn16_topk resident on the device at once (occupancy x CUs); the host hands a
+ * nearly empty last wave of workgroups to a sliced launch instead of letting it run alone */
+int meld_knn16_resident_blocks(int d, int nprod);
+int meld_knn16_max_slices(int ksel); /* largest n_slices meld_knn16_merge_slices accepts */
 int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32_t* s_cnt, int64_t q_count,
                             int ksel, int n_slices, int32_t* out_idx, float* out_d2, int32_t* out_cnt,
                             meld_stream_t stream);

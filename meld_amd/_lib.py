@@ -40,6 +40,7 @@ SIGNATURES = {
     "meld_knn16_error_coef": (_f64, [_i32]),
     "meld_knn16_error_coef_const": (_f64, [_i32]),
     "meld_knn16_error_coef_lin": (_f64, [_i32]),
+    "meld_knn16_resident_blocks": (_i32, [_i32, _i32]),
     "meld_knn16_tile_bytes": (_sz, [_i32]),
     "meld_knn16_query_bytes": (_sz, [_i32]),
     "meld_knn16_prepare": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -47,7 +48,8 @@ SIGNATURES = {
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),
     "meld_knn16_bounds_temp_bytes": (_sz, [_i64, _i32, _i64]),
     "meld_knn16_bounds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
-    "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn16_max_slices": (_i32, [_i32]),
     "meld_knn16_merge_slices": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_radius_exact": (
         _i32,

@@ -40,30 +40,21 @@ constexpr int K16_NWAVE = K16_THREADS / 64;
 constexpr int K16_SLACK = 128;     // CAP = ksel + slack
 constexpr int K16_CAPMAX = 256;
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
-constexpr float K16_BIG = 1.0e30f;  // squared norm of the padding references ("infinitely far")
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// v_min3_f32 without the canonicalising v_max that hipcc puts in front of fminf on MFMA outputs
-// (the accumulators never hold signalling NaNs): 8 instructions for the minimum of 16 values
-// instead of ~36.  Measured: 366 -> 347 ms at 1M cells.
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-  float r;
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float min16(const float (&v)[16]) {
+// minimum of the 16 accumulator values of a lane: plain fminf so that the compiler forms
+// v_min3_f32, schedules them between MFMAs and inserts the MFMA -> VALU wait states itself
+// (an inline-asm v_min3 is invisible to the hazard recognizer: stale accumulators were read).
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float min16(const f32x16& v) {
   const float a = min3f(v[0], v[1], v[2]);
   const float b = min3f(v[3], v[4], v[5]);
   const float c = min3f(v[6], v[7], v[8]);
   const float d = min3f(v[9], v[10], v[11]);
   const float e = min3f(v[12], v[13], v[14]);
-  const float f = min3f(a, b, v[15]);
-  const float g = min3f(c, d, e);
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(f), "v"(g));
-  return r;
+  return __builtin_fminf(min3f(a, b, v[15]), min3f(c, d, e));
 }
 
 __device__ __forceinline__ unsigned ordered_bits(float f) {
@@ -78,18 +69,37 @@ __device__ __forceinline__ int ld_sc1_i(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Keep (unsorted) the entries of a candidate row whose d2 is <= the ksel-th smallest d2.
-// Returns the new count through *n_out and the threshold as return value.  Wave-uniform args.
-__device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__ d2row, int* __restrict__ idxrow,
-                                   int lane, int* n_out) {
+// A candidate row is two half-rows: slots [0, half) are filled by the lanes that hold the query with
+// h = 0, slots [half, 2 half) by the lanes with h = 1, each lane appending with a private register
+// counter (no atomics, no returning LDS operation on the append path).  n0 / n1 = their lengths.
+// Slot p of the row -> is it filled, and its position q in the packed sequence of n0 + n1 entries.
+__device__ __forceinline__ bool knn16_row_slot(int p, int n0, int n1, int half, int* q) {
+  if (p < half) {
+    *q = p;
+    return p < n0;
+  }
+  *q = n0 + (p - half);
+  return (p - half) < n1;
+}
+// position pos of a packed sequence that is split as (m0 | rest) over the two half-rows
+__device__ __forceinline__ int knn16_split_pos(int pos, int m0, int half) { return pos < m0 ? pos : half + (pos - m0); }
+
+// Keep (unsorted) the entries of a candidate row whose d2 is <= the ksel-th smallest d2, spread evenly
+// over the two half-rows.  Returns the new lengths through *n0_out / *n1_out and the threshold as
+// return value.  Wave-uniform arguments.
+__device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, float* __restrict__ d2row,
+                                   int* __restrict__ idxrow, int lane, int* n0_out, int* n1_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's append stores have reached L2
   float d[K16_SLOTS];
   int ix[K16_SLOTS];
   unsigned key[K16_SLOTS];
+  bool valid[K16_SLOTS];
 #pragma unroll
   for (int e = 0; e < K16_SLOTS; ++e) {
     const int p = lane + 64 * e;
-    if (p < n) {
+    int q;
+    valid[e] = p < 2 * half && knn16_row_slot(p, n0, n1, half, &q);
+    if (valid[e]) {
       d[e] = ld_sc1_f(d2row + p);
       ix[e] = ld_sc1_i(idxrow + p);
       key[e] = ordered_bits(d[e]);
@@ -109,46 +119,55 @@ __device__ float knn16_squeeze_row(int n, int ksel, int cap, float* __restrict__
     for (int e = 0; e < K16_SLOTS; ++e) c += __popcll(__ballot(key[e] < trial));
     if (c < ksel) T = trial;
   }
-  // survivors: key <= T (ties at T all stay; if that overflows the row the caller re-ranks)
+  // survivors: key <= T (ties at T all stay; if that leaves no room the caller re-ranks)
+  int total = 0;
+#pragma unroll
+  for (int e = 0; e < K16_SLOTS; ++e) total += __popcll(__ballot(valid[e] && key[e] <= T));
+  const int m0 = (total + 1) >> 1;
   int base = 0;
   float thr = INFINITY;
 #pragma unroll
   for (int e = 0; e < K16_SLOTS; ++e) {
-    const bool keep = key[e] <= T && (lane + 64 * e) < n;
+    const bool keep = valid[e] && key[e] <= T;
     const unsigned long long b = __ballot(keep);
     if (keep) {
-      const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
-      if (pos < cap) {
-        d2row[pos] = d[e];
-        idxrow[pos] = ix[e];
-      }
+      const int dst = knn16_split_pos(base + __popcll(b & ((1ull << lane) - 1ull)), m0, half);
+      d2row[dst] = d[e];
+      idxrow[dst] = ix[e];
     }
     base += __popcll(b);
     const unsigned long long bt = __ballot(keep && key[e] == T);
     if (bt) thr = __shfl(d[e], __ffsll((long long)bt) - 1, 64);
   }
-  *n_out = min(base, cap);
+  *n0_out = m0;
+  *n1_out = total - m0;
   return thr;
 }
 
-// Final ordering of a row: rank by (d2, idx), keep the ksel smallest sorted, scale back.
-__device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restrict__ d2row, int* __restrict__ idxrow,
-                               float* sd, int* si, int lane) {
+// Ordering of a row: rank by (d2, idx), keep the ksel smallest sorted, scale by out_scale.
+// split_m0 < 0: final form, entry of rank r at slot r.  split_m0 >= 0 (mid-scan, after pathological
+// ties): rank r goes to the half-row position knn16_split_pos(r, split_m0, half).
+__device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_scale, int split_m0,
+                               float* __restrict__ d2row, int* __restrict__ idxrow, float* sd, int* si, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int n = n0 + n1;
   float d[K16_SLOTS];
   int ix[K16_SLOTS];
+  bool valid[K16_SLOTS];
 #pragma unroll
   for (int e = 0; e < K16_SLOTS; ++e) {
     const int p = lane + 64 * e;
-    if (p < n) {
+    int q = 0;
+    valid[e] = p < 2 * half && knn16_row_slot(p, n0, n1, half, &q);
+    if (valid[e]) {
       d[e] = ld_sc1_f(d2row + p);
       ix[e] = ld_sc1_i(idxrow + p);
+      sd[q] = d[e];
+      si[q] = ix[e];
     } else {
       d[e] = INFINITY;
       ix[e] = 0x7fffffff;
     }
-    sd[p] = d[e];
-    si[p] = ix[e];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int rk[K16_SLOTS];
@@ -162,37 +181,45 @@ __device__ void knn16_rank_row(int n, int ksel, float out_scale, float* __restri
   }
 #pragma unroll
   for (int q = 0; q < K16_SLOTS; ++q) {
-    const int p = lane + 64 * q;
-    if (p < n && rk[q] < ksel) {
-      d2row[rk[q]] = d[q] * out_scale;
-      idxrow[rk[q]] = ix[q];
+    if (valid[q] && rk[q] < ksel) {
+      const int dst = split_m0 < 0 ? rk[q] : knn16_split_pos(rk[q], split_m0, half);
+      d2row[dst] = d[q] * out_scale;
+      idxrow[dst] = ix[q];
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <int KB, int ABL, int NPROD>  // KP16 = 16 * KB >= d + 2; ABL: 0 = product, 1 / 3 = profiling ablations;
-                                      // NPROD: split products on the coordinate K blocks (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
-__global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_kernel(
+// Waves per SIMD the kernel is compiled for (min = max).  Pinning it (a) keeps the MFMA results in VGPRs
+// -- with a 512-register budget hipcc selects the AGPR form and every vote pays 32 v_accvgpr_read -- and
+// (b) lets the scheduler keep the interleaved MFMA / vote order instead of trading it for occupancy it
+// cannot reach.  The first pass at d <= 61 fits three waves (168 registers): measured 135 ms vs 151 ms
+// with two at 1M cells -- the waves mostly wait (barrier per tile, selection slow path), so occupancy pays.
+__host__ __device__ constexpr int k16_waves(int KB, int ABL, int NPROD) {
+  return (NPROD == 1 && KB <= 4 && ABL != 6) ? 3 : ((KB <= 6 || (NPROD == 1 && KB <= 8)) ? 2 : 1);
+}
+
+template <int KB, int ABL, int NPROD>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
+                                      // only), 6 = product at two waves per SIMD where three are the default;
+                                      // NPROD: split products (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
+__global__ __launch_bounds__(K16_THREADS)
+__attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(
     const _Float16* __restrict__ Q16, const float* __restrict__ Qn, const _Float16* __restrict__ Rt16,
     const float* __restrict__ scale_info, int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
-    float err_coef, int tile_origin, int* __restrict__ cand_idx, float* __restrict__ cand_d2,
-    int* __restrict__ cand_cnt) {
-  // reference tile = KB coordinate blocks [kb][k-half][plane][ref][8 halves] followed by the 64
-  // squared norms (fp32): the norms are added in the epilogue instead of riding through the MFMAs
-  constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8 + 2 * K16_TS;  // halves per reference tile (a norm = 2 halves)
-  constexpr int TILE_V4 = TILE_H / 8;                           // 16-byte vectors per tile = KB * 256 + 16
-  constexpr int NV = TILE_V4 / K16_THREADS;                     // full rounds of the 256 threads = KB
-  constexpr bool HAS_TAIL = (TILE_V4 % K16_THREADS) != 0;       // the 16 norm vectors
-  static_assert(NV <= 8, "tile too large for the staging registers");
-  static_assert(K16_THREADS == 256 && K16_TS == 64 && NV == KB && HAS_TAIL,
-                "the plane-skipping staging assumes vector u*256+tid = K block u, followed by 16 norm vectors");
-
+    float err_coef, int tile_origin, unsigned* __restrict__ convoy, int win_tiles, int tighten, int batch_every, int batch_slack,
+    unsigned long long* __restrict__ stats, const float* __restrict__ thr_init,
+    int* __restrict__ cand_idx,
+    float* __restrict__ cand_d2, int* __restrict__ cand_cnt) {
+  // reference tile = KB K-blocks [kb][k-half][plane][ref][8 halves]; K slots d .. d+2 of the hi plane
+  // hold |r|^2 as three fp16 pieces (against 1.0 on the query side), so the MFMAs deliver
+  // |r|^2 - 2 q.r directly and no norm is read in the loop
+  constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
+  constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
   __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
-  __shared__ int lds_cnt[K16_NWAVE][64];
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
   __shared__ float lds_wthr[2][K16_NWAVE];  // per-wave max threshold, double-buffered by step parity
+  __shared__ unsigned lds_v0;               // convoy position (monotone virtual tile counter) read at start-up
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -222,11 +249,17 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   nq[0] = Qn[q_base + jq];
   nq[1] = Qn[q_base + 32 + jq];
 
-  lds_cnt[wave][lane] = 0;
+  int cnt[2] = {0, 0};  // entries this lane has appended to its half of the rows of its two queries
+  const int half = cap >> 1;
   if (lane == 0) lds_wthr[0][wave] = lds_wthr[1][wave] = INFINITY;
-  float thr[2] = {INFINITY, INFINITY};
-  float thrp[2] = {INFINITY, INFINITY};  // thr - |q|^2
+  // thr_init (optional, scaled units): a bound the caller knows every wanted neighbour to lie below (the
+  // re-search of rows whose first-pass list could not be certified knows one); it starts the thresholds
+  // there instead of at +inf, so that only a handful of candidates per query ever take the slow path
+  // (only thrp = thr - |q|^2 lives in registers: the kernel is compiled for a fixed register budget)
+  auto thr_start = [&](int g) __attribute__((always_inline)) { return thr_init ? thr_init[q_base + g * 32 + jq] : INFINITY; };
+  float thrp[2] = {thr_start(0) - nq[0], thr_start(1) - nq[1]};
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
+  unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
   // the cells are in locality order) and wrapping around: step s -> tile (t0 + s) mod n_tiles.
@@ -237,7 +270,27 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   const float prune_margin = lb2 ? err_coef * norm2_max[0] * scale_info[0] * scale_info[0] : 0.0f;
   const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
   const float* my_lb = lb2 ? lb2 + (size_t)blockIdx.x * n_tiles : nullptr;
+  // Convoy order (convoy != nullptr; single slice, no pruning).  Every workgroup streams the WHOLE
+  // reference set: with each of them at its own position that is n_workgroups x |Rt16| of L2-miss
+  // traffic (500 GB at 1M cells -- the fabric, not the matrix pipe, bounds the kernel).  Instead a
+  // workgroup first scans a short window around its own position (its spatial neighbourhood in
+  // locality order: the thresholds tighten at once), then joins the sweep all resident workgroups
+  // share: it starts at the position the front has published in *convoy and publishes its own
+  // progress, so that the workgroups of an XCD read the same tiles at about the same time and all
+  // but the first find them in L2.  The counter is only a hint -- any start position is correct,
+  // every workgroup still scans every tile exactly once.
+  const int win = convoy ? min(win_tiles, n_scan) : 0;                               // tiles in the own window
+  const int win_lo = convoy ? max(0, min(t0 - (win - K16_BQ / K16_TS) / 2, n_scan - win)) : 0;  // its first tile
+  const int n_rest = n_scan - win;                                                     // tiles outside the window
+  if (convoy && tid == 0) lds_v0 = __hip_atomic_load(convoy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int u0 = 0;  // start of the sweep among the n_rest tiles outside the window (set after the first barrier)
   auto tile_of = [&](int s) {
+    if (convoy) {
+      if (s < win) return tile_lo + win_lo + s;
+      int u = u0 + (s - win);
+      u = u >= n_rest ? u - n_rest : u;
+      return tile_lo + (u < win_lo ? u : u + win);
+    }
     const int t = t0 + s;
     return tile_lo + (t >= n_scan ? t - n_scan : t);
   };
@@ -254,37 +307,43 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
-  const bool tail_ok = HAS_TAIL && (NV * K16_THREADS + tid < TILE_V4);
-  float4 p0, p1, p2, p3, p4, p5, p6, p7, pt;
-  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = pt = make_float4(0.f, 0.f, 0.f, 0.f);
-  // Vector v = tid + u * 256 of a tile is (kb = u, k-half, plane, ref) = (u, tid >> 7, (tid >> 6) & 1, tid & 63):
-  // a wave copies one plane.  With NPROD == 1 the lo planes of the coordinate blocks are never read,
-  // so the two waves that own them skip those copies (3/8 of the staging traffic).
-  const bool lo_wave = ((tid >> 6) & 1) != 0;
-#define K16_NEED(U) (NPROD == 3 || !lo_wave)
-#define K16_LOAD(SRC)                                                            \
-  do {                                                                           \
-    if constexpr (NV > 0) if (K16_NEED(0)) p0 = (SRC)[tid + 0 * K16_THREADS];    \
-    if constexpr (NV > 1) if (K16_NEED(1)) p1 = (SRC)[tid + 1 * K16_THREADS];    \
-    if constexpr (NV > 2) if (K16_NEED(2)) p2 = (SRC)[tid + 2 * K16_THREADS];    \
-    if constexpr (NV > 3) if (K16_NEED(3)) p3 = (SRC)[tid + 3 * K16_THREADS];    \
-    if constexpr (NV > 4) if (K16_NEED(4)) p4 = (SRC)[tid + 4 * K16_THREADS];    \
-    if constexpr (NV > 5) if (K16_NEED(5)) p5 = (SRC)[tid + 5 * K16_THREADS];    \
-    if constexpr (NV > 6) if (K16_NEED(6)) p6 = (SRC)[tid + 6 * K16_THREADS];    \
-    if constexpr (NV > 7) if (K16_NEED(7)) p7 = (SRC)[tid + 7 * K16_THREADS];    \
-    if (tail_ok) pt = (SRC)[tid + NV * K16_THREADS];                             \
+  float4 p0, p1, p2, p3, p4, p5, p6, p7, p8;
+  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Staging through registers, every thread the same number of 16-byte vectors.  NPROD == 3 copies the
+  // whole tile (vector tid + 256 u).  NPROD == 1 never reads the lo planes, so only the hi vectors are
+  // copied: the j-th of them, j = tid + 256 u, sits at ((j >> 6) << 7) + (j & 63) (one 64-vector plane
+  // out of every 128) -- half the staging traffic and no per-wave predication.
+  constexpr int N_STAGE = (NPROD == 3) ? KB * 256 : KB * 128;           // vectors to copy per tile
+  constexpr int NS = (N_STAGE + K16_THREADS - 1) / K16_THREADS;         // rounds
+  constexpr bool STAGE_TAIL = (N_STAGE % K16_THREADS) != 0;             // last round half empty (odd KB, NPROD == 1)
+  static_assert(NS <= 9, "tile too large for the staging registers");
+  const int stage_off = (NPROD == 3) ? tid : (((tid >> 6) << 7) + (tid & 63));
+  constexpr int STAGE_STRIDE = (NPROD == 3) ? K16_THREADS : 2 * K16_THREADS;  // offset step per round
+  const bool stage_last = !STAGE_TAIL || tid < (N_STAGE % K16_THREADS);
+#define K16_ROUND_OK(U) ((U) + 1 < NS || stage_last)
+#define K16_LOAD(SRC)                                                                       \
+  do {                                                                                      \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) p0 = (SRC)[stage_off + 0 * STAGE_STRIDE];    \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) p1 = (SRC)[stage_off + 1 * STAGE_STRIDE];    \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) p2 = (SRC)[stage_off + 2 * STAGE_STRIDE];    \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) p3 = (SRC)[stage_off + 3 * STAGE_STRIDE];    \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) p4 = (SRC)[stage_off + 4 * STAGE_STRIDE];    \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) p5 = (SRC)[stage_off + 5 * STAGE_STRIDE];    \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) p6 = (SRC)[stage_off + 6 * STAGE_STRIDE];    \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) p7 = (SRC)[stage_off + 7 * STAGE_STRIDE];    \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) p8 = (SRC)[stage_off + 8 * STAGE_STRIDE];    \
   } while (0)
-#define K16_STORE(DST)                                                           \
-  do {                                                                           \
-    if constexpr (NV > 0) if (K16_NEED(0)) (DST)[tid + 0 * K16_THREADS] = p0;    \
-    if constexpr (NV > 1) if (K16_NEED(1)) (DST)[tid + 1 * K16_THREADS] = p1;    \
-    if constexpr (NV > 2) if (K16_NEED(2)) (DST)[tid + 2 * K16_THREADS] = p2;    \
-    if constexpr (NV > 3) if (K16_NEED(3)) (DST)[tid + 3 * K16_THREADS] = p3;    \
-    if constexpr (NV > 4) if (K16_NEED(4)) (DST)[tid + 4 * K16_THREADS] = p4;    \
-    if constexpr (NV > 5) if (K16_NEED(5)) (DST)[tid + 5 * K16_THREADS] = p5;    \
-    if constexpr (NV > 6) if (K16_NEED(6)) (DST)[tid + 6 * K16_THREADS] = p6;    \
-    if constexpr (NV > 7) if (K16_NEED(7)) (DST)[tid + 7 * K16_THREADS] = p7;    \
-    if (tail_ok) (DST)[tid + NV * K16_THREADS] = pt;                             \
+#define K16_STORE(DST)                                                                      \
+  do {                                                                                      \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) (DST)[stage_off + 0 * STAGE_STRIDE] = p0;    \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) (DST)[stage_off + 1 * STAGE_STRIDE] = p1;    \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) (DST)[stage_off + 2 * STAGE_STRIDE] = p2;    \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) (DST)[stage_off + 3 * STAGE_STRIDE] = p3;    \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) (DST)[stage_off + 4 * STAGE_STRIDE] = p4;    \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) (DST)[stage_off + 5 * STAGE_STRIDE] = p5;    \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) (DST)[stage_off + 6 * STAGE_STRIDE] = p6;    \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) (DST)[stage_off + 7 * STAGE_STRIDE] = p7;    \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) (DST)[stage_off + 8 * STAGE_STRIDE] = p8;    \
   } while (0)
   {
     const float4* src = R4 + (size_t)tile_of(0) * TILE_V4;
@@ -292,148 +351,284 @@ __global__ __launch_bounds__(K16_THREADS, (KB <= 4 ? 3 : 2)) void knn16_topk_ker
   }
   K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
   __syncthreads();
+  if (convoy && n_rest > 0) {
+    const int v0 = (int)(lds_v0 % (unsigned)n_scan);  // same value for every wave of the workgroup
+    u0 = v0 < win_lo ? v0 : (v0 < win_lo + win ? win_lo : v0 - win);
+    u0 = u0 >= n_rest ? 0 : u0;
+  }
+
+  // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
+  // their loads past the first barrier and then has to guard their first use inside the loop with
+  // s_waitcnt vmcnt(N) -- which, on every later iteration, also waits for the tile loads that were
+  // just issued (vmcnt is in-order) and exposes their latency.  An asm use forces the wait here.
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      asm volatile("" : "+v"(bhi[g][kb]));
+      if (NPROD == 3) asm volatile("" : "+v"(blo[g][kb]));
+    }
+    asm volatile("" : "+v"(nq[g]));
+  }
+
+  // ---- software-pipelined scan -------------------------------------------------------------
+  // A block = 32 references x the wave's 64 queries = one pair of 32x32 accumulator tiles.  A wave
+  // issues in order, so the only way to keep the matrix pipe busy while a block is voted on is to
+  // interleave, in program order, the MFMAs of block b with the (straight-line) vote on block b-1:
+  // two accumulator pairs alternate, accA = sub-tile 0 of the current tile, accB = sub-tile 1 (of the
+  // previous tile at the loop top).  The vote is plain C++ (no inline asm) so that the compiler
+  // schedules it between the MFMAs and supplies the MFMA -> VALU wait states itself.
+  f32x16 accA0, accA1, accB0, accB1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = INFINITY;  // nothing to vote on before the first tile
+  int refB = 0;
+
+  // |r|^2 - 2 q.r of sub-tile `sub` of the tile in lds_tile[buf] (the norm rides in K slots d .. d+2,
+  // |q|^2 is folded into the threshold: thrp = thr - |q|^2)
+  auto mfma_block = [&](int buf, int sub, f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
+    // tile layout [kb][h][plane][i][8 halves]: lane reads 16 B at ((kb*2+h)*2+plane)*TS + i
+    const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[buf]) + sub * 32 + jq;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      // hi parts alone (NPROD == 1, error <= 2^-9 |x~||y~|, see meld_knn16_error_coef) or the
+      // full hi/lo split
+      const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
+      if (NPROD == 3) {
+        const f16x8 alo = a8[((kb * 2 + h) * 2 + 1) * K16_TS];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[0][kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[1][kb], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[0][kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[1][kb], c1, 0, 0, 0);
+      }
+    }
+  };
+  // minimum over the lane's 16 references of each query group (straight-line VALU)
+  auto vote = [&](const f32x16& c0, const f32x16& c1, float& m0, float& m1) __attribute__((always_inline)) {
+    m0 = min16(c0);
+    m1 = min16(c1);
+  };
+  // compact row j of query group g (wave-uniform arguments) and refresh its threshold
+  auto squeeze = [&](int g, int j) __attribute__((always_inline)) {
+    const int cg = g ? cnt[1] : cnt[0];
+    const int n0 = __shfl(cg, j, 64), n1 = __shfl(cg, j + 32, 64);
+    const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
+    int m0, m1;
+    float nt = knn16_squeeze_row(n0, n1, half, ksel, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1);
+    if (m0 > half - 32) {
+      // pathological ties at the threshold: rank the row down to exactly ksel entries
+      knn16_rank_row(m0, m1, half, ksel, 1.0f, (min(m0 + m1, ksel) + 1) >> 1, cand_d2 + ro, cand_idx + ro, lds_sd[wave],
+                     lds_si[wave], lane);
+      const int tot = min(m0 + m1, ksel);
+      m0 = (tot + 1) >> 1;
+      m1 = tot - m0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      nt = ld_sc1_f(cand_d2 + ro + knn16_split_pos(tot - 1, m0, half));
+    }
+    if (jq == j) {
+      const int mine = h ? m1 : m0;
+      if (g) cnt[1] = mine; else cnt[0] = mine;
+      thrp[g] = ((n0 + n1 >= ksel) ? nt : thr_start(g)) - nq[g];
+    }
+  };
+  auto refresh_wmax = [&]() __attribute__((always_inline)) {
+    if (my_lb == nullptr) return;  // only the pruning test reads it
+    float w = fmaxf(thrp[0] + nq[0], thrp[1] + nq[1]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
+    wmax = w;
+  };
+  // slow path: append the entries below the thresholds to the candidate rows, compact full rows.
+  // Hits are sparse (well under one per block on average), so the 16 values of a lane are not walked
+  // one by one: the minimum of each triple is tested wave-wide first and only a triple with a hit
+  // is opened (padding references have |r|^2 = +inf and never pass, so no index test is needed).
+  auto select = [&](const f32x16& c0, const f32x16& c1, float m0, float m1, int ref_base) __attribute__((always_inline)) {
+    unsigned long long need = 0;  // rows to compact: bit 32 g + j
+    if (ABL == 2) ++st_slow;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x16 acc = g ? c1 : c0;
+      if (!__any((g ? m1 : m0) < thrp[g])) continue;
+      const size_t rowoff = (size_t)(row_base + g * 32 + jq) * cap + (size_t)(h * half);
+      auto append = [&](int r) __attribute__((always_inline)) {
+        const float v = acc[r];
+        if (v < thrp[g]) {
+          const int pos = g ? cnt[1]++ : cnt[0]++;
+          if (ABL == 2) ++st_app;
+          cand_d2[rowoff + pos] = v + nq[g];
+          cand_idx[rowoff + pos] = ref_base + (r & 3) + 8 * (r >> 2);
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        if (__any(min3f(acc[3 * t], acc[3 * t + 1], acc[3 * t + 2]) < thrp[g])) {
+          append(3 * t);
+          append(3 * t + 1);
+          append(3 * t + 2);
+        }
+      }
+      if (__any(acc[15] < thrp[g])) append(15);
+      // a half-row is compacted as soon as fewer than 16 free slots remain: a block adds at most 16
+      // entries to it (the lane's 16 references), so an append never runs out of room
+      const unsigned long long full = __ballot((g ? cnt[1] : cnt[0]) > half - 16);
+      need |= ((full | (full >> 32)) & 0xffffffffull) << (32 * g);
+    }
+    if (__builtin_expect(need != 0, 0)) {
+      while (need) {
+        const int j = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        squeeze(j >> 5, j & 31);
+        if (ABL == 2) ++st_sq;
+      }
+      refresh_wmax();
+    }
+  };
+  // Issue order of one pipeline segment (the MFMAs of a block + the vote on the previous one, all in
+  // one basic block): the A-fragment reads first, a few vote instructions to cover their latency,
+  // then every MFMA followed by the VALU instructions that fit into its 32-cycle pipe slot.
+  constexpr int N_MFMA = 2 * KB * (NPROD == 3 ? 3 : 1);
+  constexpr int N_DSR = KB * (NPROD == 3 ? 2 : 1);
+  constexpr int VALU_PER_MFMA = (N_MFMA >= 16) ? 1 : ((N_MFMA >= 8) ? 2 : 4);
+  auto pipeline_order = [&]() __attribute__((always_inline)) {
+    if (NPROD == 3) {
+      __builtin_amdgcn_sched_group_barrier(0x100, N_DSR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+      for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+      }
+    } else {
+      // two A fragments in flight (the register budget of three waves per SIMD has no room for more):
+      // the fragment of K block kb + 2 is requested right after the MFMAs of block kb have issued
+      __builtin_amdgcn_sched_group_barrier(0x100, KB < 2 ? KB : 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+        if (kb + 2 < KB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  // MFMAs of (buf, sub) into (n0, n1) interleaved with the vote on the finished block (c0, c1);
+  // then the slow path if any lane of the finished block has a candidate
+  auto segment = [&](int buf, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
+                     __attribute__((always_inline)) {
+    if (issue) mfma_block(buf, sub, n0, n1);
+    if (ABL == 3) {  // profiling ablation: MFMAs only, accumulators kept live
+      asm volatile("" ::"v"(c0[0]), "v"(c0[15]), "v"(c1[0]), "v"(c1[15]));
+      return;
+    }
+    float m0, m1;
+    vote(c0, c1, m0, m1);
+    const bool hit = m0 < thrp[0] || m1 < thrp[1];
+    if (issue) pipeline_order();
+    if (ABL == 1) {  // profiling ablation: distances + minimum, selection removed
+      asm volatile("" ::"v"(m0), "v"(m1));
+      return;
+    }
+    if (__any(hit)) select(c0, c1, m0, m1, ref_base);
+  };
 
   int s_cur = 0;
   int cur = 0;
   int par = 0;
   while (s_cur < n_scan) {
     // block-uniform bound: every wave reads the values published before the last barrier
-    float bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3]));
-    bound += prune_margin;
+    float bound = 0.0f;
+    if (my_lb) bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3])) + prune_margin;
     const int s_next = next_live(s_cur + 1, bound);
     if (s_next < n_scan) {
       const float4* src = R4 + (size_t)tile_of(s_next) * TILE_V4;
       K16_LOAD(src);
     }
     const int t = tile_of(s_cur);
+    // End of the own window: compact every row that holds more than ksel candidates, so that the
+    // long sweep starts from thresholds that are exact for what has been seen (a stale threshold
+    // admits candidates that cannot survive, and each of them costs a trip through the slow path).
+    // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
+    segment(cur, 0, accA0, accA1, accB0, accB1, refB, true);
+    // sub-tile 1 on the pipe while sub-tile 0 is voted on
+    segment(cur, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
+    refB = t * K16_TS + 32 + 4 * h;
 
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      // The accumulators start from |r|^2 of the lane's 16 references (rows 8m + 4h + (0..3)), the
-      // MFMAs add -2 q.r, and |q|^2 is folded into the threshold (thrp = thr - |q|^2): the epilogue
-      // needs no arithmetic before the vote.
-      const float4* nr4 = reinterpret_cast<const float4*>(lds_tile[cur] + KB * 2 * 2 * K16_TS * 8) + sub * 8 + h;
-      f32x16 acc0, acc1;
-#pragma unroll
-      for (int m4 = 0; m4 < 4; ++m4) {
-        const float4 v4 = nr4[2 * m4];
-        acc0[4 * m4 + 0] = acc1[4 * m4 + 0] = v4.x;
-        acc0[4 * m4 + 1] = acc1[4 * m4 + 1] = v4.y;
-        acc0[4 * m4 + 2] = acc1[4 * m4 + 2] = v4.z;
-        acc0[4 * m4 + 3] = acc1[4 * m4 + 3] = v4.w;
-      }
-      // tile layout [kb][h][plane][i][8 halves]: lane reads 16 B at ((kb*2+h)*2+plane)*TS + i
-      const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[cur]) + sub * 32 + jq;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        // -2 x.y on the matrix pipe; the coordinate blocks run on the hi parts alone (NPROD == 1,
-        // error <= 2^-9 |x~||y~|, see meld_knn16_error_coef) or with the full hi/lo split
-        const bool full = (NPROD == 3);
-        const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], acc1, 0, 0, 0);
-        if (full) {
-          const f16x8 alo = a8[((kb * 2 + h) * 2 + 1) * K16_TS];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[0][kb], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[1][kb], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[0][kb], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[1][kb], acc1, 0, 0, 0);
-        }
-      }
-
-      const int ref_base = t * K16_TS + sub * 32 + 4 * h;
-      // The vote below reads the accumulators from inline asm (v_min3_f32), which the hazard
-      // recognizer does not look into: the MFMA -> VALU-read wait states (up to 19 for a 16-pass
-      // XDL op) are inserted here by hand, tied to the accumulators so that no MFMA can be
-      // scheduled after them.  (Without this the first registers of a chain were read stale.)
-      asm volatile("s_nop 15\n\ts_nop 4" : "+v"(acc0), "+v"(acc1));
+    const bool window_end = convoy && s_cur + 1 == win && win > 0 && tighten;
+    if (window_end || (batch_every > 0 && (s_cur & (batch_every - 1)) == batch_every - 1)) {
+      // (Placed here, in front of the staging store whose vmcnt(0) wait follows anyway: a cold region with
+      // memory operations in front of a pipeline segment makes the compiler wait for ALL outstanding loads at
+      // the join -- the tile loads just issued -- on every iteration.)
+      // Batched compaction, at the same step in every wave of the workgroup (the waves meet at a
+      // barrier per tile, so a compaction at a random moment in one wave stalls all four; done
+      // together the stalls overlap): every row that has gathered more than batch_slack entries beyond
+      // ksel -- or, at the end of the own window, any row above ksel.  Fresher thresholds also mean
+      // fewer candidates that cannot survive.
+      const int limit = ksel + (window_end ? 0 : batch_slack);
+      unsigned long long todo = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const f32x16 acc = g ? acc1 : acc0;
-        if (ABL == 3) {  // profiling ablation: MFMAs only, accumulators kept live
-          asm volatile("" ::"v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
-          continue;
+        const int cg = g ? cnt[1] : cnt[0];
+        const int tot = cg + __shfl_xor(cg, 32, 64);
+        todo |= (__ballot(tot > limit) & 0xffffffffull) << (32 * g);
+      }
+      if (todo) {
+        while (todo) {
+          const int j = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          squeeze(j >> 5, j & 31);
+          if (ABL == 2) ++st_sq;
         }
-        float av[16];  // |r|^2 - 2 q.r  (= d2 - |q|^2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) av[r] = acc[r];
-        const float m = min16(av);
-        if (ABL == 1) {
-          asm volatile("" ::"v"(m));  // profiling ablation: distances + minimum, selection removed
-        } else if (__any(m < thrp[g])) {
-          int* cntp = &lds_cnt[wave][g * 32 + jq];
-          const size_t rowoff = (size_t)(row_base + g * 32 + jq) * cap;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = av[r];
-            const int ref = ref_base + (r & 3) + 8 * (r >> 2);
-            if (v < thrp[g] && ref < n_ref) {
-              const int pos = atomicAdd(cntp, 1);
-              if (pos < cap) {
-                cand_d2[rowoff + pos] = v + nq[g];
-                cand_idx[rowoff + pos] = ref;
-              }
-            }
-          }
-          const int c = __hip_atomic_load(cntp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          unsigned long long need = __ballot(h == 0 && c > cap - 32);
-          if (need) {
-            while (need) {
-              const int j = __ffsll((long long)need) - 1;
-              need &= need - 1;
-              int* cj = &lds_cnt[wave][g * 32 + j];
-              const int n = min(__hip_atomic_load(cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
-              const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
-              int n_new;
-              float nt = knn16_squeeze_row(n, ksel, cap, cand_d2 + ro, cand_idx + ro, lane, &n_new);
-              if (n_new > cap - 32) {
-                // pathological ties at the threshold: rank the row down to exactly ksel entries
-                knn16_rank_row(n_new, ksel, 1.0f, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
-                n_new = min(n_new, ksel);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                nt = ld_sc1_f(cand_d2 + ro + n_new - 1);
-              }
-              if (lane == 0) *cj = n_new;
-              if (jq == j) {
-                thr[g] = (n >= ksel) ? nt : INFINITY;
-                thrp[g] = thr[g] - nq[g];
-              }
-            }
-            float w = fmaxf(thr[0], thr[1]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
-            wmax = w;
-          }
-        }
+        refresh_wmax();
       }
     }
 
     if (s_next < n_scan) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
-    if (lane == 0) lds_wthr[par ^ 1][wave] = wmax;
+    if (my_lb && lane == 0) lds_wthr[par ^ 1][wave] = wmax;
+    // publish the position in the shared sweep (a monotone hint for workgroups that start later)
+    if (convoy && tid == 0 && s_cur >= win && ((s_cur - win) & 31) == 0)
+      __hip_atomic_fetch_max(convoy, lds_v0 + (unsigned)(s_cur - win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     s_cur = s_next;
     cur ^= 1;
     par ^= 1;
   }
+  segment(0, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
 
+  if (ABL == 2 && stats) {  // profiling counters requested (MELD_KNN16_STATS): wave-blocks, slow-path entries, appends, compactions
+    unsigned a = st_app;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) {
+      atomicAdd(stats + 0, (unsigned long long)(2 * n_scan));
+      atomicAdd(stats + 1, (unsigned long long)st_slow);
+      atomicAdd(stats + 2, (unsigned long long)a);
+      atomicAdd(stats + 3, (unsigned long long)st_sq);
+    }
+  }
   // final: sort every row, convert back to input units, publish its length
   const float out_scale = scale_info[1];  // 1 / s^2
   for (int j = 0; j < 64; ++j) {
-    const int n = min(__hip_atomic_load(&lds_cnt[wave][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
+    const int cg = (j >> 5) ? cnt[1] : cnt[0];
+    const int n0 = __shfl(cg, j & 31, 64), n1 = __shfl(cg, (j & 31) + 32, 64);
     const int qr = row_base + j;
     const size_t ro = (size_t)qr * cap;
-    knn16_rank_row(n, ksel, out_scale, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
-    if (lane == 0) cand_cnt[qr] = min(n, ksel);
+    knn16_rank_row(n0, n1, half, ksel, out_scale, -1, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
+    if (lane == 0) cand_cnt[qr] = min(n0 + n1, ksel);
   }
 #undef K16_LOAD
 #undef K16_STORE
-#undef K16_NEED
+#undef K16_ROUND_OK
 }
 
 // Merge the per-slice candidate rows of one query (n_slices * q_pad rows of stride cap) into its
 // final row: the ksel smallest of the union, sorted by (d2, idx).  One wave per query; at most
 // K16_CAPMAX entries in the union.
-constexpr int K16_MERGE_MAX = 1024;                 // entries in the union of the slice lists of one query
+constexpr int K16_MERGE_MAX = 4096;                 // entries in the union of the slice lists of one query
 constexpr int K16_MERGE_SLOTS = K16_MERGE_MAX / 64;  // per lane
 
 __global__ __launch_bounds__(64) void knn16_merge_slices_kernel(const int* __restrict__ s_idx,
@@ -587,21 +782,31 @@ __global__ __launch_bounds__(256) void prepare_refs16_kernel(const double* __res
   if (i < n_pad) {
     const int64_t t = i / K16_TS;
     const int ii = (int)(i % K16_TS);
-    const size_t tile_h = (size_t)KB * 2 * 2 * K16_TS * 8 + 2 * K16_TS;
+    const size_t tile_h = (size_t)KB * 2 * 2 * K16_TS * 8;
     _Float16* tile = Rt16 + (size_t)t * tile_h;
     const bool real = i < N;
     const double* xrow = X + (real ? i : 0) * d;
-    const float n = real ? scaled_norm2(xrow, mean, s, d) : K16_BIG;  // padding rows are infinitely far
+    const float n = real ? scaled_norm2(xrow, mean, s, d) : INFINITY;  // padding rows are infinitely far
     if (real) {
       n_orig = n * scale_info[1];
       norm2[i] = n_orig;
     }
-    reinterpret_cast<float*>(tile + (size_t)KB * 2 * 2 * K16_TS * 8)[ii] = n;
+    // |r|^2 = n1 + n2 + n3 (fp16 pieces; residual <= 2^-33 n, or 2^-25 absolute once n3 is subnormal)
+    // (a padding row is (+inf, 0, 0): inf * 1.0 accumulates to +inf, which never passes `< thr`)
+    const _Float16 n1 = (_Float16)n;
+    const float r1 = real ? n - (float)n1 : 0.0f;
+    const _Float16 n2 = (_Float16)r1;
+    const _Float16 n3 = (_Float16)(r1 - (float)n2);
     for (int c = 0; c < KB * 16; ++c) {
-      const float v = (real && c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : 0.0f;
       const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
       _Float16* base = tile + ((size_t)((kb * 2 + hh) * 2) * K16_TS + ii) * 8 + e;
-      split_store(base, base + (size_t)K16_TS * 8, v);
+      if (c >= d && c < d + 3) {  // norm pieces: hi plane only (their products with 1.0 are exact)
+        *base = c == d ? n1 : (c == d + 1 ? n2 : n3);
+        base[(size_t)K16_TS * 8] = (_Float16)0.0f;
+      } else {
+        const float v = (real && c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : 0.0f;
+        split_store(base, base + (size_t)K16_TS * 8, v);
+      }
     }
   }
   float m = n_orig;
@@ -625,7 +830,8 @@ __global__ __launch_bounds__(256) void prepare_queries16_kernel(const double* __
   Qn[q] = scaled_norm2(xrow, mean, s, d);
   _Float16* row = Q16 + (size_t)q * (KB * 32);
   for (int c = 0; c < KB * 16; ++c) {
-    const float v = c < d ? s * (float)(xrow[c] - mean[c]) : 0.0f;
+    // K slots d .. d+2 carry 1.0 against the three norm pieces of the references
+    const float v = c < d ? s * (float)(xrow[c] - mean[c]) : (c < d + 3 ? 1.0f : 0.0f);
     const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
     _Float16* base = row + ((kb * 2 + hh) * 2) * 8 + e;
     split_store(base, base + 8, v);
@@ -638,9 +844,9 @@ using namespace meld;
 
 extern "C" int meld_knn16_kblocks(int d) {
   if (d < 1) return MELD_ERR_INVALID;
-  const int kb = (d + 15) / 16;
-  if (kb > 8) {
-    set_err("meld_knn16_kblocks: d=%d exceeds the largest instantiated distance kernel (d <= 128)", d);
+  const int kb = (d + 3 + 15) / 16;  // d coordinates + three K slots for the reference norm
+  if (kb > 9) {
+    set_err("meld_knn16_kblocks: d=%d exceeds the largest instantiated distance kernel (d <= 141)", d);
     return MELD_ERR_UNSUPPORTED;
   }
   return kb;
@@ -648,7 +854,7 @@ extern "C" int meld_knn16_kblocks(int d) {
 // bytes of one reference tile / one query row of the fp16 operand arrays
 extern "C" size_t meld_knn16_tile_bytes(int d) {
   const int kb = meld_knn16_kblocks(d);
-  return kb < 0 ? 0 : (size_t)kb * 2 * 2 * K16_TS * 16 + sizeof(float) * K16_TS;
+  return kb < 0 ? 0 : (size_t)kb * 2 * 2 * K16_TS * 16;
 }
 extern "C" size_t meld_knn16_query_bytes(int d) {
   const int kb = meld_knn16_kblocks(d);
@@ -665,14 +871,16 @@ extern "C" int meld_knn16_row_capacity(int ksel) {
 }
 // Bound on |d2_approx - d2_exact| / max_i |x~_i|^2 (n_max) that meld_knn_refine budgets for.
 // d2 = sum_c q_c r_c with sum |q_c r_c| <= |x~_q|^2 + |x~_r|^2 + 2 |x~_q||x~_r| <= 4 n_max.
-//   fp32 accumulation of <= 64 products per chain: gamma_64 * 4 n_max = 2^-16 n_max;
+//   The kernel accumulates |r|^2 - 2 q.r, sum of |terms| <= |r|^2 + 2 |q||r| <= 3 n_max, over <= 144 K
+//   slots (x3 products with the full split): fp32 accumulation error <= gamma_432 * 3 n_max < 2^-14.3 n_max;
+//   |r|^2 itself enters as three exact fp16 pieces (residual <= 2^-33 n_max + 2^-25);
 //   nprod = 3: every operand is hi + lo (|v - hi - lo| <= 2^-22 |v|), dropped lo.lo terms
-//              <= 3 * 2^-22 * 4 n_max: total < 2^-15 n_max            (measured: 7.6e-7 n_max)
+//              <= 3 * 2^-22 * 2 n_max: total < 2^-14 n_max            (measured: 7.6e-7 n_max)
 //   nprod = 1: coordinate blocks on the fp16 hi parts only:
 //              |q.r - qhi.rhi| <= |qlo.r| + |qhi.rlo| <= 2 * 2^-11 |x~_q| |2 x~_r| <= 2^-9 n_max
-//              (Cauchy-Schwarz); the norms are added in fp32 in the epilogue   (measured: 5.4e-4 n_max)
+//              (Cauchy-Schwarz)                                        (measured: 5.4e-4 n_max)
 extern "C" double meld_knn16_error_coef(int nprod) {
-  const double full = 3.0517578125e-05;  // 2^-15
+  const double full = 6.103515625e-05;  // 2^-14
   return nprod == 1 ? (0.001953125 + full) : full;
 }
 // The same bound split for a per-row allowance  E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~|
@@ -680,7 +888,7 @@ extern "C" double meld_knn16_error_coef(int nprod) {
 // the data get a tighter allowance than the global worst case.
 extern "C" double meld_knn16_error_coef_const(int nprod) {
   (void)nprod;
-  return 3.0517578125e-05;
+  return 6.103515625e-05;  // 2^-14
 }
 extern "C" double meld_knn16_error_coef_lin(int nprod) { return nprod == 1 ? 0.001953125 : 0.0; }
 
@@ -754,8 +962,8 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                                int64_t n_ref, int d,
                                int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
-                               const float* norm2_max, int64_t q_begin, int32_t* cand_idx, float* cand_d2,
-                               int32_t* cand_cnt, meld_stream_t stream) {
+                               const float* norm2_max, int64_t q_begin, const float* thr_init, int32_t* cand_idx,
+                               float* cand_d2, int32_t* cand_cnt, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
@@ -779,10 +987,40 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   const size_t pad_lds = pad_env ? (size_t)atoi(pad_env) : 0;
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
+  // convoy order (see the kernel): a per-device counter, zeroed on the launch stream; only a hint,
+  // so concurrent launches sharing it are harmless.  MELD_KNN16_CONVOY=0 / MELD_KNN16_WINDOW=<tiles>
+  // are profiling hooks.
+  unsigned* convoy = nullptr;
+  unsigned long long* stats = nullptr;
+  int win_tiles = 16;
+  int tighten = 1;
+  int batch_every = 8, batch_slack = 32;  // batched compaction: every 8 tiles, rows with > ksel + 32 entries
+  if (const char* e = getenv("MELD_KNN16_BATCH_EVERY")) {  // profiling hooks (a power of two, or 0 = off)
+    batch_every = atoi(e);
+    MELD_CHECK_ARG(batch_every >= 0 && (batch_every & (batch_every - 1)) == 0, "MELD_KNN16_BATCH_EVERY must be a power of two");
+  }
+  if (const char* e = getenv("MELD_KNN16_BATCH_SLACK")) batch_slack = std::max(0, atoi(e));
+  {
+    static unsigned* counters[64] = {nullptr};  // (a racing first call leaks 256 B at worst)
+    int dev = 0;
+    MELD_HIP_CALL(hipGetDevice(&dev));
+    MELD_CHECK_ARG(dev >= 0 && dev < 64, "meld_knn16_topk: device index out of range");
+    if (counters[dev] == nullptr) MELD_HIP_CALL(hipMalloc(reinterpret_cast<void**>(&counters[dev]), 256));
+    MELD_HIP_CALL(hipMemsetAsync(counters[dev], 0, 256, S(stream)));
+    if (getenv("MELD_KNN16_STATS")) stats = reinterpret_cast<unsigned long long*>(counters[dev] + 8);  // profiling hook
+    if (n_slices == 1 && lb2 == nullptr) {
+      const char* cv_env = getenv("MELD_KNN16_CONVOY");
+      const char* win_env = getenv("MELD_KNN16_WINDOW");
+      const char* tg_env = getenv("MELD_KNN16_TIGHTEN");
+      if (win_env) win_tiles = std::max(K16_BQ / K16_TS, atoi(win_env));
+      if (tg_env) tighten = atoi(tg_env);
+      if (cv_env && atoi(cv_env) != 0) convoy = counters[dev];
+    }
+  }
 #define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
   hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, Qn, r,  \
                      scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
-                     tile_origin, cand_idx, cand_d2, cand_cnt)
+                     tile_origin, convoy, win_tiles, tighten, batch_every, batch_slack, stats, thr_init, cand_idx, cand_d2, cand_cnt)
 #define K16_LAUNCH(KBV, ABLV)        \
   do {                               \
     if (nprod == 1)                  \
@@ -796,6 +1034,10 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
       K16_LAUNCH(KBV, 1);              \
     else if (abl == 3)                 \
       K16_LAUNCH(KBV, 3);              \
+    else if (stats != nullptr)         \
+      K16_LAUNCH(KBV, 2);              \
+    else if (abl == 6 && KBV <= 4)     \
+      K16_LAUNCH((KBV <= 4 ? KBV : 1), 6); \
     else                               \
       K16_LAUNCH(KBV, 0);              \
     break;
@@ -808,6 +1050,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     K16_CASE(6)
     K16_CASE(7)
     K16_CASE(8)
+    K16_CASE(9)
     default:
       set_err("meld_knn16_topk: KB=%d is not an instantiated size", KB);
       return MELD_ERR_UNSUPPORTED;
@@ -816,8 +1059,53 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
 #undef K16_LAUNCH
 #undef K16_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_topk_kernel");
+  if (stats) {
+    unsigned long long st[4] = {0, 0, 0, 0};
+    MELD_HIP_CALL(hipStreamSynchronize(S(stream)));
+    MELD_HIP_CALL(hipMemcpy(st, stats, sizeof(st), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu\n",
+            st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3]);
+  }
   return MELD_OK;
 }
+
+// Workgroups of the search kernel that are resident on the device at once (occupancy x CUs): the
+// host uses it to avoid a nearly empty last wave of workgroups (it hands the remainder to a sliced
+// launch instead).
+extern "C" int meld_knn16_resident_blocks(int d, int nprod) {
+  MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_resident_blocks: nprod must be 1 or 3");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  int per_cu = 0;
+#define K16_OCC(KBV)                                                                                              \
+  case KBV:                                                                                                       \
+    if (nprod == 1) {                                                                                             \
+      MELD_HIP_CALL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn16_topk_kernel<KBV, 0, 1>, K16_THREADS, 0)); \
+    } else {                                                                                                      \
+      MELD_HIP_CALL(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, knn16_topk_kernel<KBV, 0, 3>, K16_THREADS, 0)); \
+    }                                                                                                             \
+    break;
+  switch (KB) {
+    K16_OCC(1)
+    K16_OCC(2)
+    K16_OCC(3)
+    K16_OCC(4)
+    K16_OCC(5)
+    K16_OCC(6)
+    K16_OCC(7)
+    K16_OCC(8)
+    K16_OCC(9)
+    default:
+      return MELD_ERR_UNSUPPORTED;
+  }
+#undef K16_OCC
+  int dev = 0, cus = 0;
+  MELD_HIP_CALL(hipGetDevice(&dev));
+  MELD_HIP_CALL(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return per_cu * cus;
+}
+
+extern "C" int meld_knn16_max_slices(int ksel) { return ksel < 1 ? MELD_ERR_INVALID : std::max(1, K16_MERGE_MAX / ksel); }
 
 extern "C" int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32_t* s_cnt, int64_t q_count,
                                        int ksel, int n_slices, int32_t* out_idx, float* out_d2, int32_t* out_cnt,

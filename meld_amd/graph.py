@@ -252,6 +252,10 @@ class HipOps:
         # the (workgroup, tile) pairs stay live and the table costs 3 ms; it pays on low-dimensional or
         # well-separated data
         self.prune = (os.environ.get("MELD_KNN_PRUNE", "0") != "0") if prune is None else bool(prune)
+        # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
+        # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
+        # waves and the sliced launch costs more than the idle tail, so it is off
+        self.split_tail = os.environ.get("MELD_KNN_SPLIT_TAIL", "0") != "0"
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
         self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
@@ -302,8 +306,32 @@ class HipOps:
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count) // 4, dtype=torch.float32, device=dev)
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
+            # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
+            # of the chip idle is searched separately with the references cut into slices, so that its
+            # few query blocks x slices fill the chip again.
+            n_blocks = q_pad // BQ
+            q_main, tail_slices = q_count, 1
+            if lb2 is None and self.split_tail:
+                resident = lib.meld_knn16_resident_blocks(d, self.nprod)
+                if resident < 0:
+                    check(resident, "meld_knn16_resident_blocks")
+                tail_blocks = n_blocks % resident if resident > 0 else 0
+                if n_blocks > resident and 0 < tail_blocks <= resident // 2:
+                    tail_slices = int(max(1, min(lib.meld_knn16_max_slices(ksel), resident // tail_blocks, n_tiles)))
+                    if tail_slices > 1:
+                        q_main = (n_blocks - tail_blocks) * BQ
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_count, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                if q_main < q_count:
+                    q_tail = q_count - q_main
+                    qt_pad = q_pad - q_main
+                    qb = lib.meld_knn16_query_bytes(d)
+                    t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
+                    t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
+                    t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, self.nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, ptr(t_idx), ptr(t_d2), ptr(t_cnt), st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
+                    del t_idx, t_d2, t_cnt
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if self.nprod == 1 else None
@@ -369,12 +397,31 @@ class HipOps:
             check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), ptr(Qn2), st), "meld_knn16_prepare_rows")
             # few queries: cut the references into slices so that the re-search fills the chip
             n_blocks2 = q2_pad // BQ2
-            n_slices = int(max(1, min(1024 // ksel, 768 // max(n_blocks2, 1), n_tiles)))
+            resident = lib.meld_knn16_resident_blocks(d, 3)
+            if resident < 0:
+                check(resident, "meld_knn16_resident_blocks")
+            n_slices = int(max(1, min(lib.meld_knn16_max_slices(ksel), 2 * resident // max(n_blocks2, 1), n_tiles)))
+            # Start the thresholds of the re-search at a bound instead of +inf: the first pass found ksel
+            # references with approximate d2 <= tau, so the true ksel-th distance is <= tau + E1 and its
+            # full-precision approximation <= tau + E1 + E3 -- nothing above that can enter the list.
+            # (Without it every slice selects from scratch: 19k appends per query at 1M cells.)
+            r64 = rows2.to(torch.int64)
+            cnt1 = cand_cnt[r64].to(torch.int64)
+            tau = cand_d2[r64 * cap + (cnt1 - 1).clamp_(min=0)].to(torch.float64)
+            nmx = nmax.to(torch.float64)
+            e1 = float(err_coef) * nmx + float(err_lin) * torch.sqrt(norm2[q_begin + r64].to(torch.float64) * nmx)
+            e3 = float(lib.meld_knn16_error_coef(3)) * nmx
+            s2 = research["scale_info"][0].to(torch.float64) ** 2
+            bound = ((tau + e1 + e3) * s2 * (1.0 + 1e-5)).to(torch.float32)
+            bound = torch.where(cnt1 >= ksel, bound, torch.full_like(bound, float("inf")))
+            thr2 = torch.empty(q2_pad, dtype=torch.float32, device=dev)
+            thr2[:n_flag_h] = bound
+            thr2[n_flag_h:] = bound[-1]
             c2_idx = torch.empty(n_slices * q2_pad * cap, dtype=torch.int32, device=dev)
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)

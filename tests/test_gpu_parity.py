@@ -296,7 +296,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, ptr(ci), ptr(cd), ptr(cc), st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, ptr(ci), ptr(cd), ptr(cc), st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -415,7 +415,7 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
         cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
         cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
-        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, ptr(ci), ptr(cd), ptr(cc), st))
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, ptr(ci), ptr(cd), ptr(cc), st))
         if S > 1:
             mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
             md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")

@@ -1,22 +1,33 @@
-"""Run only the graph-build stage (for profiling the search kernel): python tools/knn_only.py N [reps]"""
-import sys, os, time
+"""Time the candidate-search stage alone on the benchmark cells (in locality order, as in fit):
+python tools/knn_only.py N[,N...] [reps]      (env: MELD_KNN_* switches of HipOps, MELD_KNN16_ABLATION)"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import meld_amd
+import torch
+
 from meld_amd import graph as mg
 from meld_amd.graph import HipOps
+from meld_amd.reorder import locality_permutation
 from oracle import meld_oracle as mo
-reps = 2
+
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for n in [int(a) for a in sys.argv[1].split(",")]:
     X, _ = mo.synthetic_cells(n, n_dims=50, seed=0)
     Xd = torch.from_numpy(X).cuda()
-    if os.environ.get('ZERO'):
-        Xd = torch.zeros_like(Xd); Xd[0, 0] = 1.0
+    perm = locality_permutation(Xd)
+    if perm is not None:
+        Xd = Xd.index_select(0, perm).contiguous()
     ops = HipOps()
     for r in range(reps):
         mg.record_events(True)
         keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, n, 15, 40, 1e-4, 64)
         torch.cuda.synchronize()
-        ms = mg.event_times_ms()["knn_topk"][0]
-    ideal = (n / 32.0) ** 2 * 12 * 32 / 1024 / 2.4e9 * 1e3
-    print("N=%d knn_topk %.2f ms  ideal@2.4GHz %.2f ms  util %.1f%%  flagged %d  ns/pair %.4f" % (n, ms, ideal, 100 * ideal / ms, info["n_flagged_rows"], ms * 1e6 / n / n))
+        ev = mg.event_times_ms()
+        ms = ev["knn_topk"][0]
+        mg.record_events(False)
+    kb = (50 + 3 + 15) // 16
+    ideal = (n / 32.0) ** 2 * kb * 32 / 1024 / 2.4e9 * 1e3
+    print("N=%d knn_topk %.2f ms  (hi.hi MFMA stream @2.4GHz %.2f ms, %.1f%%)  stage2 %.2f ms  researched %d  swept %d  env %s" % (
+        n, ms, ideal, 100 * ideal / ms, ev.get("knn_topk_stage2", [0.0])[0], info["n_researched_rows"], info["n_flagged_rows"],
+        {k: v for k, v in os.environ.items() if k.startswith("MELD_KNN")}))
