@@ -231,6 +231,16 @@ int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const double* val
                     double coef, double* dots, meld_stream_t stream);
 
 /* r = a * x  (n doubles) -- initialises r = c0/2 * T0 */
+/* Device-resident Lanczos iterations [it_begin, it_begin + n_iter) of L = diag(dw) - W (single GPU:
+ * all n_rows rows local), for the lmax estimate ([UPSTREAM pygsp Graph.estimate_lmax], reference
+ * meld/filter.py:39).  v0/v1/v2 [n_rows]: the three rotating vectors -- before iteration 0, v1 holds the
+ * (un-normalised) start vector and v0 zeros; state[8]: state[0] = state[3] = 1 / |start|, the rest zero; scratch:
+ * 3 * meld_spmm_dot_slots() doubles, zero before iteration 0.  alphas[it] / betas[it] receive the
+ * tridiagonal entries; nothing is synchronised -- read them back when a convergence check is due. */
+int meld_lanczos_steps(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw,
+                       int64_t n_rows, int64_t nnz_hint, double* v0, double* v1, double* v2, double* state,
+                       double* alphas, double* betas, int it_begin, int n_iter, double* scratch,
+                       meld_stream_t stream);
 int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream);
 /* y = a * x + b * y  (n doubles) -- Lanczos vector update.  If nrm2 != NULL it receives
  * meld_spmm_dot_slots() partial sums of <y, y> (zeroed by the call; the caller adds them up). */

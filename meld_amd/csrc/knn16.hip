@@ -521,7 +521,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto segment = [&](int buf, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
                      __attribute__((always_inline)) {
     if (issue) mfma_block(buf, sub, n0, n1);
-    if (ABL == 3) {  // profiling ablation: MFMAs only, accumulators kept live
+    if (ABL == 3 || ABL == 4 || ABL == 8 || ABL == 9) {  // profiling ablation: MFMAs only, accumulators kept live
       asm volatile("" ::"v"(c0[0]), "v"(c0[15]), "v"(c1[0]), "v"(c1[15]));
       return;
     }
@@ -544,8 +544,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     float bound = 0.0f;
     if (my_lb) bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3])) + prune_margin;
     const int s_next = next_live(s_cur + 1, bound);
-    if (s_next < n_scan) {
-      const float4* src = R4 + (size_t)tile_of(s_next) * TILE_V4;
+    if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
+      const float4* src = R4 + (size_t)(ABL == 8 ? (tile_of(s_next) & 63) : tile_of(s_next)) * TILE_V4;
       K16_LOAD(src);
     }
     const int t = tile_of(s_cur);
@@ -587,12 +587,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       }
     }
 
-    if (s_next < n_scan) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    if (s_next < n_scan && ABL != 9) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
     if (my_lb && lane == 0) lds_wthr[par ^ 1][wave] = wmax;
     // publish the position in the shared sweep (a monotone hint for workgroups that start later)
     if (convoy && tid == 0 && s_cur >= win && ((s_cur - win) & 31) == 0)
       __hip_atomic_fetch_max(convoy, lds_v0 + (unsigned)(s_cur - win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    if (ABL != 4 || (s_cur & 1)) __syncthreads();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
     s_cur = s_next;
     cur ^= 1;
     par ^= 1;
@@ -1034,6 +1034,12 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
       K16_LAUNCH(KBV, 1);              \
     else if (abl == 3)                 \
       K16_LAUNCH(KBV, 3);              \
+    else if (abl == 4 && KBV == 4)     \
+      K16_LAUNCH(4, 4);                \
+    else if (abl == 8 && KBV == 4)     \
+      K16_LAUNCH(4, 8);                \
+    else if (abl == 9 && KBV == 4)     \
+      K16_LAUNCH(4, 9);                \
     else if (stats != nullptr)         \
       K16_LAUNCH(KBV, 2);              \
     else if (abl == 6 && KBV <= 4)     \

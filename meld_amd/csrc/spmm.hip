@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256) void cheby_step_kernel(
     const int64_t* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
     const double* __restrict__ dw, int64_t n_rows, int ld, int colofs, const double* __restrict__ x_full,
     int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
-    double coef, double* __restrict__ dots, int chunk) {
+    double coef, double* __restrict__ dots, int chunk, const double* __restrict__ coef_dev) {
+  // coef_dev (device-resident Lanczos): alpha and gamma come from device memory, written by the
+  // previous iteration's scalar kernel, so that no host round trip separates the iterations
+  if (coef_dev != nullptr) {
+    alpha = coef_dev[3];
+    gamma = coef_dev[4];
+  }
   extern __shared__ __attribute__((aligned(16))) double prod[];  // [chunk][P]
   __shared__ int64_t s_rowptr[RB + 1];
   __shared__ double s_dot[2][4];
@@ -185,8 +191,10 @@ __global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ x
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
-                                                    double* __restrict__ y, int64_t n, double* __restrict__ nrm2) {
+                                                    double* __restrict__ y, int64_t n, double* __restrict__ nrm2,
+                                                    const double* __restrict__ a_dev) {
   __shared__ double s_part[4];
+  if (a_dev != nullptr) a = *a_dev;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const double v = a * x[i] + b * y[i];
@@ -212,15 +220,47 @@ __global__ __launch_bounds__(256) void normalize_rows_l1_kernel(const double* __
   for (int c = 0; c < p; ++c) out[i * p + c] = in[i * p + c] / s;
 }
 
+// Scalar steps of the device-resident Lanczos recurrence (one wave each).
+// state: [0] s_cur (v_k = s_cur u_k), [1] s_prev, [2] beta_{k-1}, [3] alpha argument of the next
+// SpMV (= s_cur), [4] its gamma argument (= -beta_{k-1} s_prev), [5] a of w = y + a u (= -alpha_k s_cur)
+__global__ __launch_bounds__(64) void lanczos_alpha_kernel(double* __restrict__ state, const double* __restrict__ dots,
+                                                           double* __restrict__ nrm2, double* __restrict__ alphas, int it) {
+  double v = dots[threadIdx.x];  // <y, u> partial sums, DOT_SLOTS == 64
+  v = wave_sum(v);
+  nrm2[threadIdx.x] = 0.0;  // the axpby kernel that follows accumulates into these slots
+  if (threadIdx.x == 0) {
+    const double alpha = v * state[0];
+    alphas[it] = alpha;
+    state[5] = -alpha * state[0];
+  }
+}
+__global__ __launch_bounds__(64) void lanczos_beta_kernel(double* __restrict__ state, const double* __restrict__ nrm2,
+                                                          double* __restrict__ dots, double* __restrict__ betas, int it) {
+  double v = nrm2[threadIdx.x];
+  v = wave_sum(v);
+  dots[threadIdx.x] = 0.0;  // the next SpMV accumulates <y, u> and <y, y> into these slots
+  dots[DOT_SLOTS + threadIdx.x] = 0.0;
+  if (threadIdx.x == 0) {
+    const double beta = sqrt(v);
+    betas[it] = beta;
+    const double s_cur = state[0];
+    state[1] = s_cur;
+    state[2] = beta;
+    state[0] = 1.0 / beta;
+    state[3] = 1.0 / beta;
+    state[4] = -beta * s_cur;
+  }
+}
+
 template <int P, int RB>
 static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows,
                         int ld, int colofs, const double* x_full, int64_t x_row_offset, const double* z, double* y,
                         double* r, double alpha, double beta, double gamma, double coef, double* dots, int chunk,
-                        hipStream_t st) {
+                        hipStream_t st, const double* coef_dev = nullptr) {
   const unsigned grid = (unsigned)(ceil_div(ceil_div(n_rows, RB), 8) * 8);  // multiple of 8: bijective XCD remap
   const size_t lds = sizeof(double) * (size_t)chunk * P;
   hipLaunchKernelGGL((cheby_step_kernel<P, RB>), dim3(grid), dim3(256), lds, st, rowptr, col, val, dw, n_rows, ld,
-                     colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma, coef, dots, chunk);
+                     colofs, x_full, x_row_offset, z, y, r, alpha, beta, gamma, coef, dots, chunk, coef_dev);
   return 0;
 }
 
@@ -268,6 +308,42 @@ extern "C" int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const 
   return MELD_OK;
 }
 
+// n_iter iterations of the Lanczos recurrence of L = diag(dw) - W with every scalar on the device.
+// Replaces the per-iteration host round trips of the lmax estimate ([UPSTREAM pygsp
+// Graph.estimate_lmax], reference meld/filter.py:39): one SpMV, one wave-sized scalar kernel, one
+// axpby, one scalar kernel per iteration, nothing read back until the caller looks at alphas/betas.
+extern "C" int meld_lanczos_steps(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw,
+                                  int64_t n_rows, int64_t nnz_hint, double* v0, double* v1, double* v2, double* state,
+                                  double* alphas, double* betas, int it_begin, int n_iter, double* scratch,
+                                  meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && dw && v0 && v1 && v2 && state && alphas && betas && scratch && n_rows > 0 && it_begin >= 0 &&
+                     n_iter >= 0,
+                 "meld_lanczos_steps: bad arguments");
+  hipStream_t st = S(stream);
+  double* V[3] = {v0, v1, v2};
+  double* dots = scratch;                  // 2 * DOT_SLOTS, zero on entry of iteration 0 (caller) and re-zeroed by the beta kernel
+  double* nrm2 = scratch + 2 * DOT_SLOTS;  // DOT_SLOTS
+  constexpr int RB = 32;
+  const double mean_span = (nnz_hint > 0) ? (double)nnz_hint / (double)n_rows * RB : 1024.0;
+  const int chunk = (int)std::max<int64_t>(512, std::min<int64_t>((int64_t)(mean_span * 1.3) / 256 * 256 + 256, (48 * 1024) / 8 / 256 * 256));
+  const unsigned grid_ax = (unsigned)std::min<int64_t>(2048, ceil_div(n_rows, 256));
+  for (int it = it_begin; it < it_begin + n_iter; ++it) {
+    // roles rotate with the iteration: u_prev = V[it % 3], u = V[(it + 1) % 3], y = V[(it + 2) % 3]
+    double* u_prev = V[it % 3];
+    double* u = V[(it + 1) % 3];
+    double* y = V[(it + 2) % 3];
+    // y = s_cur L u - beta_{k-1} s_prev u_prev ;  dots <- <y, u>
+    launch_cheby<1, RB>(rowptr, col, val, dw, n_rows, 1, 0, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots, chunk, st,
+                        state);
+    hipLaunchKernelGGL(lanczos_alpha_kernel, dim3(1), dim3(64), 0, st, state, dots, nrm2, alphas, it);
+    // w = y - alpha v_k (in y) ;  nrm2 <- |w|^2
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_ax), dim3(256), 0, st, 0.0, u, 1.0, y, n_rows, nrm2, state + 5);
+    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it);
+  }
+  MELD_LAUNCH_CHECK("meld_lanczos_steps");
+  return MELD_OK;
+}
+
 extern "C" int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream) {
   MELD_CHECK_ARG(x && r && n >= 0, "meld_scale_f64: bad arguments");
   if (n == 0) return MELD_OK;
@@ -283,7 +359,7 @@ extern "C" int meld_axpby_f64(double a, const double* x, double b, double* y, in
   if (nrm2) MELD_HIP_CALL(hipMemsetAsync(nrm2, 0, sizeof(double) * DOT_SLOTS, S(stream)));
   if (n == 0) return MELD_OK;
   const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n, 256));
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), a, x, b, y, n, nrm2);
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), a, x, b, y, n, nrm2, (const double*)nullptr);
   MELD_LAUNCH_CHECK("axpby_kernel");
   return MELD_OK;
 }

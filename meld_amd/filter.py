@@ -29,18 +29,26 @@ class IndicatorSignal:
     passes this instead of the dense [N, p] matrix so that only the codes cross PCIe."""
 
     def __init__(self, codes, n_columns, scale=None):
-        self.codes = np.ascontiguousarray(codes, dtype=np.int64)
+        # codes: host int array, or an int64 device tensor (labels factorised on the device)
+        self.codes = codes if isinstance(codes, torch.Tensor) else np.ascontiguousarray(codes, dtype=np.int64)
         self.n_columns = int(n_columns)
         self.scale = None if scale is None else np.asarray(scale, dtype=np.float64)
-        self.shape = (self.codes.shape[0], self.n_columns)
+        self.shape = (int(self.codes.shape[0]), self.n_columns)
+
+    def host_codes(self):
+        return self.codes.cpu().numpy() if isinstance(self.codes, torch.Tensor) else self.codes
 
     def to_dense(self):
+        codes = self.host_codes()
         out = np.zeros(self.shape, dtype=np.float64)
-        out[np.arange(self.shape[0]), self.codes] = 1.0 if self.scale is None else self.scale[self.codes]
+        out[np.arange(self.shape[0]), codes] = 1.0 if self.scale is None else self.scale[codes]
         return out
 
     def to_device(self, device):
-        codes = torch.from_numpy(self.codes.astype(np.int32)).to(device).to(torch.int64)
+        if isinstance(self.codes, torch.Tensor):
+            codes = self.codes.to(device=device, dtype=torch.int64)
+        else:
+            codes = torch.from_numpy(self.codes.astype(np.int32)).to(device).to(torch.int64)
         out = torch.zeros(self.shape, dtype=torch.float64, device=device)
         if self.scale is None:
             vals = torch.ones(self.shape[0], dtype=torch.float64, device=device)
@@ -48,7 +56,6 @@ class IndicatorSignal:
             vals = torch.from_numpy(self.scale).to(device)[codes]
         out[torch.arange(self.shape[0], device=device), codes] = vals
         return out
-
 
 
 def _stream():
@@ -135,6 +142,53 @@ def chebyshev_apply(G, signal, coeffs, lmax):
     return r
 
 
+def _ritz_check(alphas, betas, tol):
+    """(theta, relative residual, breakdown) of the k x k Lanczos tridiagonal; betas[k-1] is the
+    residual norm of the last step."""
+    k = len(alphas)
+    T = np.diag(alphas) + np.diag(betas[: k - 1], 1) + np.diag(betas[: k - 1], -1)
+    ev, evec = np.linalg.eigh(T)
+    theta = float(ev[-1])
+    resid = abs(betas[k - 1] * evec[-1, -1]) / max(abs(theta), 1e-300)
+    return theta, resid
+
+
+def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
+    """Single-GPU Lanczos with every scalar on the device (``meld_lanczos_steps``): iterations are
+    enqueued in batches and the tridiagonal entries are read back only when a convergence check is
+    due -- a first batch of 4 checks' worth, then one check per ``check_every`` iterations -- instead of
+    two host round trips per iteration."""
+    dev, n = G.val.device, G.N
+    slots = ops.dot_slots()
+    V = torch.zeros(3, n, dtype=torch.float64, device=dev)
+    V[1].copy_(u0[:n])
+    state = torch.zeros(8, dtype=torch.float64, device=dev)
+    inv = 1.0 / torch.linalg.vector_norm(V[1])
+    state[0] = inv
+    state[3] = inv
+    alphas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
+    betas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(3 * slots, dtype=torch.float64, device=dev)
+    it, theta, resid = 0, 0.0, float("inf")
+    batch = 4 * check_every
+    while it < max_iter:
+        n_iter = min(batch, max_iter - it)
+        ops.lanczos_steps(G, V, state, alphas_d, betas_d, it, n_iter, scratch)
+        it_new = it + n_iter
+        ab = torch.stack([alphas_d[:it_new], betas_d[:it_new]]).cpu().numpy()  # the one synchronisation per batch
+        alphas, betas = ab[0], ab[1]
+        # examine the prefixes a per-iteration loop would have examined
+        for k in range(it + 1, it_new + 1):
+            done = betas[k - 1] <= 1e-14 * max(abs(alphas[k - 1]), 1e-300) or not np.isfinite(betas[k - 1])
+            if k % check_every == 0 or done or k == max_iter:
+                theta, resid = _ritz_check(alphas[:k], betas[:k], tol)
+                if resid <= tol or done:
+                    return theta, dict(iterations=k, residual=resid, tol=tol, device_resident=True)
+        it = it_new
+        batch = check_every
+    return theta, dict(iterations=it, residual=resid, tol=tol, device_resident=True)
+
+
 def lanczos_lmax(G, tol=1e-4, max_iter=300, check_every=5, seed=0):
     """Largest eigenvalue of L = diag(dw) - W by the Lanczos recurrence on the device SpMV.
 
@@ -154,6 +208,9 @@ def lanczos_lmax(G, tol=1e-4, max_iter=300, check_every=5, seed=0):
     idx = torch.arange(G.n_pad, dtype=torch.float64, device=dev)
     u = torch.frac(torch.sin(idx * 12.9898 + float(seed) + 1.0) * 43758.5453) - 0.5
     u[G.N :] = 0.0
+    max_iter = min(max_iter, G.N)
+    if comm is None and hasattr(ops, "lanczos_steps") and G.n_pad == G.N:
+        return _lanczos_lmax_device(G, ops, u, tol, max_iter, check_every)
     nrm = float(torch.linalg.vector_norm(u).item())
     u_prev = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)
     y = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)

@@ -545,6 +545,15 @@ class HipOps:
             "meld_cheby_step",
         )
 
+    def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch):
+        """Iterations [it_begin, it_begin + n_iter) of the device-resident Lanczos recurrence
+        (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors."""
+        check(
+            self.lib.meld_lanczos_steps(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz, ptr(V[0]), ptr(V[1]),
+                                        ptr(V[2]), ptr(state), ptr(alphas), ptr(betas), int(it_begin), int(n_iter), ptr(scratch), _stream()),
+            "meld_lanczos_steps",
+        )
+
     def scale(self, x, a, r):
         check(self.lib.meld_scale_f64(ptr(x), float(a), ptr(r), x.numel(), _stream()), "meld_scale_f64")
 

@@ -13,6 +13,7 @@ from functools import partial
 
 import numpy as np
 import pandas as pd
+import torch
 
 from . import filter as _filter
 from . import utils
@@ -167,6 +168,42 @@ class MELD(GraphEstimator):
         rank[order] = np.arange(order.shape[0])
         return rank[codes], uniques[order]
 
+    # labels below this many cells are factorised on the host (the device path costs a few launches)
+    _DEVICE_FACTORIZE_MIN = 200_000
+
+    @staticmethod
+    def _factorize_device(labels, device):
+        """``_factorize`` on the GPU for fixed-width string / integer labels: the raw label words
+        go over PCIe once, rows are folded into 64-bit keys, ``torch.unique`` groups them, and the
+        grouping is verified word by word against one representative row per group (a key collision
+        falls back to the host path).  Returns (codes as an int64 device tensor, sorted uniques,
+        label counts) or None when the dtype is not eligible."""
+        lab = np.ascontiguousarray(labels)
+        if lab.dtype.kind in "US" and lab.dtype.itemsize % 4 == 0 and lab.dtype.itemsize > 0:
+            words = lab.view(np.int32).reshape(lab.shape[0], -1)
+        elif lab.dtype.kind in "iu" and lab.dtype.itemsize == 8:
+            words = lab.view(np.int32).reshape(lab.shape[0], -1)
+        else:
+            return None
+        n = lab.shape[0]
+        t = torch.from_numpy(words).to(device)
+        key = t[:, 0].to(torch.int64)
+        for c in range(1, t.shape[1]):
+            key = key * 1000003 + t[:, c].to(torch.int64)  # wraps around; verified below
+        _, inv = torch.unique(key, return_inverse=True)
+        p = int(inv.max().item()) + 1
+        first = torch.full((p,), n, dtype=torch.int64, device=device)
+        first.scatter_reduce_(0, inv, torch.arange(n, dtype=torch.int64, device=device), reduce="amin")
+        if not bool((t == t[first][inv]).all().item()):
+            return None  # two different labels share a key
+        uniques = lab[first.cpu().numpy()]
+        order = np.argsort(uniques, kind="stable")  # the p uniques, ordered as np.unique does
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.shape[0])
+        codes = torch.from_numpy(rank).to(device)[inv]
+        counts = torch.bincount(codes, minlength=p).cpu().numpy()
+        return codes, uniques[order], counts
+
     @staticmethod
     def _flatten_labels(sample_labels):
         labels = np.asarray(getattr(sample_labels, "values", sample_labels))
@@ -177,7 +214,7 @@ class MELD(GraphEstimator):
                 raise ValueError("sample_labels must be a single column. Got" "shape={}".format(labels.shape))
         return labels
 
-    def _create_sample_indicators(self, sample_labels, _factorized=None):
+    def _create_sample_indicators(self, sample_labels, _factorized=None, _materialize=True):
         """One 0/1 column per sample label, columns sorted like ``np.unique``."""
         self.sample_labels_ = sample_labels
         labels = self._flatten_labels(sample_labels)
@@ -185,20 +222,21 @@ class MELD(GraphEstimator):
         self._codes = codes
         self._indicator_scale = None  # 0/1 indicators
         self._sample_indicators = None
-        return self.sample_indicators
+        return self.sample_indicators if _materialize else None
 
     @property
     def sample_indicators(self):
         """DataFrame [N, p] of the (optionally column-normalised) sample indicators.  Built on
         first access from the label codes: the filter itself assembles the signal on the device."""
         if getattr(self, "_sample_indicators", None) is None and getattr(self, "_codes", None) is not None:
-            n, p = self._codes.shape[0], self.samples.shape[0]
+            codes = self._codes.cpu().numpy() if isinstance(self._codes, torch.Tensor) else self._codes
+            n, p = codes.shape[0], self.samples.shape[0]
             if self._indicator_scale is None:
                 arr = np.zeros((n, p), dtype=np.int64)
-                arr[np.arange(n), self._codes] = 1
+                arr[np.arange(n), codes] = 1
             else:
                 arr = np.zeros((n, p), dtype=np.float64)
-                arr[np.arange(n), self._codes] = self._indicator_scale[self._codes]
+                arr[np.arange(n), codes] = self._indicator_scale[codes]
             self._sample_indicators = pd.DataFrame(arr, index=getattr(self, "_labels_index", None), columns=self.samples)
         return getattr(self, "_sample_indicators", None)
 
@@ -220,8 +258,17 @@ class MELD(GraphEstimator):
             )
         raw = np.asarray(getattr(sample_labels, "values", sample_labels))
         factorized = None
+        self._label_counts = None
         if raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1):
-            factorized = self._factorize(raw.reshape(-1))  # one pass serves both checks below
+            flat = raw.reshape(-1)
+            dev = getattr(getattr(self.graph, "val", None), "device", None)
+            if flat.shape[0] >= self._DEVICE_FACTORIZE_MIN and dev is not None and dev.type == "cuda":
+                on_device = self._factorize_device(flat, dev)
+                if on_device is not None:
+                    factorized = on_device[:2]
+                    self._label_counts = on_device[2]
+            if factorized is None:
+                factorized = self._factorize(flat)  # one pass serves both checks below
             n_unique = factorized[1].shape[0]
         else:
             n_unique = len(pd.unique(raw.ravel()))
@@ -231,11 +278,13 @@ class MELD(GraphEstimator):
             )
         self._labels_index = sample_labels.index if hasattr(sample_labels, "index") else None
 
-        self._create_sample_indicators(sample_labels, _factorized=factorized)
+        # (the [N, p] DataFrame of indicators is only built if someone reads ``sample_indicators``)
+        self._create_sample_indicators(sample_labels, _factorized=factorized, _materialize=False)
         if self.sample_normalize:
             # each indicator column divided by its sum (reference meld/meld.py:229-232): the column sums
             # are the label counts, so the normalised signal is 1/count at the cell's own label
-            counts = np.bincount(self._codes, minlength=self.samples.shape[0]).astype(np.float64)
+            counts = self._label_counts if self._label_counts is not None else np.bincount(self._codes, minlength=self.samples.shape[0])
+            counts = np.asarray(counts, dtype=np.float64)
             self._indicator_scale = 1.0 / counts
             self._sample_indicators = None
 

@@ -221,3 +221,31 @@ def test_exact_solver_on_sparse_graph_matches_chebyshev():
     assert abs(lmax_exact - lam) / lam < 1e-10
     b = meld.MELD(knn=8, beta=20, solver="chebyshev", chebyshev_order=120, lmax=lmax_exact).fit_transform(X, labels)
     assert np.abs(a.values - b.values).max() / np.abs(a.values).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["U5", "U12", "S8", "int64"])
+def test_device_label_factorization_matches_the_host_path(kind):
+    """Large label arrays are factorised on the GPU (meld.MELD._factorize_device); codes, sorted
+    uniques and counts must equal the host path's (= np.unique(..., return_inverse=True))."""
+    import torch
+
+    import meld_amd
+
+    rng = np.random.default_rng(5)
+    n = 300_000
+    if kind == "int64":
+        pool = np.array([7, -3, 2**40, 0, 11], dtype=np.int64)
+    elif kind == "S8":
+        pool = np.array([b"ctrl", b"treat", b"treat2", b"a"], dtype="S8")
+    else:
+        pool = np.array(["ctrl", "treat", "trea", "b", "zz"], dtype="<" + kind)
+    labels = pool[rng.integers(0, pool.shape[0], size=n)]
+    codes_h, uniq_h = meld_amd.MELD._factorize(labels)
+    out = meld_amd.MELD._factorize_device(labels, torch.device("cuda"))
+    assert out is not None
+    codes_d, uniq_d, counts = out
+    ref_u, ref_inv = np.unique(labels, return_inverse=True)
+    assert np.array_equal(uniq_d, ref_u) and np.array_equal(uniq_h, ref_u)
+    assert np.array_equal(codes_d.cpu().numpy(), ref_inv) and np.array_equal(codes_h, ref_inv)
+    assert np.array_equal(counts, np.bincount(ref_inv))

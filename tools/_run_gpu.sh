@@ -1,13 +1,6 @@
-mkdir -p gpurun_out/r2i
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2i/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2i/pytest.log
-tail -3 gpurun_out/r2i/pytest.log
-{
-python tools/knn_only.py 1000000 3
-MELD_KNN16_BATCH_EVERY=0 python tools/knn_only.py 1000000 3
-MELD_KNN16_BATCH_EVERY=32 python tools/knn_only.py 1000000 3
-MELD_KNN16_BATCH_EVERY=32 MELD_KNN16_BATCH_SLACK=48 python tools/knn_only.py 1000000 3
-MELD_KNN16_ABLATION=6 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=1 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=3 python tools/knn_only.py 1000000 2
-} > gpurun_out/r2i/timing.log 2>&1
-grep -v "amdgpu.ids" gpurun_out/r2i/timing.log | cut -c1-330
+mkdir -p gpurun_out/r2m
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2m/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2m/pytest.log
+tail -5 gpurun_out/r2m/pytest.log
+python bench.py --steps 5 --warmup 1 --cpu-sample 0 --stages > gpurun_out/r2m/bench.log 2>&1
+grep -v "amdgpu.ids" gpurun_out/r2m/bench.log | cut -c1-400; grep -o '"stages.*' gpurun_out/r2m/bench.log
+python tools/profile_transform.py > gpurun_out/r2m/transform.log 2>&1; tail -22 gpurun_out/r2m/transform.log | cut -c1-150
