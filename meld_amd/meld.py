@@ -190,10 +190,11 @@ class MELD(GraphEstimator):
         key = t[:, 0].to(torch.int64)
         for c in range(1, t.shape[1]):
             key = key * 1000003 + t[:, c].to(torch.int64)  # wraps around; verified below
-        _, inv = torch.unique(key, return_inverse=True)
-        p = int(inv.max().item()) + 1
-        first = torch.full((p,), n, dtype=torch.int64, device=device)
-        first.scatter_reduce_(0, inv, torch.arange(n, dtype=torch.int64, device=device), reduce="amin")
+        _, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+        # first occurrence of every group: a stable sort of the codes puts each group's smallest index at
+        # the group's start (a scatter-min over N indices into p slots is an atomic pile-up: 21 ms at 1M, p = 2)
+        by_code = torch.argsort(inv, stable=True)
+        first = by_code[torch.cumsum(cnt, 0) - cnt]
         if not bool((t == t[first][inv]).all().item()):
             return None  # two different labels share a key
         uniques = lab[first.cpu().numpy()]
@@ -201,7 +202,7 @@ class MELD(GraphEstimator):
         rank = np.empty_like(order)
         rank[order] = np.arange(order.shape[0])
         codes = torch.from_numpy(rank).to(device)[inv]
-        counts = torch.bincount(codes, minlength=p).cpu().numpy()
+        counts = cnt.cpu().numpy()[order]
         return codes, uniques[order], counts
 
     @staticmethod

@@ -337,6 +337,33 @@ def test_both_search_kernels_build_the_same_graph():
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("search,nprod", [("f16x3", 1), ("f16x3", 3), ("f32", 3)])
+def test_query_ranges_compose_to_the_full_graph(search, nprod):
+    """What a rank of the row-sharded driver computes (queries [r0, r0 + n) against all references)
+    must be the corresponding rows of the single-range result, for ragged ranges that do not start
+    at a tile or workgroup boundary."""
+    from meld_amd.graph import HipOps
+
+    mo = _oracle()
+    N = 9000
+    X, _ = mo.synthetic_cells(N, n_dims=24, seed=21)
+    Xd = torch.from_numpy(X).cuda()
+    ops = HipOps(search=search, nprod=nprod)
+    keys, vals, bw, _ = ops.directed_kernel_coo(Xd, 0, N, 7, 40, 1e-4, 32)
+    M = keys.shape[0] // 2
+    full = dict(zip(keys[:M].tolist(), vals[:M].tolist()))
+    got = {}
+    for r0, n in ((0, 2999), (2999, 3002), (6001, 2999)):
+        k, v, b, _ = ops.directed_kernel_coo(Xd, r0, n, 7, 40, 1e-4, 32)
+        m = k.shape[0] // 2
+        rows = (k[:m] >> 32)
+        assert int(rows.min()) >= r0 and int(rows.max()) < r0 + n
+        assert torch.equal((k[m:] & 0xFFFFFFFF), rows)  # transposed half: (j, i) of the same entries
+        assert torch.equal(b, bw[r0 : r0 + n])
+        got.update(zip(k[:m].tolist(), v[:m].tolist()))
+    assert got == full
+
+
 def test_locality_reordering_does_not_change_results():
     """The permutation is a memory-layout decision only: identical graph and densities (to
     rounding: summation order inside a row changes) with and without it."""
