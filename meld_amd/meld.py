@@ -123,17 +123,21 @@ class MELD(GraphEstimator):
             raise NotImplementedError("n_landmark is not implemented by the MI355X graph builder")
         if self.decay is None:
             raise NotImplementedError("decay=None (unweighted kNN graph) is not implemented")
-        if self.n_pca is not None and self.n_pca < min(tuple(data.shape)):
-            raise NotImplementedError(
-                "PCA reduction (n_pca={} < min(X.shape)={}) is not implemented; reduce the data first "
-                "or pass n_pca=None".format(self.n_pca, min(tuple(data.shape)))
-            )
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         if isinstance(data, torch.Tensor):
             X = data.to(device="cuda", dtype=torch.float64)
         else:
             X = torch.from_numpy(data).to("cuda")
+        self.data_nu = None
+        if self.n_pca is not None and self.n_pca < min(tuple(X.shape)):
+            # graphtools reduces the data with PCA first (Data._reduce_data) and builds the graph on
+            # the scores; here: exact top-n_pca subspace on the device (meld_amd/pca.py)
+            from .pca import pca_project
+
+            self._log("Calculating PCA ({} components)...".format(self.n_pca))
+            X = pca_project(X, self.n_pca, seed=42 if self.random_state is None else int(self.random_state))
+            self.data_nu = X
         if self.thresh == 0:
             from .dense import build_dense_graph
 

@@ -369,9 +369,28 @@ class OracleGraph:
         self.lmax = None
 
 
-def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree"):
-    """A1-A5: data -> OracleGraph.  No PCA branch: graphtools only reduces when
-    ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger."""
+def pca_reduce(X, n_pca, random_state=42, exact=True):
+    """[UPSTREAM graphtools/base.py Data._reduce_data] graphtools reduces dense data with
+    ``sklearn.decomposition.PCA(n_pca, svd_solver="randomized", random_state=...)`` when
+    ``n_pca < min(X.shape)`` and builds the graph on the scores (reference passes ``n_pca`` through at
+    ``meld/meld.py:117-118``; default 100).  ``exact=True`` uses the full SVD instead -- the subspace
+    the randomized solver approximates -- which is what the product computes; ``exact=False`` is
+    the reference's own (approximate, seed-dependent) step."""
+    from sklearn.decomposition import PCA
+
+    X = np.asarray(X, dtype=np.float64)
+    if n_pca is None or n_pca >= min(X.shape):
+        return X
+    solver = "full" if exact else "randomized"
+    return PCA(n_pca, svd_solver=solver, random_state=random_state).fit_transform(X)
+
+
+def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None):
+    """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
+    ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
+    ``pca_reduce`` first."""
+    if n_pca is not None:
+        X = pca_reduce(X, n_pca)
     if thresh == 0:
         Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
         K = apply_anisotropy(symmetrize(Kd), anisotropy)

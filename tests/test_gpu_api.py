@@ -18,6 +18,12 @@ def _meld():
     return meld_amd
 
 
+def _oracle():
+    from oracle import meld_oracle
+
+    return meld_oracle
+
+
 def load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
@@ -118,9 +124,55 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         meld.MELD().fit_transform(data, labels, sample_idx=labels)  # MNN graph (reference test_mnn)
     with pytest.raises(NotImplementedError):
-        meld.MELD(n_pca=1).fit(data)
+        meld.MELD(n_landmark=50).fit(data)
     with pytest.raises(ValueError):
         meld.MELD(distance="cosine")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n_pca", [((3000, 60), 20), ((600, 900), 15), ((2500, 1200), 10)])
+def test_pca_front_end_matches_the_oracle(shape, n_pca):
+    """n_pca < min(X.shape): the graph is built on the PCA scores (graphtools Data._reduce_data).
+    The product computes the exact subspace (covariance / Gram eigh, randomized range finder above
+    pca.EXACT_MAX); the oracle sklearn's full-SVD PCA.  Distances -- all the graph sees -- are
+    invariant to the sign conventions, so W and the densities must agree to rounding."""
+    import torch
+
+    from meld_amd import pca as mpca
+
+    meld = _meld()
+    mo = _oracle()
+    rng = np.random.default_rng(3)
+    N, G = shape
+    latent = rng.normal(size=(N, 8)) * np.array([9, 7, 5, 4, 3, 2.5, 2, 1.5])
+    X = latent @ rng.normal(size=(8, G)) + 0.05 * rng.normal(size=(N, G)) + rng.normal(size=G)
+    labels = np.where(latent[:, 0] + rng.normal(size=N) > 0, "treat", "ctrl")
+    old = mpca.EXACT_MAX
+    try:
+        if shape == (2500, 1200):
+            mpca.EXACT_MAX = 1000  # force the randomized range finder
+        Y = mpca.pca_project(torch.from_numpy(X).cuda(), n_pca).cpu().numpy()
+        Yr = mo.pca_reduce(X, n_pca)
+        from scipy.spatial.distance import pdist
+
+        sub = rng.choice(N, size=400, replace=False)
+        tol = 1e-9 if shape != (2500, 1200) else 1e-6  # the sketch converges geometrically, not exactly
+        assert np.abs(pdist(Y[sub]) - pdist(Yr[sub])).max() <= tol * pdist(Yr[sub]).max()
+        if shape == (2500, 1200):
+            return
+        op = meld.MELD(n_pca=n_pca, knn=7, chebyshev_order=30, verbose=0)
+        G_ref = mo.build_graph(X, knn=7, n_pca=n_pca)
+        op.fit(X)
+        W = op.graph.W
+        assert (W != 0).multiply(G_ref.W != 0).nnz == W.nnz == G_ref.W.nnz
+        assert abs(W - G_ref.W).max() <= 1e-8
+        lmax = mo.estimate_lmax(G_ref.L, G_ref.dw)
+        op.graph.lmax = lmax
+        dens = op.transform(labels)
+        ref = mo.meld_filter(mo.sample_indicators(labels)[1], G_ref, beta=60, chebyshev_order=30, lmax=lmax)
+        assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+    finally:
+        mpca.EXACT_MAX = old
 
 
 @pytest.mark.parametrize(

@@ -1,9 +1,10 @@
-mkdir -p gpurun_out/r2o
-timeout 900 python -m pytest tests/test_gpu_api.py -x -q -m gpu > gpurun_out/r2o/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2o/pytest.log
-tail -3 gpurun_out/r2o/pytest.log
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/r2o/prof_stdout.log 2>&1
-python tools/rocpd_summary.py /tmp/prof/bench_results.db > gpurun_out/r2o/kernel_stats.md 2>&1
-head -14 gpurun_out/r2o/kernel_stats.md | cut -c1-200
-python bench.py --steps 5 --warmup 1 --stages > gpurun_out/r2o/bench_full.json 2> gpurun_out/r2o/bench_full.err
-cut -c1-300 gpurun_out/r2o/bench_full.json; grep -o '"stages.*' gpurun_out/r2o/bench_full.json | cut -c1-700
+mkdir -p gpurun_out/r2r
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2r/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2r/pytest.log
+tail -12 gpurun_out/r2r/pytest.log
+{
+python tools/time_pca.py 200000 2000 50
+python tools/time_pca.py 1000000 200 50
+python tools/time_pca.py 100000 12000 100
+python bench.py --steps 5 --warmup 1 --cpu-sample 0 --stages
+} > gpurun_out/r2r/timing.log 2>&1
+grep -v "amdgpu.ids" gpurun_out/r2r/timing.log | cut -c1-330; grep -o '"stages.*' gpurun_out/r2r/timing.log | cut -c1-600
