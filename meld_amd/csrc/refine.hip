@@ -51,13 +51,24 @@ __global__ __launch_bounds__(256) void refine_kernel(
   const double* xi = X + gi * d;
   const size_t ro = (size_t)q * cap;
 
+  // search-error allowance: constant part + the part that scales with this row's own norm
+  // (|q.r - q~.r~| <= c_lin |x_q| max|x_r|, the per-row form of the Cauchy-Schwarz bound)
+  double E = err_coef * (double)norm2_max[0];
+  if (norm2 != nullptr) E += err_coef_lin * sqrt((double)norm2[gi] * (double)norm2_max[0]);
+  // Candidates that cannot lie inside the radius are not gathered: the list is sorted by approximate
+  // d2, the exact (knn+1)-th distance^2 is <= approx[knn] + E, so radius^2 <= rf^2 (approx[knn] + E), and
+  // a candidate with approx > rf^2 (approx[knn] + E) + E has exact d2 > radius^2 (>= bandwidth^2): it
+  // ranks behind the bandwidth entry and its kernel value is below thresh either way.
+  double skip_above = INFINITY;
+  if (n > knn) skip_above = radius_factor * radius_factor * ((double)cand_d2[ro + knn] + E) + E;
+
   double dist[2];
   int idx[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int c = lane + 64 * e;
-    if (c < n) {
-      idx[e] = cand_idx[ro + c];
+    if (c < n) idx[e] = cand_idx[ro + c];
+    if (c < n && (double)cand_d2[ro + c] <= skip_above) {
       const double* xj = X + (int64_t)idx[e] * d;
       double s = 0.0;
       if ((d & 1) == 0) {
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
       }
       dist[e] = sqrt(s);
     } else {
-      idx[e] = 0x7fffffff;
+      if (c >= n) idx[e] = 0x7fffffff;
       dist[e] = INFINITY;
     }
   }
@@ -114,10 +125,6 @@ __global__ __launch_bounds__(256) void refine_kernel(
 
   // completeness test in squared-distance space
   const double radius = bw * radius_factor;
-  // search-error allowance: constant part + the part that scales with this row's own norm
-  // (|q.r - q~.r~| <= c_lin |x_q| max|x_r|, the per-row form of the Cauchy-Schwarz bound)
-  double E = err_coef * (double)norm2_max[0];
-  if (norm2 != nullptr) E += err_coef_lin * sqrt((double)norm2[gi] * (double)norm2_max[0]);
   bool complete = true;
   if (cand_cnt[q] >= ksel) {
     const double tau = (double)cand_d2[ro + ksel - 1];
