@@ -756,85 +756,95 @@ __global__ void finish_scale_kernel(float* scale_info) {
   scale_info[1] = 1.0f / (s * s);
 }
 
-__device__ __forceinline__ void split_store(_Float16* dst_hi, _Float16* dst_lo, float v) {
-  const _Float16 hi = (_Float16)v;
-  *dst_hi = hi;
-  *dst_lo = (_Float16)(v - (float)hi);
-}
+// Operand preparation, one workgroup per 64 rows (a reference tile / 64 queries).  The rows are
+// read with coalesced loads into LDS as centred, scaled fp32 values (a thread-per-row version gathers
+// 400-byte-strided rows: 3.5 ms at 1M x 50 against 1 ms here); thread (row, part) then converts every
+// fourth group of 8 K slots and stores hi / lo as 16-byte vectors.
+//   IS_REF: rows [tile * 64, ...) of X -> tile layout [kb][h][plane][ref][8], values -2 x~ and the three
+//           fp16 pieces of |x~|^2 in K slots d .. d+2 (hi plane; padding rows: (+inf, 0, 0));
+//           norm2[i] = |x_i - mean|^2 (input units), norm2_max = their maximum.
+//   else  : query rows q_begin + (rows ? rows[q] : q) -> [q][kb][h][plane][8], values x~ and 1.0 in K slots
+//           d .. d+2; Qn[q] = |x~|^2.
+constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
-__device__ __forceinline__ float scaled_norm2(const double* xrow, const double* mean, float s, int d) {
+template <bool IS_REF>
+__global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                        const double* __restrict__ mean,
+                                                        const float* __restrict__ scale_info, int KB, int64_t q_begin,
+                                                        int64_t n_rows, const int* __restrict__ rows,
+                                                        _Float16* __restrict__ out16, float* __restrict__ out_norm,
+                                                        float* __restrict__ norm2_max) {
+  __shared__ float xs[K16_TS][K16_DMAX + 4];  // row stride 145 floats: odd, conflict-free column walks
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * K16_TS;
+  const float s = scale_info[0];
+  for (int u = tid; u < K16_TS * d; u += 256) {
+    const int r = u / d, k = u - r * d;
+    const int64_t i = row0 + r;
+    float v = 0.0f;
+    if (IS_REF) {
+      if (i < N) v = s * (float)(X[i * d + k] - mean[k]);
+    } else {
+      const int64_t qq = i < n_rows ? i : n_rows - 1;  // padding queries repeat the last one
+      const int64_t src = q_begin + (rows ? (int64_t)rows[qq] : qq);
+      v = s * (float)(X[src * d + k] - mean[k]);
+    }
+    xs[r][k] = v;
+  }
+  __syncthreads();
+  const int r = tid & 63, part = tid >> 6;
+  const int64_t i = row0 + r;
+  const bool real = !IS_REF || i < N;
   float n = 0.0f;
-  for (int k = 0; k < d; ++k) {
-    const float v = s * (float)(xrow[k] - mean[k]);
-    n = fmaf(v, v, n);
-  }
-  return n;
-}
-
-__global__ __launch_bounds__(256) void prepare_refs16_kernel(const double* __restrict__ X, int64_t N, int d,
-                                                             const double* __restrict__ mean,
-                                                             const float* __restrict__ scale_info, int KB,
-                                                             int64_t n_pad, _Float16* __restrict__ Rt16,
-                                                             float* __restrict__ norm2, float* __restrict__ norm2_max) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float s = scale_info[0];
-  float n_orig = 0.0f;
-  if (i < n_pad) {
-    const int64_t t = i / K16_TS;
-    const int ii = (int)(i % K16_TS);
-    const size_t tile_h = (size_t)KB * 2 * 2 * K16_TS * 8;
-    _Float16* tile = Rt16 + (size_t)t * tile_h;
-    const bool real = i < N;
-    const double* xrow = X + (real ? i : 0) * d;
-    const float n = real ? scaled_norm2(xrow, mean, s, d) : INFINITY;  // padding rows are infinitely far
-    if (real) {
-      n_orig = n * scale_info[1];
-      norm2[i] = n_orig;
-    }
-    // |r|^2 = n1 + n2 + n3 (fp16 pieces; residual <= 2^-33 n, or 2^-25 absolute once n3 is subnormal)
-    // (a padding row is (+inf, 0, 0): inf * 1.0 accumulates to +inf, which never passes `< thr`)
-    const _Float16 n1 = (_Float16)n;
-    const float r1 = real ? n - (float)n1 : 0.0f;
-    const _Float16 n2 = (_Float16)r1;
-    const _Float16 n3 = (_Float16)(r1 - (float)n2);
-    for (int c = 0; c < KB * 16; ++c) {
-      const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
-      _Float16* base = tile + ((size_t)((kb * 2 + hh) * 2) * K16_TS + ii) * 8 + e;
-      if (c >= d && c < d + 3) {  // norm pieces: hi plane only (their products with 1.0 are exact)
-        *base = c == d ? n1 : (c == d + 1 ? n2 : n3);
-        base[(size_t)K16_TS * 8] = (_Float16)0.0f;
-      } else {
-        const float v = (real && c < d) ? -2.0f * (s * (float)(xrow[c] - mean[c])) : 0.0f;
-        split_store(base, base + (size_t)K16_TS * 8, v);
-      }
-    }
-  }
-  float m = n_orig;
+  for (int k = 0; k < d; ++k) n = fmaf(xs[r][k], xs[r][k], n);
+  if (!real) n = INFINITY;  // padding references are infinitely far
+  // |r|^2 = n1 + n2 + n3 (fp16 pieces; residual <= 2^-33 n, or 2^-25 absolute once n3 is subnormal);
+  // a padding row is (+inf, 0, 0): inf * 1.0 accumulates to +inf, which never passes `< thr`
+  const _Float16 n1 = (_Float16)n;
+  const float r1 = real ? n - (float)n1 : 0.0f;
+  const _Float16 n2 = (_Float16)r1;
+  const _Float16 n3 = (_Float16)(r1 - (float)n2);
+  for (int g = part; g < KB * 2; g += 4) {
+    f16x8 hi, lo;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(norm2_max), __float_as_int(m));
-}
-
-__global__ __launch_bounds__(256) void prepare_queries16_kernel(const double* __restrict__ X, int d,
-                                                                const double* __restrict__ mean,
-                                                                const float* __restrict__ scale_info, int KB,
-                                                                int64_t q_begin, int64_t q_count, int64_t q_pad,
-                                                                const int* __restrict__ rows,
-                                                                _Float16* __restrict__ Q16, float* __restrict__ Qn) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= q_pad) return;
-  const float s = scale_info[0];
-  const int64_t qq = q < q_count ? q : q_count - 1;
-  const int64_t src = q_begin + (rows ? (int64_t)rows[qq] : qq);
-  const double* xrow = X + src * d;
-  Qn[q] = scaled_norm2(xrow, mean, s, d);
-  _Float16* row = Q16 + (size_t)q * (KB * 32);
-  for (int c = 0; c < KB * 16; ++c) {
-    // K slots d .. d+2 carry 1.0 against the three norm pieces of the references
-    const float v = c < d ? s * (float)(xrow[c] - mean[c]) : (c < d + 3 ? 1.0f : 0.0f);
-    const int kb = c >> 4, hh = (c >> 3) & 1, e = c & 7;
-    _Float16* base = row + ((kb * 2 + hh) * 2) * 8 + e;
-    split_store(base, base + 8, v);
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      _Float16 h16, l16 = (_Float16)0.0f;
+      if (c < d) {
+        const float v = IS_REF ? -2.0f * xs[r][c] : xs[r][c];
+        h16 = (_Float16)v;
+        l16 = (_Float16)(v - (float)h16);
+      } else if (c < d + 3) {
+        h16 = IS_REF ? (c == d ? n1 : (c == d + 1 ? n2 : n3)) : (_Float16)1.0f;  // exact against 1.0: hi plane only
+      } else {
+        h16 = (_Float16)0.0f;
+      }
+      hi[e] = h16;
+      lo[e] = l16;
+    }
+    if (IS_REF) {
+      f16x8* tile = reinterpret_cast<f16x8*>(out16) + (size_t)blockIdx.x * ((size_t)KB * 2 * 2 * K16_TS);
+      tile[(size_t)(g * 2 + 0) * K16_TS + r] = hi;
+      tile[(size_t)(g * 2 + 1) * K16_TS + r] = lo;
+    } else {
+      f16x8* qrow = reinterpret_cast<f16x8*>(out16) + (size_t)i * ((size_t)KB * 4);
+      qrow[g * 2 + 0] = hi;
+      qrow[g * 2 + 1] = lo;
+    }
+  }
+  if (part == 0) {
+    if (IS_REF) {
+      float n_orig = 0.0f;
+      if (real) {
+        n_orig = n * scale_info[1];
+        out_norm[i] = n_orig;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) n_orig = fmaxf(n_orig, __shfl_xor(n_orig, off, 64));
+      if (r == 0) atomicMax(reinterpret_cast<int*>(norm2_max), __float_as_int(n_orig));
+    } else {
+      out_norm[i] = n;
+    }
   }
 }
 
@@ -906,11 +916,11 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
   hipLaunchKernelGGL(absmax_centered_kernel, dim3(2048), dim3(256), 0, st, X, N * (int64_t)d, d, mean, scale_info);
   hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
   const int64_t n_pad = ceil_div(N, K16_TS) * K16_TS;
-  hipLaunchKernelGGL(prepare_refs16_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, st, X, N, d, mean,
-                     scale_info, KB, n_pad, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
+  hipLaunchKernelGGL((prepare16_kernel<true>), dim3((unsigned)(n_pad / K16_TS)), dim3(256), 0, st, X, N, d, mean, scale_info,
+                     KB, (int64_t)0, N, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
   const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
-  hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, st, X, d, mean,
-                     scale_info, KB, q_begin, q_count, q_pad, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn);
+  hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, st, X, N, d, mean, scale_info,
+                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
   MELD_LAUNCH_CHECK("meld_knn16_prepare");
   return MELD_OK;
 }
@@ -925,8 +935,8 @@ extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const 
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
   const int64_t q_pad = ceil_div(n_rows, K16_BQ) * K16_BQ;
-  hipLaunchKernelGGL(prepare_queries16_kernel, dim3((unsigned)ceil_div(q_pad, 256)), dim3(256), 0, S(stream), X, d, mean,
-                     scale_info, KB, q_begin, n_rows, q_pad, rows, reinterpret_cast<_Float16*>(Q16), Qn);
+  hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, S(stream), X, N, d, mean,
+                     scale_info, KB, q_begin, n_rows, rows, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
   MELD_LAUNCH_CHECK("meld_knn16_prepare_rows");
   return MELD_OK;
 }
