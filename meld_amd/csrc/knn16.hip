@@ -69,6 +69,14 @@ __device__ __forceinline__ int ld_sc1_i(const int* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// End of a cold region (row compaction) inside the scan loop: s_waitcnt vmcnt(0) issued through the BUILTIN,
+// which the compiler's wait-count model sees (an inline-asm s_waitcnt it does not).  Without it the
+// model carries "some load of the region may still be pending" over the loop back edge and guards the first
+// ds_read of EVERY iteration with s_waitcnt vmcnt(0) -- i.e. the wave waits for the tile loads it has just
+// issued instead of overlapping them with the iteration (measured: 134 ms with luck in the register
+// allocation, 151 ms without).  Encoding (gfx9): vmcnt = 0, expcnt = 7, lgkmcnt = 15.
+#define K16_COLD_REGION_END() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 // A candidate row is two half-rows: slots [0, half) are filled by the lanes that hold the query with
 // h = 0, slots [half, 2 half) by the lanes with h = 1, each lane appending with a private register
 // counter (no atomics, no returning LDS operation on the append path).  n0 / n1 = their lengths.
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(K16_THREADS)
 __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(
     const _Float16* __restrict__ Q16, const float* __restrict__ Qn, const _Float16* __restrict__ Rt16,
     const float* __restrict__ scale_info, int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
-    float err_coef, int tile_origin, unsigned* __restrict__ convoy, int win_tiles, int tighten, int batch_every, int batch_slack,
+    float err_coef, int tile_origin, int batch_every, int batch_slack, int two_sided,
     unsigned long long* __restrict__ stats, const float* __restrict__ thr_init,
     int* __restrict__ cand_idx,
     float* __restrict__ cand_d2, int* __restrict__ cand_cnt) {
@@ -219,7 +227,6 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
   __shared__ float lds_wthr[2][K16_NWAVE];  // per-wave max threshold, double-buffered by step parity
-  __shared__ unsigned lds_v0;               // convoy position (monotone virtual tile counter) read at start-up
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -270,29 +277,22 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const float prune_margin = lb2 ? err_coef * norm2_max[0] * scale_info[0] * scale_info[0] : 0.0f;
   const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
   const float* my_lb = lb2 ? lb2 + (size_t)blockIdx.x * n_tiles : nullptr;
-  // Convoy order (convoy != nullptr; single slice, no pruning).  Every workgroup streams the WHOLE
-  // reference set: with each of them at its own position that is n_workgroups x |Rt16| of L2-miss
-  // traffic (500 GB at 1M cells -- the fabric, not the matrix pipe, bounds the kernel).  Instead a
-  // workgroup first scans a short window around its own position (its spatial neighbourhood in
-  // locality order: the thresholds tighten at once), then joins the sweep all resident workgroups
-  // share: it starts at the position the front has published in *convoy and publishes its own
-  // progress, so that the workgroups of an XCD read the same tiles at about the same time and all
-  // but the first find them in L2.  The counter is only a hint -- any start position is correct,
-  // every workgroup still scans every tile exactly once.
-  const int win = convoy ? min(win_tiles, n_scan) : 0;                               // tiles in the own window
-  const int win_lo = convoy ? max(0, min(t0 - (win - K16_BQ / K16_TS) / 2, n_scan - win)) : 0;  // its first tile
-  const int n_rest = n_scan - win;                                                     // tiles outside the window
-  if (convoy && tid == 0) lds_v0 = __hip_atomic_load(convoy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int u0 = 0;  // start of the sweep among the n_rest tiles outside the window (set after the first barrier)
+  // (A "convoy" order -- all resident workgroups sweeping the same tiles at the same time so that all but
+  // the first find them in L2 -- was tried: the base loop gained 7 %, but the thresholds converge later and
+  // the net was +3 %; its progress counter was also a returning atomic in the loop, whose pending result made
+  // the compiler guard the first ds_read of every iteration with s_waitcnt vmcnt(0).  Removed.)
   auto tile_of = [&](int s) {
-    if (convoy) {
-      if (s < win) return tile_lo + win_lo + s;
-      int u = u0 + (s - win);
-      u = u >= n_rest ? u - n_rest : u;
-      return tile_lo + (u < win_lo ? u : u + win);
+    // own tiles first, then outwards on both sides of the own position (two_sided): in the locality
+    // order both the next and the previous leaves are spatial neighbours, so the thresholds tighten
+    // sooner than on a forward-only walk.  offsets -B .. F-1 with F + B = n_scan: every tile once.
+    int off = s;
+    if (two_sided && s >= K16_BQ / K16_TS) {
+      const int j = s - K16_BQ / K16_TS;
+      off = (j & 1) ? -1 - (j >> 1) : K16_BQ / K16_TS + (j >> 1);
     }
-    const int t = t0 + s;
-    return tile_lo + (t >= n_scan ? t - n_scan : t);
+    int t = t0 + off;
+    t = t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
+    return tile_lo + t;
   };
   // first step >= s whose tile may hold a candidate given the block-wide threshold bound
   auto next_live = [&](int s, float bound) {
@@ -321,17 +321,30 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   constexpr int STAGE_STRIDE = (NPROD == 3) ? K16_THREADS : 2 * K16_THREADS;  // offset step per round
   const bool stage_last = !STAGE_TAIL || tid < (N_STAGE % K16_THREADS);
 #define K16_ROUND_OK(U) ((U) + 1 < NS || stage_last)
-#define K16_LOAD(SRC)                                                                       \
-  do {                                                                                      \
-    if constexpr (NS > 0) if (K16_ROUND_OK(0)) p0 = (SRC)[stage_off + 0 * STAGE_STRIDE];    \
-    if constexpr (NS > 1) if (K16_ROUND_OK(1)) p1 = (SRC)[stage_off + 1 * STAGE_STRIDE];    \
-    if constexpr (NS > 2) if (K16_ROUND_OK(2)) p2 = (SRC)[stage_off + 2 * STAGE_STRIDE];    \
-    if constexpr (NS > 3) if (K16_ROUND_OK(3)) p3 = (SRC)[stage_off + 3 * STAGE_STRIDE];    \
-    if constexpr (NS > 4) if (K16_ROUND_OK(4)) p4 = (SRC)[stage_off + 4 * STAGE_STRIDE];    \
-    if constexpr (NS > 5) if (K16_ROUND_OK(5)) p5 = (SRC)[stage_off + 5 * STAGE_STRIDE];    \
-    if constexpr (NS > 6) if (K16_ROUND_OK(6)) p6 = (SRC)[stage_off + 6 * STAGE_STRIDE];    \
-    if constexpr (NS > 7) if (K16_ROUND_OK(7)) p7 = (SRC)[stage_off + 7 * STAGE_STRIDE];    \
-    if constexpr (NS > 8) if (K16_ROUND_OK(8)) p8 = (SRC)[stage_off + 8 * STAGE_STRIDE];    \
+  // Tile loads are raw buffer loads: the descriptor (SGPRs) carries the tile base, the per-thread offset is
+  // one loop-invariant VGPR and the round offset an immediate/SGPR.  With flat global addressing the
+  // compiler materialises a 64-bit VGPR address per load and iteration, recycles those registers as
+  // A-fragment destinations and then guards the first ds_read of the iteration with s_waitcnt vmcnt(0) --
+  // i.e. waits for the loads it has just issued (measured: 134 -> 151 ms).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int stage_voff = stage_off * 16;
+  auto as_f4 = [](u32x4 v) __attribute__((always_inline)) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+#define K16_BLOAD(U) as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsrc, stage_voff, (U) * STAGE_STRIDE * 16, 0))
+#define K16_LOAD(TILE)                                                                                             \
+  do {                                                                                                             \
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                         \
+        const_cast<float4*>(R4 + (size_t)(TILE) * TILE_V4), 0, TILE_V4 * 16, 0x00020000);                          \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) p0 = K16_BLOAD(0);                                                  \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) p1 = K16_BLOAD(1);                                                  \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) p2 = K16_BLOAD(2);                                                  \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) p3 = K16_BLOAD(3);                                                  \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) p4 = K16_BLOAD(4);                                                  \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) p5 = K16_BLOAD(5);                                                  \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) p6 = K16_BLOAD(6);                                                  \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) p7 = K16_BLOAD(7);                                                  \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) p8 = K16_BLOAD(8);                                                  \
   } while (0)
 #define K16_STORE(DST)                                                                      \
   do {                                                                                      \
@@ -345,17 +358,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     if constexpr (NS > 7) if (K16_ROUND_OK(7)) (DST)[stage_off + 7 * STAGE_STRIDE] = p7;    \
     if constexpr (NS > 8) if (K16_ROUND_OK(8)) (DST)[stage_off + 8 * STAGE_STRIDE] = p8;    \
   } while (0)
-  {
-    const float4* src = R4 + (size_t)tile_of(0) * TILE_V4;
-    K16_LOAD(src);
-  }
+  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)));
   K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
   __syncthreads();
-  if (convoy && n_rest > 0) {
-    const int v0 = (int)(lds_v0 % (unsigned)n_scan);  // same value for every wave of the workgroup
-    u0 = v0 < win_lo ? v0 : (v0 < win_lo + win ? win_lo : v0 - win);
-    u0 = u0 >= n_rest ? 0 : u0;
-  }
 
   // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
   // their loads past the first barrier and then has to guard their first use inside the loop with
@@ -369,6 +374,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       if (NPROD == 3) asm volatile("" : "+v"(blo[g][kb]));
     }
     asm volatile("" : "+v"(nq[g]));
+    asm volatile("" : "+v"(thrp[g]));  // (its start value may come from thr_init)
   }
 
   // ---- software-pipelined scan -------------------------------------------------------------
@@ -433,6 +439,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       if (g) cnt[1] = mine; else cnt[0] = mine;
       thrp[g] = ((n0 + n1 >= ksel) ? nt : thr_start(g)) - nq[g];
     }
+    // every load of this cold region has landed when it ends: a result still pending at the join with
+    // the hot loop would make the compiler put s_waitcnt vmcnt(0) in front of the next pipeline segment
+    asm volatile("" : "+v"(thrp[0]), "+v"(thrp[1]), "+v"(cnt[0]), "+v"(cnt[1]));
   };
   auto refresh_wmax = [&]() __attribute__((always_inline)) {
     if (my_lb == nullptr) return;  // only the pruning test reads it
@@ -484,6 +493,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
         if (ABL == 2) ++st_sq;
       }
       refresh_wmax();
+      K16_COLD_REGION_END();
     }
   };
   // Issue order of one pipeline segment (the MFMAs of a block + the vote on the previous one, all in
@@ -539,36 +549,36 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   int s_cur = 0;
   int cur = 0;
   int par = 0;
+  int t_cur = tile_of(0);
   while (s_cur < n_scan) {
     // block-uniform bound: every wave reads the values published before the last barrier
     float bound = 0.0f;
     if (my_lb) bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3])) + prune_margin;
     const int s_next = next_live(s_cur + 1, bound);
+    // The tile index of the NEXT step is computed before its loads are issued and carried to the next
+    // iteration: no control flow may sit between the loads and the first pipeline segment (at such a join
+    // the compiler waits for all outstanding loads -- the ones just issued -- on every iteration).
+    const int t = t_cur;
+    const int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
+    t_cur = t_next;
     if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
-      const float4* src = R4 + (size_t)(ABL == 8 ? (tile_of(s_next) & 63) : tile_of(s_next)) * TILE_V4;
-      K16_LOAD(src);
+      K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next));
     }
-    const int t = tile_of(s_cur);
-    // End of the own window: compact every row that holds more than ksel candidates, so that the
-    // long sweep starts from thresholds that are exact for what has been seen (a stale threshold
-    // admits candidates that cannot survive, and each of them costs a trip through the slow path).
     // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
     segment(cur, 0, accA0, accA1, accB0, accB1, refB, true);
     // sub-tile 1 on the pipe while sub-tile 0 is voted on
     segment(cur, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
     refB = t * K16_TS + 32 + 4 * h;
 
-    const bool window_end = convoy && s_cur + 1 == win && win > 0 && tighten;
-    if (window_end || (batch_every > 0 && (s_cur & (batch_every - 1)) == batch_every - 1)) {
+    if (batch_every > 0 && (s_cur & (batch_every - 1)) == batch_every - 1) {
       // (Placed here, in front of the staging store whose vmcnt(0) wait follows anyway: a cold region with
       // memory operations in front of a pipeline segment makes the compiler wait for ALL outstanding loads at
       // the join -- the tile loads just issued -- on every iteration.)
       // Batched compaction, at the same step in every wave of the workgroup (the waves meet at a
       // barrier per tile, so a compaction at a random moment in one wave stalls all four; done
       // together the stalls overlap): every row that has gathered more than batch_slack entries beyond
-      // ksel -- or, at the end of the own window, any row above ksel.  Fresher thresholds also mean
-      // fewer candidates that cannot survive.
-      const int limit = ksel + (window_end ? 0 : batch_slack);
+      // ksel.  Fresher thresholds also mean fewer candidates that cannot survive.
+      const int limit = ksel + batch_slack;
       unsigned long long todo = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -584,14 +594,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
           if (ABL == 2) ++st_sq;
         }
         refresh_wmax();
+        K16_COLD_REGION_END();
       }
     }
 
     if (s_next < n_scan && ABL != 9) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
     if (my_lb && lane == 0) lds_wthr[par ^ 1][wave] = wmax;
-    // publish the position in the shared sweep (a monotone hint for workgroups that start later)
-    if (convoy && tid == 0 && s_cur >= win && ((s_cur - win) & 31) == 0)
-      __hip_atomic_fetch_max(convoy, lds_v0 + (unsigned)(s_cur - win), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ABL != 4 || (s_cur & 1)) __syncthreads();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
     s_cur = s_next;
     cur ^= 1;
@@ -621,6 +629,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     if (lane == 0) cand_cnt[qr] = min(n0 + n1, ksel);
   }
 #undef K16_LOAD
+#undef K16_BLOAD
 #undef K16_STORE
 #undef K16_ROUND_OK
 }
@@ -997,40 +1006,28 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   const size_t pad_lds = pad_env ? (size_t)atoi(pad_env) : 0;
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
-  // convoy order (see the kernel): a per-device counter, zeroed on the launch stream; only a hint,
-  // so concurrent launches sharing it are harmless.  MELD_KNN16_CONVOY=0 / MELD_KNN16_WINDOW=<tiles>
-  // are profiling hooks.
-  unsigned* convoy = nullptr;
   unsigned long long* stats = nullptr;
-  int win_tiles = 16;
-  int tighten = 1;
-  int batch_every = 8, batch_slack = 32;  // batched compaction: every 8 tiles, rows with > ksel + 32 entries
+  int batch_every = 32, batch_slack = 32;  // batched compaction: every 32 tiles, rows with > ksel + 32 entries
   if (const char* e = getenv("MELD_KNN16_BATCH_EVERY")) {  // profiling hooks (a power of two, or 0 = off)
     batch_every = atoi(e);
     MELD_CHECK_ARG(batch_every >= 0 && (batch_every & (batch_every - 1)) == 0, "MELD_KNN16_BATCH_EVERY must be a power of two");
   }
   if (const char* e = getenv("MELD_KNN16_BATCH_SLACK")) batch_slack = std::max(0, atoi(e));
-  {
-    static unsigned* counters[64] = {nullptr};  // (a racing first call leaks 256 B at worst)
+  int two_sided = 1;  // scan order: own tiles, then alternately forwards / backwards (0 = forwards only)
+  if (const char* e = getenv("MELD_KNN16_TWO_SIDED")) two_sided = atoi(e) != 0;
+  if (getenv("MELD_KNN16_STATS")) {  // profiling hook: selection counters, printed after the launch
+    static unsigned long long* counters[64] = {nullptr};  // (a racing first call leaks 256 B at worst)
     int dev = 0;
     MELD_HIP_CALL(hipGetDevice(&dev));
     MELD_CHECK_ARG(dev >= 0 && dev < 64, "meld_knn16_topk: device index out of range");
     if (counters[dev] == nullptr) MELD_HIP_CALL(hipMalloc(reinterpret_cast<void**>(&counters[dev]), 256));
     MELD_HIP_CALL(hipMemsetAsync(counters[dev], 0, 256, S(stream)));
-    if (getenv("MELD_KNN16_STATS")) stats = reinterpret_cast<unsigned long long*>(counters[dev] + 8);  // profiling hook
-    if (n_slices == 1 && lb2 == nullptr) {
-      const char* cv_env = getenv("MELD_KNN16_CONVOY");
-      const char* win_env = getenv("MELD_KNN16_WINDOW");
-      const char* tg_env = getenv("MELD_KNN16_TIGHTEN");
-      if (win_env) win_tiles = std::max(K16_BQ / K16_TS, atoi(win_env));
-      if (tg_env) tighten = atoi(tg_env);
-      if (cv_env && atoi(cv_env) != 0) convoy = counters[dev];
-    }
+    stats = counters[dev];
   }
 #define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
   hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, Qn, r,  \
                      scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
-                     tile_origin, convoy, win_tiles, tighten, batch_every, batch_slack, stats, thr_init, cand_idx, cand_d2, cand_cnt)
+                     tile_origin, batch_every, batch_slack, two_sided, stats, thr_init, cand_idx, cand_d2, cand_cnt)
 #define K16_LAUNCH(KBV, ABLV)        \
   do {                               \
     if (nprod == 1)                  \
