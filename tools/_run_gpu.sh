@@ -1,12 +1,7 @@
-mkdir -p gpurun_out/r2v
-{
-python tools/knn_only.py 1000000 3
-MELD_KNN16_TWO_SIDED=0 python tools/knn_only.py 1000000 3
-MELD_KNN16_BATCH_EVERY=32 python tools/knn_only.py 1000000 3
-MELD_KNN16_ABLATION=1 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=3 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=6 python tools/knn_only.py 1000000 2
-} > gpurun_out/r2v/timing.log 2>&1
-grep -v "amdgpu.ids" gpurun_out/r2v/timing.log | cut -c1-330
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2v/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2v/pytest.log
-tail -4 gpurun_out/r2v/pytest.log
+mkdir -p gpurun_out/r2x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/r2x/prof_stdout.log 2>&1
+python tools/rocpd_summary.py /tmp/prof/bench_results.db > gpurun_out/r2x/kernel_stats.md 2>&1
+head -12 gpurun_out/r2x/kernel_stats.md | cut -c1-200
+python bench.py --steps 5 --warmup 1 --stages > gpurun_out/r2x/bench_full.json 2> gpurun_out/r2x/bench_full.err
+cut -c1-300 gpurun_out/r2x/bench_full.json; grep -o '"stages.*' gpurun_out/r2x/bench_full.json | cut -c1-700
