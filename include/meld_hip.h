@@ -241,6 +241,17 @@ int meld_lanczos_steps(const int64_t* rowptr, const int32_t* col, const double* 
                        int64_t n_rows, int64_t nnz_hint, double* v0, double* v1, double* v2, double* state,
                        double* alphas, double* betas, int it_begin, int n_iter, double* scratch,
                        meld_stream_t stream);
+/* The same iteration as four stream-ordered phases, for the row-sharded driver (it all-reduces dots after
+ * the SpMV and nrm2 after the axpy, and all-gathers the new vector): x_full is the gathered iterate,
+ * x_row_offset the first local row in it; z_local / y_local / x_local are local rows; state / dots
+ * (2 * slots) / nrm2 (slots) as in meld_lanczos_steps. */
+int meld_lanczos_spmv(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows,
+                      int64_t nnz_hint, const double* x_full, int64_t x_row_offset, const double* z_local,
+                      double* y_local, const double* state, double* dots, meld_stream_t stream);
+int meld_lanczos_alpha(double* state, const double* dots, double* nrm2, double* alphas, int it, meld_stream_t stream);
+int meld_lanczos_axpy(const double* x_local, double* y_local, int64_t n_rows, const double* state, double* nrm2,
+                      meld_stream_t stream);
+int meld_lanczos_beta(double* state, const double* nrm2, double* dots, double* betas, int it, meld_stream_t stream);
 int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream);
 /* y = a * x + b * y  (n doubles) -- Lanczos vector update.  If nrm2 != NULL it receives
  * meld_spmm_dot_slots() partial sums of <y, y> (zeroed by the call; the caller adds them up). */

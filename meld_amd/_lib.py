@@ -74,6 +74,10 @@ SIGNATURES = {
         [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr],
     ),
     "meld_lanczos_steps": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
+    "meld_lanczos_spmv": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_lanczos_alpha": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "meld_lanczos_axpy": (_i32, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
+    "meld_lanczos_beta": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
     "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),

@@ -344,6 +344,47 @@ extern "C" int meld_lanczos_steps(const int64_t* rowptr, const int32_t* col, con
   return MELD_OK;
 }
 
+// The four phases of one device-resident Lanczos iteration as separate entry points, for the row-sharded
+// driver: it interleaves them with the all-reduces of the partial sums (dots after the SpMV, nrm2 after the
+// axpy) and the all-gather of the new vector, all stream-ordered, so that a sharded iteration needs no host
+// round trip either.  x_full [n_total] is the gathered iterate, the other vectors are the local rows.
+extern "C" int meld_lanczos_spmv(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw,
+                                 int64_t n_rows, int64_t nnz_hint, const double* x_full, int64_t x_row_offset,
+                                 const double* z_local, double* y_local, const double* state, double* dots,
+                                 meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && dw && x_full && z_local && y_local && state && dots && n_rows > 0, "meld_lanczos_spmv: bad arguments");
+  constexpr int RB = 32;
+  const double mean_span = (nnz_hint > 0) ? (double)nnz_hint / (double)n_rows * RB : 1024.0;
+  const int chunk = (int)std::max<int64_t>(512, std::min<int64_t>((int64_t)(mean_span * 1.3) / 256 * 256 + 256, (48 * 1024) / 8 / 256 * 256));
+  launch_cheby<1, RB>(rowptr, col, val, dw, n_rows, 1, 0, x_full, x_row_offset, z_local, y_local, nullptr, 0.0, 0.0, 0.0, 0.0,
+                      dots, chunk, S(stream), state);
+  MELD_LAUNCH_CHECK("meld_lanczos_spmv");
+  return MELD_OK;
+}
+extern "C" int meld_lanczos_alpha(double* state, const double* dots, double* nrm2, double* alphas, int it,
+                                  meld_stream_t stream) {
+  MELD_CHECK_ARG(state && dots && nrm2 && alphas && it >= 0, "meld_lanczos_alpha: bad arguments");
+  hipLaunchKernelGGL(lanczos_alpha_kernel, dim3(1), dim3(64), 0, S(stream), state, dots, nrm2, alphas, it);
+  MELD_LAUNCH_CHECK("lanczos_alpha_kernel");
+  return MELD_OK;
+}
+extern "C" int meld_lanczos_axpy(const double* x_local, double* y_local, int64_t n_rows, const double* state, double* nrm2,
+                                 meld_stream_t stream) {
+  MELD_CHECK_ARG(x_local && y_local && state && nrm2 && n_rows >= 0, "meld_lanczos_axpy: bad arguments");
+  if (n_rows == 0) return MELD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n_rows, 256));
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, S(stream), 0.0, x_local, 1.0, y_local, n_rows, nrm2, state + 5);
+  MELD_LAUNCH_CHECK("axpby_kernel");
+  return MELD_OK;
+}
+extern "C" int meld_lanczos_beta(double* state, const double* nrm2, double* dots, double* betas, int it,
+                                 meld_stream_t stream) {
+  MELD_CHECK_ARG(state && nrm2 && dots && betas && it >= 0, "meld_lanczos_beta: bad arguments");
+  hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, S(stream), state, nrm2, dots, betas, it);
+  MELD_LAUNCH_CHECK("lanczos_beta_kernel");
+  return MELD_OK;
+}
+
 extern "C" int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream) {
   MELD_CHECK_ARG(x && r && n >= 0, "meld_scale_f64: bad arguments");
   if (n == 0) return MELD_OK;

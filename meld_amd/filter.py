@@ -189,7 +189,55 @@ def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
     return theta, dict(iterations=it, residual=resid, tol=tol, device_resident=True)
 
 
-def lanczos_lmax(G, tol=1e-4, max_iter=300, check_every=5, seed=0):
+def _lanczos_lmax_phases(G, ops, comm, u0, tol, max_iter, check_every):
+    """Device-resident Lanczos on a row-sharded graph: the four phases of an iteration
+    (``meld_lanczos_spmv / _alpha / _axpy / _beta``) interleaved with the all-reduces of the partial
+    sums and the all-gather of the new vector, all stream-ordered -- one host synchronisation per batch
+    of iterations instead of two per iteration.  Every rank reads back the same alphas / betas, so all
+    ranks take the same decisions and issue the same collectives."""
+    dev, n_pad = G.val.device, G.n_pad
+    slots = ops.dot_slots()
+    V = torch.zeros(3, n_pad, dtype=torch.float64, device=dev)
+    V[1].copy_(u0)
+    state = torch.zeros(8, dtype=torch.float64, device=dev)
+    inv = 1.0 / torch.linalg.vector_norm(V[1])
+    state[0] = inv
+    state[3] = inv
+    alphas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
+    betas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
+    dots = torch.zeros(2 * slots, dtype=torch.float64, device=dev)
+    nrm2 = torch.zeros(slots, dtype=torch.float64, device=dev)
+    it, theta, resid = 0, 0.0, float("inf")
+    batch = 4 * check_every
+    while it < max_iter:
+        n_iter = min(batch, max_iter - it)
+        for k in range(it, it + n_iter):
+            u_prev, u, y = V[k % 3], V[(k + 1) % 3], V[(k + 2) % 3]
+            ops.lanczos_spmv(G, u, _local(G, u_prev), _local(G, y), state, dots)
+            if comm is not None:
+                comm.all_reduce_sum(dots)
+            ops.lanczos_alpha(state, dots, nrm2, alphas_d, k)
+            ops.lanczos_axpy(_local(G, u), _local(G, y), state, nrm2)
+            if comm is not None:
+                comm.all_reduce_sum(nrm2)
+            ops.lanczos_beta(state, nrm2, dots, betas_d, k)
+            if comm is not None:
+                comm.all_gather_rows(y, _local(G, y))
+        it_new = it + n_iter
+        ab = torch.stack([alphas_d[:it_new], betas_d[:it_new]]).cpu().numpy()  # the one synchronisation per batch
+        alphas, betas = ab[0], ab[1]
+        for k in range(it + 1, it_new + 1):
+            done = betas[k - 1] <= 1e-14 * max(abs(alphas[k - 1]), 1e-300) or not np.isfinite(betas[k - 1])
+            if k % check_every == 0 or done or k == max_iter:
+                theta, resid = _ritz_check(alphas[:k], betas[:k], tol)
+                if resid <= tol or done:
+                    return theta, dict(iterations=k, residual=resid, tol=tol, device_resident=True)
+        it = it_new
+        batch = check_every
+    return theta, dict(iterations=it, residual=resid, tol=tol, device_resident=True)
+
+
+def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
     """Largest eigenvalue of L = diag(dw) - W by the Lanczos recurrence on the device SpMV.
 
     Vectors stay un-normalised on the device (u_k = beta_{k-1} v_k); the 1/beta scalings are folded
@@ -211,6 +259,8 @@ def lanczos_lmax(G, tol=1e-4, max_iter=300, check_every=5, seed=0):
     max_iter = min(max_iter, G.N)
     if comm is None and hasattr(ops, "lanczos_steps") and G.n_pad == G.N:
         return _lanczos_lmax_device(G, ops, u, tol, max_iter, check_every)
+    if hasattr(ops, "lanczos_spmv"):
+        return _lanczos_lmax_phases(G, ops, comm, u, tol, max_iter, check_every)
     nrm = float(torch.linalg.vector_norm(u).item())
     u_prev = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)
     y = torch.zeros(G.n_pad, dtype=torch.float64, device=dev)

@@ -82,6 +82,39 @@ class CpuOps:
             dots[0] = float((yv * xl).sum())
             dots[s] = float((yv * yv).sum())
 
+    # the four phases of the device-resident Lanczos iteration (meld_lanczos_spmv / _alpha / _axpy / _beta)
+    def lanczos_spmv(self, G, x_full, z_local, y_local, state, dots):
+        n = G.n_rows
+        xf = x_full.numpy()
+        W = sparse.csr_matrix((G.val.numpy(), G.col.numpy(), G.rowptr.numpy()[: n + 1]), shape=(n, xf.shape[0]))
+        xl = xf[G.row_begin : G.row_begin + n]
+        st = state.numpy()
+        yv = st[3] * (G.dw_dev.numpy()[:n] * xl - W @ xf) + st[4] * z_local.numpy()[:n]
+        y_local.numpy()[:n] = yv
+        d = dots.numpy()
+        d[0] += float(yv @ xl)  # the beta phase zeroed the slots
+        d[self.dot_slots()] += float(yv @ yv)
+
+    def lanczos_alpha(self, state, dots, nrm2, alphas, it):
+        st = state.numpy()
+        alpha = float(dots.numpy()[: self.dot_slots()].sum()) * st[0]
+        alphas.numpy()[it] = alpha
+        st[5] = -alpha * st[0]
+        nrm2.zero_()
+
+    def lanczos_axpy(self, x_local, y_local, state, nrm2):
+        y = y_local.numpy()
+        y += state.numpy()[5] * x_local.numpy()
+        nrm2.numpy()[0] += float(y @ y)
+
+    def lanczos_beta(self, state, nrm2, dots, betas, it):
+        st = state.numpy()
+        beta = float(np.sqrt(nrm2.numpy().sum()))
+        betas.numpy()[it] = beta
+        s_cur = st[0]
+        st[1], st[2], st[0], st[3], st[4] = s_cur, beta, 1.0 / beta, 1.0 / beta, -beta * s_cur
+        dots.zero_()
+
     def scale(self, x, a, r):
         r.copy_(a * x)
 

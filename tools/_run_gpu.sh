@@ -1,7 +1,7 @@
-mkdir -p gpurun_out/r2x
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/r2x/prof_stdout.log 2>&1
-python tools/rocpd_summary.py /tmp/prof/bench_results.db > gpurun_out/r2x/kernel_stats.md 2>&1
-head -12 gpurun_out/r2x/kernel_stats.md | cut -c1-200
-python bench.py --steps 5 --warmup 1 --stages > gpurun_out/r2x/bench_full.json 2> gpurun_out/r2x/bench_full.err
-cut -c1-300 gpurun_out/r2x/bench_full.json; grep -o '"stages.*' gpurun_out/r2x/bench_full.json | cut -c1-700
+mkdir -p gpurun_out/r2y
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2y/pytest.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2y/pytest.log
+tail -4 gpurun_out/r2y/pytest.log
+python bench.py --steps 3 --warmup 1 --cpu-sample 0 --force-sharded > gpurun_out/r2y/sharded.log 2>&1
+grep -v "amdgpu.ids" gpurun_out/r2y/sharded.log | cut -c1-400
+python bench.py --steps 5 --warmup 1 --cpu-sample 0 --stages > gpurun_out/r2y/bench.log 2>&1
+grep -v "amdgpu.ids" gpurun_out/r2y/bench.log | cut -c1-300; grep -o '"stages.*' gpurun_out/r2y/bench.log | cut -c1-600
