@@ -43,6 +43,24 @@ def cheby_bytes_per_step(nnz, n, p):
     return 12 * nnz + 4 * (n + 1) + 8 * n + 40 * n * p
 
 
+def synthetic_cells(n_cells, n_dims=50, seed=0, latent_dim=10, n_clusters=20):
+    """The seeded workload of SURVEY.md section 8(d): 20 cluster centres ~ N(0, 4 I_10), points =
+    centre + N(0, I_10), embedded in ``n_dims`` by a fixed random orthonormal map, plus N(0, 0.05^2)
+    isotropic noise; labels ~ Bernoulli(expit(latent_0)).  Same generator (same stream of draws) as
+    the oracle's, restated here so that the timed path never touches ``oracle/``
+    (tests/test_host_api.py checks the two agree bit for bit)."""
+    rng = np.random.default_rng(seed)
+    latent_dim = min(latent_dim, n_dims)
+    centres = rng.normal(0.0, 2.0, size=(n_clusters, latent_dim))
+    assign = rng.integers(0, n_clusters, size=n_cells)
+    latent = centres[assign] + rng.normal(0.0, 1.0, size=(n_cells, latent_dim))
+    q, _ = np.linalg.qr(rng.normal(size=(n_dims, latent_dim)))
+    X = latent @ q.T + rng.normal(0.0, 0.05, size=(n_cells, n_dims))
+    p = 1.0 / (1.0 + np.exp(-latent[:, 0]))
+    labels = np.where(rng.random(n_cells) < p, "expt", "ctrl")
+    return np.ascontiguousarray(X, dtype=np.float64), labels
+
+
 def cpu_baseline(sample_cells, dims, knn, beta, order):
     """Oracle (kind='port') on a bounded sample, faithful configuration of the reference stack:
     sklearn ball_tree kNN with n_jobs=1 (graphtools' defaults) and single-threaded scipy SpMM."""
@@ -107,10 +125,9 @@ def main():
 
     import meld_amd
     from meld_amd import graph as mgraph
-    from oracle import meld_oracle as mo  # synthetic input generator + cpu_baseline leg only
 
     N, d = args.cells, args.dims
-    X_host, labels = mo.synthetic_cells(N, n_dims=d, seed=0)
+    X_host, labels = synthetic_cells(N, n_dims=d, seed=0)
     X = torch.from_numpy(X_host).cuda()
     del X_host
 

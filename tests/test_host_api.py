@@ -123,3 +123,20 @@ def test_fit_without_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         meld.MELD().fit(np.random.normal(size=(50, 3)))
+
+
+def test_bench_workload_generator_is_the_oracles():
+    """bench.py restates the synthetic workload so that its timed path never imports oracle/; the
+    cpu_baseline leg uses the oracle's generator -- both must produce the same cells and labels."""
+    import importlib.util
+    import os
+
+    from oracle import meld_oracle as mo
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n, d in ((500, 50), (300, 6)):
+        Xa, la = bench.synthetic_cells(n, n_dims=d, seed=3)
+        Xb, lb = mo.synthetic_cells(n, n_dims=d, seed=3)
+        assert np.array_equal(Xa, Xb) and np.array_equal(la, lb)
