@@ -301,3 +301,17 @@ def test_device_label_factorization_matches_the_host_path(kind):
     assert np.array_equal(uniq_d, ref_u) and np.array_equal(uniq_h, ref_u)
     assert np.array_equal(codes_d.cpu().numpy(), ref_inv) and np.array_equal(codes_h, ref_inv)
     assert np.array_equal(counts, np.bincount(ref_inv))
+
+
+@pytest.mark.gpu
+def test_non_finite_input_is_rejected():
+    meld = _meld()
+    import torch
+
+    X = np.random.default_rng(0).normal(size=(300, 5))
+    X[17, 2] = np.nan
+    with pytest.raises(ValueError, match="NaN or infinity"):
+        meld.MELD(verbose=0).fit(X)
+    Xt = torch.from_numpy(np.where(np.isnan(X), np.inf, X)).cuda()
+    with pytest.raises(ValueError, match="NaN or infinity"):
+        meld.MELD(verbose=0).fit(Xt)

@@ -1,7 +1,2 @@
-{
-MELD_KNN16_ABLATION=9 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=8 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=3 python tools/knn_only.py 1000000 2
-MELD_KNN16_ABLATION=1 python tools/knn_only.py 1000000 2
-python tools/knn_only.py 1000000 3
-} 2>&1 | grep -v amdgpu.ids | cut -c1-200
+timeout 900 python -m pytest tests/test_gpu_api.py -x -q -m gpu 2>&1 | tail -2
+python tools/time_host_input.py 1000000 2>&1 | grep -v amdgpu.ids
