@@ -34,8 +34,11 @@
 namespace meld {
 
 constexpr int K16_TS = 64;         // references per LDS tile
-constexpr int K16_BQ = 256;        // queries per workgroup
-constexpr int K16_THREADS = 256;   // 4 waves (64 queries each); 2-3 workgroups resident per CU
+#ifndef K16_WG_WAVES
+#define K16_WG_WAVES 4
+#endif
+constexpr int K16_BQ = 64 * K16_WG_WAVES;        // queries per workgroup
+constexpr int K16_THREADS = 64 * K16_WG_WAVES;   // waves of 64 queries each; 2-3 workgroups resident per CU
 constexpr int K16_NWAVE = K16_THREADS / 64;
 constexpr int K16_SLACK = 128;     // CAP = ksel + slack
 constexpr int K16_CAPMAX = 256;
@@ -553,7 +556,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   while (s_cur < n_scan) {
     // block-uniform bound: every wave reads the values published before the last barrier
     float bound = 0.0f;
-    if (my_lb) bound = fmaxf(fmaxf(lds_wthr[par][0], lds_wthr[par][1]), fmaxf(lds_wthr[par][2], lds_wthr[par][3])) + prune_margin;
+    if (my_lb) {
+      bound = lds_wthr[par][0];
+#pragma unroll
+      for (int w = 1; w < K16_NWAVE; ++w) bound = fmaxf(bound, lds_wthr[par][w]);
+      bound += prune_margin;
+    }
     const int s_next = next_live(s_cur + 1, bound);
     // The tile index of the NEXT step is computed before its loads are issued and carried to the next
     // iteration: no control flow may sit between the loads and the first pipeline segment (at such a join
