@@ -25,7 +25,11 @@ __all__ = [
 
 def __getattr__(name):
     # exported by the reference package but outside the hot path
-    if name in ("VertexFrequencyCluster", "Benchmarker"):
+    if name == "VertexFrequencyCluster":  # lazy: pulls in the dense linear-algebra path only when used
+        from .cluster import VertexFrequencyCluster
+
+        return VertexFrequencyCluster
+    if name == "Benchmarker":
         raise NotImplementedError(
             "meld_amd.{} is not implemented yet: it is outside the accelerated hot path "
             "(see DESIGN.md, 'Out of scope')".format(name)

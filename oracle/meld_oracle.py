@@ -470,3 +470,97 @@ def synthetic_cells(n_cells, n_dims=50, seed=0, latent_dim=10, n_clusters=20):
     p = 1.0 / (1.0 + np.exp(-latent[:, 0]))
     labels = np.where(rng.random(n_cells) < p, "expt", "ctrl")
     return np.ascontiguousarray(X, dtype=np.float64), labels
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md section 8f row 2 (i): VertexFrequencyCluster at small N -- restatement of the reference's
+# ``meld/cluster.py`` (dense windowed graph Fourier transform + PCA + KMeans).  Test infrastructure,
+# like the rest of this file.
+# ---------------------------------------------------------------------------------------------
+def diff_op(K):
+    """[UPSTREAM graphtools ``BaseGraph.diff_op``]: the kernel (diagonal included), l1-normalised by
+    rows -- the base window of reference ``meld/cluster.py:213-215``."""
+    K = np.asarray(K.todense()) if sparse.issparse(K) else np.asarray(K, dtype=np.float64)
+    return K / K.sum(axis=1, keepdims=True)
+
+
+def fourier_basis(L):
+    """[UPSTREAM pygsp ``Graph.compute_fourier_basis``]: full eigendecomposition of the (combinatorial)
+    Laplacian, eigenvalues ascending (reference ``meld/cluster.py:235-236``)."""
+    Ld = np.asarray(L.todense()) if sparse.issparse(L) else np.asarray(L, dtype=np.float64)
+    e, U = np.linalg.eigh(Ld)
+    return e, U
+
+
+def _l2_normalize_columns(M):
+    """sklearn ``preprocessing.normalize(M, "l2", axis=0)``: unit-norm columns, zero columns kept."""
+    nrm = np.sqrt((M * M).sum(axis=0, keepdims=True))
+    nrm[nrm == 0] = 1.0
+    return M / nrm
+
+
+def vfc_windows(P, window_sizes):
+    """Reference ``meld/cluster.py:179-194`` (dyadic sizes: repeated squaring) and ``:158-177``
+    (arbitrary sizes: matrix power); every window = l2-normalised columns of P^t, transposed."""
+    window_sizes = np.asarray(window_sizes)
+    if np.all(np.diff(np.log2(window_sizes)) == 1):
+        out, cur = [], P
+        out.append(_l2_normalize_columns(cur).T)
+        for _ in range(len(window_sizes) - 1):
+            cur = cur @ cur
+            out.append(_l2_normalize_columns(cur).T)
+        return out
+    return [_l2_normalize_columns(np.linalg.matrix_power(P, int(t))).T for t in window_sizes]
+
+
+def vfc_spectrogram(U, windows, s):
+    """Reference ``meld/cluster.py:98-156``: sum over the windows of tanh|normalize(U^T (W_t * s), axis=0)^T|."""
+    out = np.zeros((windows[0].shape[1], U.shape[1]))
+    for W in windows:
+        C = _l2_normalize_columns(U.T @ (W * s[None, :]))
+        out += np.tanh(np.abs(C.T))
+    return out
+
+
+def vfc_transform(K, L, sample_indicator, likelihood=None, window_sizes=None, center=True, likelihood_bias=1):
+    """Reference ``meld/cluster.py:207-309`` (fit + transform).  Returns (spectrogram, combined or None)."""
+    if window_sizes is None:
+        window_sizes = np.power(2, np.arange(9))
+    windows = vfc_windows(diff_op(K), window_sizes)
+    _, U = fourier_basis(L)
+    s = np.array(sample_indicator, dtype=np.float64)
+    if center:
+        s = s - s.mean()
+    if s.ndim == 1:
+        spec = vfc_spectrogram(U, windows, s)
+    else:
+        spec = np.hstack([vfc_spectrogram(U, windows, s[:, i]) for i in range(s.shape[1])])
+    combined = None
+    if likelihood is not None:
+        lik = np.array(likelihood, dtype=np.float64)
+        spec_n = spec / np.linalg.norm(spec)
+        ees_n = lik / np.linalg.norm(lik, ord=2, axis=0) * likelihood_bias
+        combined = np.c_[spec_n, ees_n]
+    return spec, combined
+
+
+def sort_clusters_by_values(clusters, values):
+    """[UPSTREAM scprep ``utils.sort_clusters_by_values``]: relabel clusters 0..k-1 by ascending mean of
+    ``values`` over their members (reference ``meld/cluster.py:346-353``)."""
+    clusters = np.asarray(clusters)
+    values = np.asarray(values, dtype=np.float64)
+    uniq = np.unique(clusters)
+    means = np.array([np.mean(values[clusters == c]) for c in uniq])
+    remap = {c: i for i, c in enumerate(uniq[np.argsort(means)])}
+    return np.array([remap[c] for c in clusters])
+
+
+def vfc_predict(data, n_clusters, values, random_state=None):
+    """Reference ``meld/cluster.py:315-357``: PCA(n_clusters) -> KMeans(n_clusters, n_init=10) -> clusters
+    sorted by their mean likelihood / indicator."""
+    from sklearn.cluster import KMeans
+    from sklearn.decomposition import PCA
+
+    Y = PCA(n_clusters).fit_transform(data)
+    labels = KMeans(n_clusters=n_clusters, n_init=10, random_state=random_state).fit_predict(Y)
+    return sort_clusters_by_values(labels, values)

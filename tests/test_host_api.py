@@ -11,8 +11,9 @@ import meld_amd as meld
 def test_exports_match_reference_names():
     for name in ("MELD", "get_meld_cmap", "normalize_densities", "utils", "__version__"):
         assert hasattr(meld, name)
+    assert meld.VertexFrequencyCluster.__name__ == "VertexFrequencyCluster"
     with pytest.raises(NotImplementedError):
-        meld.VertexFrequencyCluster
+        meld.Benchmarker
 
 
 def test_constructor_defaults():
@@ -140,3 +141,28 @@ def test_bench_workload_generator_is_the_oracles():
         Xa, la = bench.synthetic_cells(n, n_dims=d, seed=3)
         Xb, lb = mo.synthetic_cells(n, n_dims=d, seed=3)
         assert np.array_equal(Xa, Xb) and np.array_equal(la, lb)
+
+
+def test_vertex_frequency_cluster_argument_checks():
+    """Same checks and messages as reference meld/cluster.py (test/test_meld.py:296-345); they all fire
+    before any device work."""
+    vfc = meld.VertexFrequencyCluster(window_sizes=np.array([2, 4, 8, 24]))
+    assert vfc.window_count == 4 and vfc.n_clusters == 10 and vfc._sklearn_params == {"n_init": 10}
+    assert list(meld.VertexFrequencyCluster(window_count=5).window_sizes) == [1, 2, 4, 8, 16]
+    with pytest.raises(ValueError, match="Estimator must be `fit` before running `transform`."):
+        vfc.transform(sample_indicator=np.zeros(5))
+    with pytest.raises(ValueError, match=r"Estimator is not fit. Call VertexFrequencyCluster.fit\(\)."):
+        vfc.predict()
+    vfc.isfit, vfc.N = True, 5  # what fit() records
+    with pytest.raises(TypeError, match="`sample_indicator` must be array-like"):
+        vfc.transform(sample_indicator="invalid")
+    with pytest.raises(TypeError, match="`likelihood` must be array-like"):
+        vfc.transform(sample_indicator=np.zeros(5), likelihood="invalid")
+    with pytest.raises(ValueError, match="At least one axis of `sample_indicator` must be of length `N`."):
+        vfc.transform(sample_indicator=np.zeros(4))
+    with pytest.raises(ValueError, match="must have the same shape"):
+        vfc.transform(sample_indicator=np.zeros(5), likelihood=np.zeros((5, 2)))
+    with pytest.raises(ValueError, match=r"Estimator is not transformed. Call VertexFrequencyCluster.transform\(\)."):
+        vfc.predict()
+    vfc.set_kmeans_params(n_clusters=4, n_init=3)
+    assert vfc.n_clusters == 4 and vfc._sklearn_params == {"n_init": 3}
