@@ -53,9 +53,9 @@ def _kmeans(Y, k, n_init=10, max_iter=300, tol=1e-4, seed=None):
             cnt = torch.bincount(lab, minlength=k).to(Y.dtype)
             newC.index_add_(0, lab, Y)
             newC = torch.where(cnt[:, None] > 0, newC / cnt.clamp(min=1)[:, None], C)
-            shift = float(((newC - C) ** 2).sum())
+            shift = ((newC - C) ** 2).sum()
             C = newC
-            if shift <= var_tol:
+            if (_it & 7) == 7 and float(shift) <= var_tol:  # one host sync per 8 iterations
                 break
         D = torch.cdist(Y, C) ** 2
         lab = D.argmin(1)
