@@ -30,8 +30,7 @@ def __getattr__(name):
 
         return VertexFrequencyCluster
     if name == "Benchmarker":
-        raise NotImplementedError(
-            "meld_amd.{} is not implemented yet: it is outside the accelerated hot path "
-            "(see DESIGN.md, 'Out of scope')".format(name)
-        )
+        from .benchmark import Benchmarker
+
+        return Benchmarker
     raise AttributeError("module 'meld_amd' has no attribute {!r}".format(name))

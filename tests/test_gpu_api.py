@@ -315,3 +315,37 @@ def test_non_finite_input_is_rejected():
     Xt = torch.from_numpy(np.where(np.isnan(X), np.inf, X)).cuda()
     with pytest.raises(ValueError, match="NaN or infinity"):
         meld.MELD(verbose=0).fit(Xt)
+
+
+@pytest.mark.gpu
+def test_benchmarker_pipeline_matches_the_oracle():
+    """reference test/test_benchmark.py:9-29 without PHATE (absent here: the 3-D embedding is supplied):
+    ground-truth pdf -> labels -> graph with graphtools' defaults (n_pca=100, anisotropy=0) -> MELD
+    likelihood -> MSE, against the same pipeline on the oracle."""
+    meld = _meld()
+    mo = _oracle()
+    np.random.seed(0)
+    data = np.random.normal(0, 2, (300, 200)) + np.outer(np.linspace(-3, 3, 300), np.ones(200))
+    emb = mo.pca_reduce(data, 3)
+    b = meld.Benchmarker(seed=0)
+    b.set_phate(emb)
+    pdf = b.generate_ground_truth_pdf()
+    b.generate_sample_labels()
+    lik = b.calculate_MELD_likelihood(data=data)  # implicitly fits the graph
+    mse = b.calculate_mse(b.expt_likelihood)
+    assert lik.shape == (300,) and 0.0 <= mse < 0.25
+    G = mo.build_graph(mo.pca_reduce(data, 100), knn=5, anisotropy=0)
+    assert abs(b.graph.W - G.W).max() <= 1e-8
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    b2 = meld.Benchmarker(seed=0)
+    b2.set_phate(emb)
+    b2.generate_ground_truth_pdf()
+    b2.generate_sample_labels()
+    b2.fit_graph(data)
+    b2.graph.lmax = lmax
+    lik2 = b2.calculate_MELD_likelihood()
+    ind = mo.sample_indicators(b2.sample_labels)
+    dens = mo.meld_filter(ind[1], G, beta=60, chebyshev_order=50, lmax=lmax)
+    ref = mo.normalize_densities(dens)[:, list(ind[0]).index("expt")]
+    assert np.abs(lik2 - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert b2.calculate_mse(lik2) == pytest.approx(float(np.mean((pdf - ref) ** 2)), rel=1e-6)
