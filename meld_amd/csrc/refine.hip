@@ -26,6 +26,9 @@ namespace meld {
 constexpr int RB_FALL = 8;  // flagged rows per workgroup in the exact sweep
 
 __device__ __forceinline__ double decay_kernel(double dist, double bw, double decay) {
+  // decay = +inf: graphtools' decay=None, the unweighted kNN graph -- 1 for the knn + 1 nearest (self
+  // included; bw is the distance of the last of them), 0 beyond; the radius factor is then 1
+  if (isinf(decay)) return dist <= bw ? 1.0 : 0.0;
   double v = exp(-pow(dist / bw, decay));
   if (v != v) v = 1.0;  // graphtools: NaN -> 1
   return v;

@@ -121,8 +121,8 @@ class MELD(GraphEstimator):
             )
         if self.n_landmark is not None:
             raise NotImplementedError("n_landmark is not implemented by the MI355X graph builder")
-        if self.decay is None:
-            raise NotImplementedError("decay=None (unweighted kNN graph) is not implemented")
+        if self.decay is None and self.thresh == 0:
+            raise NotImplementedError("decay=None with thresh=0 (dense unweighted graph) is not implemented")
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         if isinstance(data, torch.Tensor):
@@ -145,7 +145,8 @@ class MELD(GraphEstimator):
 
             return build_dense_graph(X, knn=self.knn, decay=self.decay, anisotropy=self.anisotropy)
         return build_knn_graph(
-            X, knn=self.knn, decay=self.decay, thresh=self.thresh, anisotropy=self.anisotropy,
+            X, knn=self.knn, decay=float("inf") if self.decay is None else self.decay,  # None: unweighted kNN graph
+            thresh=self.thresh, anisotropy=self.anisotropy,
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)),
         )
 

@@ -102,6 +102,14 @@ def knn_kernel(
     k1 = knn + 1
     knn_max = N
     tree = NearestNeighbors(n_neighbors=k1, algorithm=algorithm, metric="euclidean", n_jobs=n_jobs).fit(X)
+    if decay is None or thresh == 1:
+        # [UPSTREAM graphtools kNNGraph.build_kernel_to_data]: without alpha decay the kernel is the binary
+        # connectivity of the knn + 1 nearest neighbours, self included ("unweighted kNN graph")
+        K = tree.kneighbors_graph(X, n_neighbors=k1, mode="connectivity").tocsr()
+        if return_intermediates:
+            dist = tree.kneighbors(X, n_neighbors=k1)[0]
+            return K, dict(bandwidth=np.maximum(dist[:, k1 - 1], np.finfo(float).eps), n_updated_first=0)
+        return K
 
     search_knn = min(k1 * search_multiplier, knn_max)
     distances, indices = tree.kneighbors(X, n_neighbors=search_knn)

@@ -364,6 +364,25 @@ def test_query_ranges_compose_to_the_full_graph(search, nprod):
     assert got == full
 
 
+@pytest.mark.parametrize("n,d,knn", [(3000, 20, 9), (9000, 50, 5)])
+def test_unweighted_knn_graph_decay_none(n, d, knn):
+    """decay=None: graphtools' unweighted kNN graph (binary connectivity of the knn + 1 nearest, self
+    included), symmetrised and anisotropy-normalised like the weighted one."""
+    import meld_amd
+
+    mo = _oracle()
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=31)
+    op = meld_amd.MELD(knn=knn, decay=None, verbose=0).fit(X)
+    G = mo.build_graph(X, knn=knn, decay=None)
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-12
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    op.graph.lmax = lmax
+    dens = op.transform(labels)
+    ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=50, lmax=lmax)
+    assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_locality_reordering_does_not_change_results():
     """The permutation is a memory-layout decision only: identical graph and densities (to
     rounding: summation order inside a row changes) with and without it."""

@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_api.py -x -q -m gpu 2>&1 | tail -15
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -12
