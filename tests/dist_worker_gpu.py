@@ -1,0 +1,60 @@
+"""Worker of tests/test_gpu_parity.py::test_two_ranks_on_one_gpu: one rank of a 2-rank group in which
+BOTH ranks drive the real HIP kernels (HipOps) on the same GPU.  RCCL refuses two ranks on one device,
+so the collectives are staged through host memory over gloo -- the kernels, the shard arithmetic
+(q_begin > 0, owner exchange, row offsets) and the order of the collectives are exactly the production
+ones; only the transport differs."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path, n, d, knn):
+    dist.init_process_group("gloo")
+    import meld_amd
+    from meld_amd import distributed as mdist
+    from oracle import meld_oracle as mo
+
+    class StagedComm(mdist.Comm):
+        """meld_amd.distributed.Comm with every collective staged through CPU tensors (gloo)."""
+
+        def all_gather_rows(self, full, local):
+            f = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(f, local.detach().cpu().contiguous(), group=self.group)
+            full.copy_(f.to(full.device))
+
+        def all_reduce_sum(self, t):
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c.to(t.device))
+            return t
+
+        def all_reduce_max(self, t):
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(c.to(t.device))
+            return t
+
+        def exchange_by_owner(self, keys_sorted, vals_sorted, rows_per_rank):
+            rk, rv = super().exchange_by_owner(keys_sorted.cpu(), vals_sorted.cpu(), rows_per_rank)
+            return rk.to(keys_sorted.device), rv.to(vals_sorted.device)
+
+    torch.cuda.set_device(0)
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
+    dens = mdist.fit_transform_sharded(op, torch.from_numpy(X).cuda(), labels, comm=StagedComm())
+    G = op.graph
+    np.savez(
+        out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, lmax=G.lmax, row_begin=G.row_begin, n_rows=G.n_rows,
+        nnz_global=G.info["nnz_global"], iters=G.lmax_info["iterations"], device_resident=bool(G.lmax_info.get("device_resident", False)),
+    )
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))

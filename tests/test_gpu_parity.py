@@ -2,6 +2,9 @@
 inputs.  Tolerances: graph weights 1e-10 relative (fp64 both sides, different but exact distance
 formulas amplified by the decay exponent), densities 1e-5 relative to the column maximum as
 BASELINE.json's north_star states (measured ~1e-12 with a common lmax)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -381,6 +384,38 @@ def test_unweighted_knn_graph_decay_none(n, d, knn):
     dens = op.transform(labels)
     ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=50, lmax=lmax)
     assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    """Both ranks of a 2-rank group run the real HIP kernels on this GPU (collectives staged through host
+    memory over gloo, see tests/dist_worker_gpu.py): every rank must return the single-GPU result."""
+    import socket
+    import subprocess
+
+    import meld_amd
+
+    mo = _oracle()
+    n, d, knn = 20011, 16, 9
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn)]
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(2)]
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
+    ref = single.fit_transform(X, labels)
+    assert [int(r["row_begin"]) for r in ranks] == [0, (n + 1) // 2]
+    assert int(ranks[0]["nnz_global"]) == single.graph.nnz
+    assert bool(ranks[0]["device_resident"])  # the phase-wise Lanczos ran, not the host loop
+    for r in ranks:
+        assert abs(float(r["lmax"]) - single.graph.lmax) <= 1e-9 * single.graph.lmax
+        assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
 
 
 def test_locality_reordering_does_not_change_results():
