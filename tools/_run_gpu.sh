@@ -1,9 +1,6 @@
-mkdir -p gpurun_out/r3a
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/r3a/prof_stdout.log 2>&1
-python tools/rocpd_summary.py /tmp/prof/bench_results.db > gpurun_out/r3a/kernel_stats.md 2>&1
-head -8 gpurun_out/r3a/kernel_stats.md | cut -c1-200
-python bench.py --steps 5 --warmup 1 --stages > gpurun_out/r3a/bench_full.json 2> gpurun_out/r3a/bench_full.err
-cut -c1-250 gpurun_out/r3a/bench_full.json
-bash tools/pmc_knn.sh /tmp/pmc_knn 1000000 > gpurun_out/r3a/pmc_summary.txt 2>&1
-tail -60 gpurun_out/r3a/pmc_summary.txt | grep "nprod1" | cut -c1-150
+#!/bin/bash
+# What the round-end checks run on the GPU box: gpurun -- 'bash tools/_run_gpu.sh'
+mkdir -p gpurun_out/check
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -1
+python bench.py 2>gpurun_out/check/bench.err | tee gpurun_out/check/bench.json | cut -c1-300
