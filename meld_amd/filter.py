@@ -20,7 +20,7 @@ import torch
 
 from ._lib import check, get_lib, ptr
 
-__all__ = ["filter", "chebyshev_coefficients", "spectral_kernel", "lanczos_lmax", "chebyshev_apply", "IndicatorSignal"]
+__all__ = ["filter", "filter_sweep", "chebyshev_coefficients", "spectral_kernel", "lanczos_lmax", "chebyshev_apply", "IndicatorSignal"]
 
 
 class IndicatorSignal:
@@ -116,6 +116,8 @@ def chebyshev_apply(G, signal, coeffs, lmax):
     ops = _ops_of(G)
     comm = getattr(G, "comm", None)
     c = np.asarray(coeffs, dtype=np.float64)
+    if c.ndim == 2:
+        return _chebyshev_apply_batch(G, signal, c, lmax)
     if c.shape[0] < 2:
         raise TypeError("The coefficients have an invalid shape")
     t_old = signal.contiguous().clone()
@@ -140,6 +142,40 @@ def chebyshev_apply(G, signal, coeffs, lmax):
                 comm.all_gather_rows(t_old, loc)
             t_old, t_cur = t_cur, t_old
     return r
+
+
+def _chebyshev_apply_batch(G, signal, C, lmax):
+    """B filters of the same signal in ONE pass over the graph (the
+    parameter-sweep mode of reference ``meld/benchmark.py:186-200``): the polynomials T_k(L) s do not depend on
+    the filter, only the coefficients c[b, k] do, so the recurrence runs once and every step is added to all
+    B accumulators (one fused elementwise pass over [B, rows, p]).  Returns [B, rows_pad, p]."""
+    ops = _ops_of(G)
+    comm = getattr(G, "comm", None)
+    if C.shape[1] < 2:
+        raise TypeError("The coefficients have an invalid shape")
+    B = C.shape[0]
+    dev = signal.device
+    Cd = torch.from_numpy(np.ascontiguousarray(C)).to(dev)
+    t_old = signal.contiguous().clone()
+    if t_old.shape[0] != G.n_pad:
+        raise ValueError("signal has {} rows, the graph expects {}".format(t_old.shape[0], G.n_pad))
+    p = int(t_old.shape[1])
+    a1 = a2 = float(lmax) / 2.0
+    t_cur = torch.zeros_like(t_old)
+    loc0 = _local(G, t_old)
+    R = (0.5 * Cd[:, 0]).view(B, 1, 1) * loc0.unsqueeze(0)
+    ops.cheby_step(G, p, t_old, G.row_begin, None, _local(G, t_cur), None, 1.0 / a1, -a2 / a1, 0.0, 0.0)
+    R.addcmul_(_local(G, t_cur).unsqueeze(0).expand_as(R), Cd[:, 1].view(B, 1, 1).expand_as(R))
+    if comm is not None:
+        comm.all_gather_rows(t_cur, _local(G, t_cur))
+    for k in range(2, C.shape[1]):
+        loc = _local(G, t_old)
+        ops.cheby_step(G, p, t_cur, G.row_begin, loc, loc, None, 2.0 / a1, -2.0 * a2 / a1, -1.0, 0.0)
+        R.addcmul_(loc.unsqueeze(0).expand_as(R), Cd[:, k].view(B, 1, 1).expand_as(R))
+        if comm is not None:
+            comm.all_gather_rows(t_old, loc)
+        t_old, t_cur = t_cur, t_old
+    return R
 
 
 def _ritz_check(alphas, betas, tol):
@@ -304,6 +340,45 @@ def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
         s_prev, s_cur = s_cur, 1.0 / beta
         beta_prev = beta
     return theta, dict(iterations=it, residual=resid, tol=tol)
+
+
+def filter_sweep(signal, graph, filter, betas, offset=0, order=1, chebyshev_order=None):  # noqa: A002
+    """``[filter(signal, graph, filter, beta, ...) for beta in betas]`` in one pass over the graph
+    (parameter-sweep mode; the reference's benchmark loop re-runs the whole
+    filter per beta, ``meld/benchmark.py:186-200``).  Returns an ndarray [len(betas), N, p]."""
+    graph.estimate_lmax()
+    betas = [float(b) for b in betas]
+    if not betas:
+        raise ValueError("betas must not be empty")
+    if chebyshev_order is None:
+        chebyshev_order = 30
+    C = np.stack([chebyshev_coefficients(spectral_kernel(filter, b, offset, order, graph.lmax), graph.lmax, chebyshev_order) for b in betas])
+    is_ind = isinstance(signal, IndicatorSignal)
+    sig = signal if is_ind else np.asarray(getattr(signal, "values", signal), dtype=np.float64)
+    if sig.shape[0] != graph.N:
+        raise ValueError("First dimension should be the number of nodes G.N = {}, got {}.".format(graph.N, sig.shape))
+    if not is_ind and sig.ndim == 1:
+        sig = sig[:, None]
+    dev = graph.val.device
+    s_dev = sig.to_device(dev) if is_ind else torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+    perm = getattr(graph, "perm", None)
+    if perm is not None:
+        s_dev = s_dev.index_select(0, perm)
+    if graph.n_pad != graph.N:
+        s_dev = torch.cat([s_dev, torch.zeros(graph.n_pad - graph.N, s_dev.shape[1], dtype=s_dev.dtype, device=dev)])
+    R = chebyshev_apply(graph, s_dev, C, graph.lmax)  # [B, rows_pad, p]
+    comm = getattr(graph, "comm", None)
+    if comm is not None:
+        full = torch.empty(R.shape[0], graph.n_pad, R.shape[2], dtype=R.dtype, device=dev)
+        for b in range(R.shape[0]):
+            comm.all_gather_rows(full[b], R[b].contiguous())
+        R = full
+    R = R[:, : graph.N]
+    if perm is not None:
+        out = torch.empty_like(R)
+        out[:, perm] = R
+        R = out
+    return R.cpu().numpy()
 
 
 def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", chebyshev_order=None):  # noqa: A001,A002

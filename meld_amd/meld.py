@@ -314,6 +314,25 @@ class MELD(GraphEstimator):
         self.sample_densities = pd.DataFrame(densities, index=self._labels_index, columns=self.samples)
         return self.sample_densities
 
+    def transform_sweep(self, sample_labels, betas):
+        """``{beta: transform(sample_labels) with that beta}`` for a list of betas in ONE pass over the
+        graph (the Chebyshev polynomials of L applied to the indicators do not depend on beta; only the
+        coefficients do).  Parameter-sweep mode of SURVEY.md section 8f row 3; no reference counterpart
+        beyond the loop of ``meld/benchmark.py:186-200``."""
+        if self.solver != "chebyshev":
+            raise NotImplementedError("transform_sweep supports solver='chebyshev' only")
+        saved = self.beta
+        first = self.transform(sample_labels)  # validation, indicators, lmax -- and the result for self.beta
+        signal = _filter.IndicatorSignal(self._codes, self.samples.shape[0], self._indicator_scale)
+        R = _filter.filter_sweep(signal, self.graph, self.filter, betas, offset=self.offset, order=self.order,
+                                 chebyshev_order=self.chebyshev_order)
+        out = {}
+        for b, beta in enumerate(betas):
+            out[beta] = pd.DataFrame(R[b], index=self._labels_index, columns=self.samples)
+        self.beta = saved
+        self.sample_densities = first
+        return out
+
     def fit_transform(self, X, sample_labels, **kwargs):
         """Builds the graph on ``X`` and estimates the density of each sample in
         ``sample_labels`` (reference ``meld/meld.py:252-274``)."""

@@ -349,3 +349,26 @@ def test_benchmarker_pipeline_matches_the_oracle():
     ref = mo.normalize_densities(dens)[:, list(ind[0]).index("expt")]
     assert np.abs(lik2 - ref).max() <= 1e-5 * np.abs(ref).max()
     assert b2.calculate_mse(lik2) == pytest.approx(float(np.mean((pdf - ref) ** 2)), rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_beta_sweep_in_one_pass_equals_separate_transforms():
+    """Parameter-sweep mode: one recurrence pass, B accumulators."""
+    meld = _meld()
+    mo = _oracle()
+    X, labels = mo.synthetic_cells(6000, n_dims=20, seed=13)
+    labels = np.random.default_rng(2).choice(["a", "b", "c"], size=6000)
+    op = meld.MELD(knn=7, chebyshev_order=30, verbose=0).fit(X)
+    betas = [5, 20, 60, 150.5]
+    sweep = op.transform_sweep(labels, betas)
+    assert list(sweep) == betas
+    for beta in betas:
+        one = meld.MELD(knn=7, beta=beta, chebyshev_order=30, verbose=0).fit(op.graph).transform(labels)
+        assert list(sweep[beta].columns) == list(one.columns)
+        np.testing.assert_allclose(sweep[beta].values, one.values, rtol=0, atol=1e-13 * np.abs(one.values).max())
+    from meld_amd import filter as mfilter
+
+    s = np.random.default_rng(3).random((6000, 3))
+    R = mfilter.filter_sweep(s, op.graph, "laplacian", [1.0, 7.0], order=2, chebyshev_order=25)
+    for b, beta in enumerate([1.0, 7.0]):
+        np.testing.assert_allclose(R[b], mfilter.filter(s, op.graph, "laplacian", beta, order=2, chebyshev_order=25), rtol=0, atol=1e-13)
