@@ -274,12 +274,57 @@ class HipOps:
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
         tm.start()
-        sums = torch.empty(d, dtype=torch.float64, device=dev)
-        check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
-        mean = sums / N
+        if d <= 256:
+            sums = torch.empty(d, dtype=torch.float64, device=dev)
+            check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
+            mean = sums / N
+        else:  # beyond the column-sum kernel's width (only the library search path handles such data)
+            mean = X.mean(dim=0)
         norm2 = torch.empty(N, dtype=torch.float32, device=dev)
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
-        if self.search == "f16x3":
+        search = self.search
+        if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
+            search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
+        if search == "wide":
+            # Library path for wide data that was not reduced by PCA: chunked fp64 GEMMs (rocBLAS) for
+            # |q|^2 + |r|^2 - 2 q.r and torch.topk merges, feeding the same exact refinement.  No hand-written
+            # kernel: the reference's default (n_pca = 100) never gets here, and the distance GEMM at d >> 100 is
+            # a plain library GEMM.
+            research = None
+            cap = int(ksel)
+            err_coef, err_lin = 1e-6, 0.0  # fp64 GEMM form + fp32 storage of d2: << 1e-6 max|x~|^2
+            Xc = X - mean
+            n2 = (Xc * Xc).sum(dim=1)
+            norm2.copy_(n2.to(torch.float32))
+            nmax.copy_(n2.max().to(torch.float32).reshape(1))
+            tm.stop("prepare")
+            kk = min(int(ksel), N)
+            cand_idx = torch.zeros(q_count * cap, dtype=torch.int32, device=dev)
+            cand_d2 = torch.full((q_count * cap,), float("inf"), dtype=torch.float32, device=dev)
+            cand_cnt = torch.full((q_count,), kk, dtype=torch.int32, device=dev)
+            QC, RC = 4096, 32768
+            with _EventSpan("knn_topk", N=N, d=d, q=q_count):
+                for q0 in range(0, q_count, QC):
+                    q1 = min(q_count, q0 + QC)
+                    Xq = Xc[q_begin + q0 : q_begin + q1]
+                    nq = n2[q_begin + q0 : q_begin + q1]
+                    best_d = torch.full((q1 - q0, 0), 0.0, dtype=torch.float64, device=dev)
+                    best_i = torch.zeros((q1 - q0, 0), dtype=torch.int64, device=dev)
+                    for r0 in range(0, N, RC):
+                        r1 = min(N, r0 + RC)
+                        D = nq[:, None] + n2[None, r0:r1] - 2.0 * (Xq @ Xc[r0:r1].T)
+                        ids = torch.arange(r0, r1, device=dev, dtype=torch.int64)[None, :].expand(q1 - q0, -1)
+                        D = torch.cat([best_d, D], dim=1)
+                        ids = torch.cat([best_i, ids], dim=1)
+                        best_d, sel = torch.topk(D, min(kk, D.shape[1]), dim=1, largest=False, sorted=True)
+                        best_i = torch.gather(ids, 1, sel)
+                    rows = torch.arange(q0, q1, device=dev, dtype=torch.int64)[:, None] * cap + torch.arange(kk, device=dev)[None, :]
+                    cand_d2[rows.reshape(-1)] = best_d.clamp_(min=0.0).to(torch.float32).reshape(-1)
+                    cand_idx[rows.reshape(-1)] = best_i.to(torch.int32).reshape(-1)
+            KP = d
+            Q = Rt = None
+            del Xc
+        elif search == "f16x3":
             # split-fp16 operands on v_mfma_f32_32x32x16_f16 (knn16.hip)
             KB = lib.meld_knn16_kblocks(d)
             if KB < 0:
@@ -492,8 +537,8 @@ class HipOps:
                 "meld_coo_emit",
             )
         tm.stop("coo_emit")
-        info = dict(ksel=int(ksel), KP=int(KP), search=self.search, nprod=self.nprod, n_flagged_rows=n_flag_h,
-                    n_researched_rows=n_flag_stage1 if self.search == 'f16x3' and self.nprod == 1 else 0, nnz_directed=M)
+        info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=self.nprod, n_flagged_rows=n_flag_h,
+                    n_researched_rows=n_flag_stage1 if search == 'f16x3' and self.nprod == 1 else 0, nnz_directed=M)
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------

@@ -78,7 +78,7 @@ def locality_permutation(X, c1=None, fanouts=(16,), seed=0):
     128-byte line of the iterate (8 rows) holds cells that the same row block gathers again."""
     lib = get_lib()
     N, d = int(X.shape[0]), int(X.shape[1])
-    if N < 8192:
+    if N < 8192 or d > 128:  # (the assignment kernels stage <= 128 coordinates; wide data keeps its order)
         return None
     import os
 

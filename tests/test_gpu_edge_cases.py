@@ -135,3 +135,24 @@ def test_repeated_transform_with_many_label_sets_and_betas():
         ref = mo.meld_filter(ind, G, beta=beta, chebyshev_order=30, lmax=lmax)
         assert list(out.columns) == list(samples)
         assert np.abs(out.values - ref).max() / np.abs(ref).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(2500, 142), (1800, 300)])
+def test_wide_data_beyond_the_mfma_kernels(n, d):
+    """d > 141 (no PCA): the candidate search falls back to chunked library GEMMs + topk on the GPU and feeds
+    the same exact refinement -- same graph and densities as the oracle."""
+    import meld_amd
+    from oracle import meld_oracle as mo
+
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=17)
+    op = meld_amd.MELD(knn=7, n_pca=None, chebyshev_order=30, verbose=0).fit(X)
+    assert op.graph.info["search"] == "wide"
+    G = mo.build_graph(X, knn=7)
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    op.graph.lmax = lmax
+    dens = op.transform(labels)
+    ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
+    assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
