@@ -160,9 +160,10 @@ int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t 
                     const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream);
 
 /* Exact fp64 radius search for the flagged rows (the analogue of graphtools' re-search /
- * radius_neighbors fallback).  mode 0: fb_cnt[f] = number of off-diagonal references with
- * v >= thresh, and err_flag[0] |= 1 if the row's bandwidth cannot be confirmed;
- * mode 1: write (column, value) at fb_off[f] + running cursor (fb_cursor[f], zeroed by caller). */
+ * radius_neighbors fallback), rows x reference chunks over the whole device.  mode 0: fb_cnt[f] = number
+ * of off-diagonal references with v >= thresh, and err_flag[0] |= 1 if the row's bandwidth cannot be
+ * confirmed (fb_cursor[n_flag] is scratch for that check and is left zeroed);
+ * mode 1: write (column, value) at fb_off[f] + running cursor (fb_cursor[f], zero on entry). */
 int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, const int32_t* flag_rows,
                           int32_t n_flag, const double* bw, int knn, double decay, double thresh,
                           int mode, int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor,

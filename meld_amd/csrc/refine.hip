@@ -166,12 +166,16 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
     const double* __restrict__ X, int64_t N, int d, int64_t q_begin, const int* __restrict__ flag_rows,
     int n_flag, const double* __restrict__ bw_all, int knn, double decay, double thresh, int mode,
     int* __restrict__ fb_cnt, const int64_t* __restrict__ fb_off, int* __restrict__ fb_cursor,
-    int* __restrict__ fb_col, double* __restrict__ fb_val, int* __restrict__ err_flag) {
+    int* __restrict__ fb_col, double* __restrict__ fb_val, int* __restrict__ err_flag, int64_t ref_chunk) {
   extern __shared__ double xq[];  // [RB_FALL][d]
   __shared__ int s_cnt[RB_FALL];
   __shared__ int s_lt[RB_FALL];
+  // grid: x = group of RB_FALL flagged rows, y = chunk of the references (a handful of flagged rows must
+  // not be swept by a handful of workgroups: 2 rows x 1M references took 195 ms on one CU)
   const int f0 = blockIdx.x * RB_FALL;
   const int nf = min(RB_FALL, n_flag - f0);
+  const int64_t ref_lo = (int64_t)blockIdx.y * ref_chunk;
+  const int64_t ref_hi = min(N, ref_lo + ref_chunk);
   int64_t gi[RB_FALL];
   double bw[RB_FALL];
 #pragma unroll
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
 #pragma unroll
   for (int f = 0; f < RB_FALL; ++f) cnt[f] = lt[f] = 0;
 
-  for (int64_t ref = threadIdx.x; ref < N; ref += blockDim.x) {
+  for (int64_t ref = ref_lo + threadIdx.x; ref < ref_hi; ref += blockDim.x) {
     const double* xr = X + ref * d;
     // same summation order as refine_kernel: even / odd coordinate chains, then their sum
     double s[RB_FALL], s1[RB_FALL];
@@ -244,11 +248,20 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
     }
     __syncthreads();
     if (threadIdx.x < nf) {
-      fb_cnt[f0 + threadIdx.x] = s_cnt[threadIdx.x];
-      // bw is the (knn+1)-th smallest distance iff at most knn references are strictly closer
-      if (s_lt[threadIdx.x] > knn) atomicOr(err_flag, 1);
+      // per-row totals over the reference chunks: kept entries in fb_cnt, references strictly closer than
+      // the bandwidth in fb_cursor (checked, and cleared for the fill pass, by radius_check_kernel)
+      if (s_cnt[threadIdx.x]) atomicAdd(&fb_cnt[f0 + threadIdx.x], s_cnt[threadIdx.x]);
+      if (s_lt[threadIdx.x]) atomicAdd(&fb_cursor[f0 + threadIdx.x], s_lt[threadIdx.x]);
     }
   }
+}
+
+// bw is the (knn+1)-th smallest distance iff at most knn references are strictly closer
+__global__ void radius_check_kernel(int* __restrict__ lt_then_cursor, int n_flag, int knn, int* __restrict__ err_flag) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_flag) return;
+  if (lt_then_cursor[f] > knn) atomicOr(err_flag, 1);
+  lt_then_cursor[f] = 0;
 }
 
 }  // namespace meld
@@ -286,12 +299,25 @@ extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t 
                                      double* fb_val, int32_t* err_flag, meld_stream_t stream) {
   if (n_flag == 0) return MELD_OK;
   MELD_CHECK_ARG(X && flag_rows && bw && n_flag > 0 && N > 0 && d > 0, "meld_knn_radius_exact: bad arguments");
-  MELD_CHECK_ARG(mode == 0 ? (fb_cnt && err_flag) : (fb_off && fb_cursor && fb_col && fb_val),
+  MELD_CHECK_ARG(mode == 0 ? (fb_cnt && err_flag && fb_cursor) : (fb_off && fb_cursor && fb_col && fb_val),
                  "meld_knn_radius_exact: missing output for mode %d", mode);
   const size_t lds = sizeof(double) * RB_FALL * d;
-  hipLaunchKernelGGL(radius_exact_kernel, dim3((unsigned)ceil_div(n_flag, RB_FALL)), dim3(256), lds, S(stream), X, N,
-                     d, q_begin, flag_rows, n_flag, bw, knn, decay, thresh, mode, fb_cnt, fb_off, fb_cursor, fb_col,
-                     fb_val, err_flag);
+  // rows x reference chunks: about four workgroups per CU however few rows are flagged
+  const int64_t n_groups = ceil_div(n_flag, RB_FALL);
+  const int64_t want_chunks = std::max<int64_t>(1, 1024 / n_groups);
+  const int64_t ref_chunk = std::max<int64_t>(1024, ceil_div(ceil_div(N, want_chunks), 256) * 256);
+  const int64_t n_chunks = ceil_div(N, ref_chunk);
+  hipStream_t st = S(stream);
+  if (mode == 0) {
+    MELD_HIP_CALL(hipMemsetAsync(fb_cnt, 0, sizeof(int32_t) * n_flag, st));
+    MELD_HIP_CALL(hipMemsetAsync(fb_cursor, 0, sizeof(int32_t) * n_flag, st));
+  }
+  hipLaunchKernelGGL(radius_exact_kernel, dim3((unsigned)n_groups, (unsigned)n_chunks), dim3(256), lds, st, X, N, d, q_begin,
+                     flag_rows, n_flag, bw, knn, decay, thresh, mode, fb_cnt, fb_off, fb_cursor, fb_col, fb_val, err_flag,
+                     ref_chunk);
+  if (mode == 0)
+    hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, st, fb_cursor, n_flag, knn,
+                       err_flag);
   MELD_LAUNCH_CHECK("radius_exact_kernel");
   return MELD_OK;
 }

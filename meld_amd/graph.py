@@ -499,10 +499,11 @@ class HipOps:
             flag_rows = torch.sort(flag_rows[:n_flag_h]).values.contiguous()  # deterministic order
             fb_cnt = torch.empty(n_flag_h, dtype=torch.int32, device=dev)
             err = torch.zeros(1, dtype=torch.int32, device=dev)
+            cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)  # count pass: references closer than bw
             check(
                 lib.meld_knn_radius_exact(
                     ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
-                    ptr(fb_cnt), None, None, None, None, ptr(err), st,
+                    ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
                 ),
                 "meld_knn_radius_exact(count)",
             )
@@ -515,8 +516,7 @@ class HipOps:
                 )
             fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
             fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
-            cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)
-            check(
+            check(  # (the count pass left the cursors at zero)
                 lib.meld_knn_radius_exact(
                     ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 1,
                     None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,

@@ -42,12 +42,19 @@ def test_dimensions(d):
     _check_graph(X, knn=7)
 
 
-def test_dimension_too_large_fails_loudly():
+def test_dimension_too_large_for_the_mfma_kernels():
+    """d > 141: the split-fp16 kernel reports it loudly through the C-ABI; the graph builder then takes the
+    library search path (test_wide_data_beyond_the_mfma_kernels); the fp32 kernel, asked for explicitly, fails."""
     import meld_amd
+    from meld_amd._lib import get_lib
+    from meld_amd.graph import HipOps
 
-    X = torch.zeros(100, 200, dtype=torch.float64, device="cuda")
-    with pytest.raises(Exception, match="exceeds the largest"):
-        meld_amd.build_knn_graph(X)
+    lib = get_lib()
+    assert lib.meld_knn16_kblocks(200) < 0 and b"exceeds the largest" in lib.meld_last_error()
+    X = torch.from_numpy(np.random.default_rng(0).normal(size=(300, 200))).cuda()
+    assert meld_amd.build_knn_graph(X).info["search"] == "wide"
+    with pytest.raises(Exception, match="exceeds|unsupported|not an instantiated|padded"):
+        HipOps(search="f32").directed_kernel_coo(X, 0, 300, 5, 40, 1e-4, 32)
 
 
 def test_duplicated_points():
