@@ -326,6 +326,10 @@ class HipOps:
             del Xc
         elif search == "f16x3":
             # split-fp16 operands on v_mfma_f32_32x32x16_f16 (knn16.hip)
+            # In very low dimension the neighbours are so close (relative to max|x|^2) that the fp16-hi first
+            # pass certifies almost nothing (1M x 3: 968k of 1M rows re-searched) and is wasted; there the full
+            # split costs next to nothing (one K block), so it is used from the start.  Same result either way.
+            nprod = 3 if (self.nprod == 1 and d <= 6) else self.nprod
             KB = lib.meld_knn16_kblocks(d)
             if KB < 0:
                 check(KB, "meld_knn16_kblocks")
@@ -333,8 +337,8 @@ class HipOps:
             cap = lib.meld_knn16_row_capacity(ksel)
             if cap < 0:
                 check(cap, "meld_knn16_row_capacity")
-            err_coef = lib.meld_knn16_error_coef_const(self.nprod)
-            err_lin = lib.meld_knn16_error_coef_lin(self.nprod)
+            err_coef = lib.meld_knn16_error_coef_const(nprod)
+            err_lin = lib.meld_knn16_error_coef_lin(nprod)
             n_tiles = (N + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
             Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device=dev)
@@ -359,7 +363,7 @@ class HipOps:
             n_blocks = q_pad // BQ
             q_main, tail_slices = q_count, 1
             if lb2 is None and self.split_tail:
-                resident = lib.meld_knn16_resident_blocks(d, self.nprod)
+                resident = lib.meld_knn16_resident_blocks(d, nprod)
                 if resident < 0:
                     check(resident, "meld_knn16_resident_blocks")
                 tail_blocks = n_blocks % resident if resident > 0 else 0
@@ -368,7 +372,7 @@ class HipOps:
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, self.nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main
@@ -376,12 +380,12 @@ class HipOps:
                     t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
                     t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
                     t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, self.nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, ptr(t_idx), ptr(t_d2), ptr(t_cnt), st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, ptr(t_idx), ptr(t_d2), ptr(t_cnt), st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             del lb2
             KP = 16 * KB
-            research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if self.nprod == 1 else None
+            research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
         else:
             research = None
             # fp32 operands on v_mfma_f32_32x32x2_f32 (knn.hip)
@@ -537,8 +541,9 @@ class HipOps:
                 "meld_coo_emit",
             )
         tm.stop("coo_emit")
-        info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=self.nprod, n_flagged_rows=n_flag_h,
-                    n_researched_rows=n_flag_stage1 if search == 'f16x3' and self.nprod == 1 else 0, nnz_directed=M)
+        nprod_used = nprod if search == "f16x3" else self.nprod
+        info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
+                    n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M)
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------
