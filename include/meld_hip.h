@@ -94,17 +94,21 @@ int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, in
                        int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
 /* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_workgroups][n_tiles] with a lower
- * bound (bounding spheres + triangle inequality, scaled space) on the squared distance between
- * any query of a workgroup (BQ consecutive queries) and any reference of a tile (TS consecutive
- * references).  meld_knn16_topk skips -- without loading it -- every tile whose bound exceeds all
- * thresholds of the workgroup plus the search-error allowance, which cannot change the result.
- * It pays when consecutive cells are spatially close (meld_assign_nearest ordering).
- * lb2 = NULL disables pruning.  q_begin = global index of query 0 (the scan of every workgroup
- * starts at its own position among the references and wraps around). */
+ * bound (scaled space) on the squared distance between any query of a workgroup (BQ consecutive
+ * cells) and any reference of a tile (TS consecutive cells): (min over the workgroup's cells of the
+ * distance to the tile centroid - tile radius)^2, the minimum taken point by point by a cells x
+ * centroids distance GEMM on the MFMA path (Rt16 = the reference operand of meld_knn16_prepare).
+ * meld_knn16_topk skips -- without loading it -- every tile whose bound exceeds all thresholds of the
+ * workgroup plus the search-error allowance, which cannot change the result.  It pays when
+ * consecutive cells are spatially close (meld_assign_nearest ordering).  lb2 = NULL disables pruning.
+ * q_begin (a multiple of TS) = global index of query 0 (the scan of every workgroup starts at its own
+ * position among the references and wraps around).
+ * No reference counterpart: graphtools delegates the search to sklearn's trees. */
 size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                      int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream);
+                      const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count, void* temp,
+                      float* lb2, meld_stream_t stream);
 /* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are
@@ -123,8 +127,15 @@ int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mea
  * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
 int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                     int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
-                    const float* norm2_max, int64_t q_begin, const float* thr_init, int32_t* cand_idx,
-                    float* cand_d2, int32_t* cand_cnt, meld_stream_t stream);
+                    const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,
+                    int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr, meld_stream_t stream);
+/* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
+ * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
+ * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2
+ * above R = radius_factor^2 (A + E) + E can lie inside the kernel radius: the row's threshold drops to R, the
+ * list stays short (far fewer appends and compactions, tighter pruning) and cand_thr[q] (input units,
+ * roundup(q_count, BQ) floats) publishes the final threshold -- the list holds every reference below it --
+ * for meld_knn_refine's completeness test.  The graph is the same with or without the cut. */
 /* workgroups of meld_knn16_topk resident on the device at once (occupancy x CUs); the host hands a
  * nearly empty last wave of workgroups to a sliced launch instead of letting it run alone */
 int meld_knn16_resident_blocks(int d, int nprod);
@@ -152,8 +163,9 @@ int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, const int32
  *                             are copied to cand_idx_out (row stride out_cap) and flag_rows receives
  *                             the local row.  NULL = row q is local row q. */
 int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
-                    const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
-                    int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh,
+                    const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt,
+                    const float* cand_thr /* [q_count] thresholds published by meld_knn16_topk's radius cut, or NULL */,
+                    int ksel, int cap /* row stride of the candidate buffers */, int knn, double decay, double thresh,
                     const float* norm2_max, double err_coef,
                     const float* norm2 /* [N] per-row |x~|^2 or NULL */, double err_coef_lin, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
@@ -266,6 +278,10 @@ int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, do
  * wave inside one group. */
 int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
                         const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream);
+/* Greedy nearest-neighbour chain over the m (<= 64) rows of every group P[g] ([n_groups][m][d] fp64),
+ * starting at the row with the smallest first coordinate: rank[g][i] = position of row i along the chain
+ * (orders the centroids of the locality permutation so that consecutive groups are close in space). */
+int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream);
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */

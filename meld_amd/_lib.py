@@ -29,7 +29,7 @@ SIGNATURES = {
     "meld_knn_topk": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_refine": (
         _i32,
-        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _f64, _ptr, _ptr, _ptr,
+        [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _f64, _ptr, _ptr, _ptr,
          _ptr, _ptr, _ptr, _i32, _ptr, _ptr],
     ),
     "meld_knn_error_coef": (_f64, [_i32]),
@@ -47,8 +47,8 @@ SIGNATURES = {
     "meld_knn16_prepare_rows": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),
     "meld_knn16_bounds_temp_bytes": (_sz, [_i64, _i32, _i64]),
-    "meld_knn16_bounds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
-    "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn16_bounds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
+    "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_max_slices": (_i32, [_i32]),
     "meld_knn16_merge_slices": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_radius_exact": (
@@ -82,6 +82,7 @@ SIGNATURES = {
     "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
 }
 
 _lib = None

@@ -43,6 +43,7 @@ constexpr int K16_NWAVE = K16_THREADS / 64;
 constexpr int K16_SLACK = 128;     // CAP = ksel + slack
 constexpr int K16_CAPMAX = 256;
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
+constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -98,8 +99,17 @@ __device__ __forceinline__ int knn16_split_pos(int pos, int m0, int half) { retu
 // Keep (unsorted) the entries of a candidate row whose d2 is <= the ksel-th smallest d2, spread evenly
 // over the two half-rows.  Returns the new lengths through *n0_out / *n1_out and the threshold as
 // return value.  Wave-uniform arguments.
-__device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, float* __restrict__ d2row,
-                                   int* __restrict__ idxrow, int lane, int* n0_out, int* n1_out) {
+__device__ __forceinline__ float from_ordered_bits(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// Radius cut (knn1 > 0): with A = the knn1-th smallest d2 of the row (knn1 = knn + 1, self included) and E
+// the search-error allowance of the row, the exact bandwidth^2 is <= A + E, so every reference inside the
+// kernel radius has approximate d2 <= R = rf2 (A + E) + E: entries above R are dropped and *r_out = R
+// (+inf when the row has fewer than knn1 entries) lets the caller lower the row's threshold to it.
+__device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, int knn1, float rf2, float err,
+                                   float* __restrict__ d2row, int* __restrict__ idxrow, int lane, int* n0_out,
+                                   int* n1_out, float* r_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's append stores have reached L2
   float d[K16_SLOTS];
   int ix[K16_SLOTS];
@@ -130,16 +140,32 @@ __device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, float* __
     for (int e = 0; e < K16_SLOTS; ++e) c += __popcll(__ballot(key[e] < trial));
     if (c < ksel) T = trial;
   }
-  // survivors: key <= T (ties at T all stay; if that leaves no room the caller re-ranks)
+  float R = INFINITY;
+  if (knn1 > 0 && n0 + n1 >= knn1) {
+    unsigned A = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned trial = A | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < K16_SLOTS; ++e) c += __popcll(__ballot(key[e] < trial));
+      if (c < knn1) A = trial;
+    }
+    R = (rf2 * (from_ordered_bits(A) + err) + err) * 1.00001f + 1e-30f;
+  }
+  *r_out = R;
+  // survivors: key <= min(T, R) (ties at T all stay; if that leaves no room the caller re-ranks);
+  // return value: the d2 whose key is T (the ksel-th smallest), +inf if the row is shorter than ksel
+  const unsigned Tc = min(T, ordered_bits(R));
   int total = 0;
 #pragma unroll
-  for (int e = 0; e < K16_SLOTS; ++e) total += __popcll(__ballot(valid[e] && key[e] <= T));
+  for (int e = 0; e < K16_SLOTS; ++e) total += __popcll(__ballot(valid[e] && key[e] <= Tc));
   const int m0 = (total + 1) >> 1;
   int base = 0;
   float thr = INFINITY;
 #pragma unroll
   for (int e = 0; e < K16_SLOTS; ++e) {
-    const bool keep = valid[e] && key[e] <= T;
+    const bool keep = valid[e] && key[e] <= Tc;
     const unsigned long long b = __ballot(keep);
     if (keep) {
       const int dst = knn16_split_pos(base + __popcll(b & ((1ull << lane) - 1ull)), m0, half);
@@ -147,7 +173,7 @@ __device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, float* __
       idxrow[dst] = ix[e];
     }
     base += __popcll(b);
-    const unsigned long long bt = __ballot(keep && key[e] == T);
+    const unsigned long long bt = __ballot(valid[e] && key[e] == T);
     if (bt) thr = __shfl(d[e], __ffsll((long long)bt) - 1, 64);
   }
   *n0_out = m0;
@@ -218,9 +244,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const _Float16* __restrict__ Q16, const float* __restrict__ Qn, const _Float16* __restrict__ Rt16,
     const float* __restrict__ scale_info, int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
     float err_coef, int tile_origin, int batch_every, int batch_slack, int two_sided,
-    unsigned long long* __restrict__ stats, const float* __restrict__ thr_init,
+    unsigned long long* __restrict__ stats, const float* __restrict__ thr_init, int knn1, float rf2, float err_c, float err_l,
     int* __restrict__ cand_idx,
-    float* __restrict__ cand_d2, int* __restrict__ cand_cnt) {
+    float* __restrict__ cand_d2, int* __restrict__ cand_cnt, float* __restrict__ cand_thr) {
   // reference tile = KB K-blocks [kb][k-half][plane][ref][8 halves]; K slots d .. d+2 of the hi plane
   // hold |r|^2 as three fp16 pieces (against 1.0 on the query side), so the MFMAs deliver
   // |r|^2 - 2 q.r directly and no norm is read in the loop
@@ -269,7 +295,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto thr_start = [&](int g) __attribute__((always_inline)) { return thr_init ? thr_init[q_base + g * 32 + jq] : INFINITY; };
   float thrp[2] = {thr_start(0) - nq[0], thr_start(1) - nq[1]};
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
-  unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
+  unsigned st_slow = 0, st_app = 0, st_sq = 0, st_vis = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
   // the cells are in locality order) and wrapping around: step s -> tile (t0 + s) mod n_tiles.
@@ -297,17 +323,23 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     t = t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
     return tile_lo + t;
   };
-  // first step >= s whose tile may hold a candidate given the block-wide threshold bound
-  auto next_live = [&](int s, float bound) {
-    if (my_lb == nullptr) return s;
-    for (int base = s; base < n_scan; base += 64) {
-      const int ss = base + lane;
-      const bool live = ss < n_scan && my_lb[tile_of(ss)] <= bound;
-      const unsigned long long b = __ballot(live);
-      if (b) return base + (int)__ffsll((long long)b) - 1;
-    }
-    return n_scan;
+  // Pruning window: lane i holds the bound of step win_base + i; win_mask = steps of the window still to
+  // visit.  The hot loop only intersects the mask with `bound` (one compare + ballot, no memory access);
+  // the table is read once per 64 steps, in a cold region at the loop top where no tile load is in flight.
+  int win_base = 0;
+  float win_lb = 0.0f;
+  unsigned long long win_mask = 0;
+  auto load_window = [&](int base) __attribute__((always_inline)) {
+    const int ss = base + lane;
+    win_base = base;
+    win_lb = ss < n_scan ? my_lb[tile_of(ss)] : INFINITY;
+    win_mask = __ballot(ss < n_scan);
+    asm volatile("" : "+v"(win_lb));
   };
+  if (my_lb) {
+    load_window(0);
+    win_mask &= ~1ull;  // step 0 is the first tile
+  }
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   float4 p0, p1, p2, p3, p4, p5, p6, p7, p8;
@@ -426,7 +458,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const int n0 = __shfl(cg, j, 64), n1 = __shfl(cg, j + 32, 64);
     const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
     int m0, m1;
-    float nt = knn16_squeeze_row(n0, n1, half, ksel, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1);
+    float rcut = INFINITY, err = 0.0f;
+    if (knn1 > 0) {  // search-error allowance of this row, scaled units (refine.hip's E, rounded up)
+      const float nmax_s = norm2_max[0] * scale_info[0] * scale_info[0];
+      err = (err_c * nmax_s + err_l * sqrtf(__shfl(g ? nq[1] : nq[0], j, 64) * nmax_s)) * 1.001f;
+    }
+    float nt = knn16_squeeze_row(n0, n1, half, ksel, knn1, rf2, err, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1, &rcut);
     if (m0 > half - 32) {
       // pathological ties at the threshold: rank the row down to exactly ksel entries
       knn16_rank_row(m0, m1, half, ksel, 1.0f, (min(m0 + m1, ksel) + 1) >> 1, cand_d2 + ro, cand_idx + ro, lds_sd[wave],
@@ -440,7 +477,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     if (jq == j) {
       const int mine = h ? m1 : m0;
       if (g) cnt[1] = mine; else cnt[0] = mine;
-      thrp[g] = ((n0 + n1 >= ksel) ? nt : thr_start(g)) - nq[g];
+      // list threshold (the ksel-th smallest once the row has ksel entries) or the radius cut, whichever is
+      // lower: the row holds every reference seen so far whose d2 is below it
+      const float t_list = (n0 + n1 >= ksel) ? nt : thr_start(g);
+      thrp[g] = fminf(thrp[g], fminf(t_list, rcut) - nq[g]);
     }
     // every load of this cold region has landed when it ends: a result still pending at the join with
     // the hot loop would make the compiler put s_waitcnt vmcnt(0) in front of the next pipeline segment
@@ -562,10 +602,23 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       for (int w = 1; w < K16_NWAVE; ++w) bound = fmaxf(bound, lds_wthr[par][w]);
       bound += prune_margin;
     }
-    const int s_next = next_live(s_cur + 1, bound);
+    int s_next = s_cur + 1;
+    if (my_lb) {
+      unsigned long long live = win_mask & __ballot(win_lb <= bound);
+      if (__builtin_expect(live == 0, 0)) {
+        while (live == 0 && win_base + 64 < n_scan) {
+          load_window(win_base + 64);
+          live = win_mask & __ballot(win_lb <= bound);
+        }
+        K16_COLD_REGION_END();
+      }
+      s_next = live ? win_base + (int)__ffsll((long long)live) - 1 : n_scan;
+      win_mask = live & (live - 1);  // (the bound only decreases: a step that fails now fails later)
+    }
     // The tile index of the NEXT step is computed before its loads are issued and carried to the next
     // iteration: no control flow may sit between the loads and the first pipeline segment (at such a join
     // the compiler waits for all outstanding loads -- the ones just issued -- on every iteration).
+    if (ABL == 2) ++st_vis;
     const int t = t_cur;
     const int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
     t_cur = t_next;
@@ -620,14 +673,19 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
     if (lane == 0) {
-      atomicAdd(stats + 0, (unsigned long long)(2 * n_scan));
+      atomicAdd(stats + 0, (unsigned long long)(2 * st_vis));
       atomicAdd(stats + 1, (unsigned long long)st_slow);
       atomicAdd(stats + 2, (unsigned long long)a);
       atomicAdd(stats + 3, (unsigned long long)st_sq);
     }
   }
-  // final: sort every row, convert back to input units, publish its length
+  // final: sort every row, convert back to input units, publish its length and its threshold (the row
+  // holds every reference whose approximate d2 is below it)
   const float out_scale = scale_info[1];  // 1 / s^2
+  if (cand_thr && h == 0) {
+    cand_thr[row_base + jq] = (thrp[0] + nq[0]) * out_scale;
+    cand_thr[row_base + 32 + jq] = (thrp[1] + nq[1]) * out_scale;
+  }
   for (int j = 0; j < 64; ++j) {
     const int cg = (j >> 5) ? cnt[1] : cnt[0];
     const int n0 = __shfl(cg, j & 31, 64), n1 = __shfl(cg, (j & 31) + 32, 64);
@@ -686,69 +744,167 @@ __global__ __launch_bounds__(64) void knn16_merge_slices_kernel(const int* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// pruning bounds: bounding spheres of reference tiles / query workgroups in the scaled space
+// pruning bounds: lb2[b][t] = lower bound on the squared distance (scaled space) between any query of
+// workgroup b (K16_BQ consecutive cells) and any reference of tile t (K16_TS consecutive cells):
+//     ( min_{p in b} |p - c_t|  -  rho_t )^2        c_t = centroid of tile t, rho_t = max_{r in t} |r - c_t|
+// (triangle inequality; holds for any centre as long as rho_t is measured from the same one).  The
+// min over the cells of b is taken point by point -- a distance GEMM cells x centroids, 1/64 of the
+// search itself, on the same MFMA path with the centroids in the query role -- not from a bounding
+// sphere of b: in a 10-d geometry a sphere around 256 cells of a leaf is as wide as the distance to
+// the neighbouring leaves and prunes nothing (2 % of the pairs), the pointwise minimum prunes ~35 %.
 // ---------------------------------------------------------------------------------------------
-// One wave per group of `gsize` (<= 256, multiple of 64 or the 64-ref tile) consecutive points
-// [first + g*gsize, ...) clipped to [0, n_pts): centre = mean, radius = max distance to it.
-// centres are written transposed ([k][group]) so that the table kernel reads them coalesced.
-__global__ __launch_bounds__(64) void group_spheres_kernel(const double* __restrict__ X, int64_t n_pts, int d,
+// One workgroup per reference tile: centroid (scaled fp32) written as a query-operand row
+// ([kb][h][plane][8], 1.0 in K slots d .. d+2), its squared norm, and the tile radius.
+__global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restrict__ X, int64_t N, int d,
                                                            const double* __restrict__ mean,
-                                                           const float* __restrict__ scale_info, int64_t first,
-                                                           int gsize, int n_groups, float* __restrict__ centre_t,
-                                                           float* __restrict__ radius) {
-  const int g = blockIdx.x;
-  const int lane = threadIdx.x;
+                                                           const float* __restrict__ scale_info, int KB,
+                                                           _Float16* __restrict__ cent16, float* __restrict__ cent_n,
+                                                           float* __restrict__ cent_r) {
+  __shared__ float xs[K16_TS][K16_DMAX + 4];
+  __shared__ float cs[K16_DMAX + 19];
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * K16_TS;
+  const int cnt = (int)min((int64_t)K16_TS, N - row0);
   const float s = scale_info[0];
-  const int64_t b = first + (int64_t)g * gsize;
-  const int64_t e = min(b + gsize, n_pts);
-  const int cnt = (int)max((int64_t)0, e - b);
-  // pass 1: centre
-  for (int k = 0; k < d; ++k) {
-    float acc = 0.0f;
-    for (int64_t i = b + lane; i < e; i += 64) acc += s * (float)(X[i * d + k] - mean[k]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) centre_t[(size_t)k * n_groups + g] = cnt ? acc / (float)cnt : 0.0f;
+  for (int u = tid; u < K16_TS * d; u += 256) {
+    const int r = u / d, k = u - r * d;
+    const int64_t i = row0 + r;
+    xs[r][k] = i < N ? s * (float)(X[i * d + k] - mean[k]) : 0.0f;
   }
   __syncthreads();
-  // pass 2: radius
-  float r2 = 0.0f;
-  for (int64_t i = b + lane; i < e; i += 64) {
+  if (tid < KB * 16) {
     float acc = 0.0f;
-    for (int k = 0; k < d; ++k) {
-      const float t = s * (float)(X[i * d + k] - mean[k]) - centre_t[(size_t)k * n_groups + g];
-      acc = fmaf(t, t, acc);
-    }
-    r2 = fmaxf(r2, acc);
+    if (tid < d)
+      for (int r = 0; r < cnt; ++r) acc += xs[r][tid];
+    cs[tid] = tid < d ? acc / (float)cnt : 0.0f;
   }
+  __syncthreads();
+  if (tid < 64) {
+    float r2 = 0.0f;
+    if (tid < cnt) {
+      for (int k = 0; k < d; ++k) {
+        const float t = xs[tid][k] - cs[k];
+        r2 = fmaf(t, t, r2);
+      }
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
-  if (lane == 0) radius[g] = cnt ? sqrtf(r2) * 1.0001f + 1e-30f : -1.0f;  // -1: empty group
+    for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+    float n = 0.0f;
+    for (int k = 0; k < d; ++k) n = fmaf(cs[k], cs[k], n);
+    if (tid == 0) {
+      cent_r[blockIdx.x] = sqrtf(r2) * 1.0001f + 1e-30f;
+      cent_n[blockIdx.x] = n;
+    }
+  } else if (tid - 64 < KB * 2) {
+    const int g = tid - 64;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      _Float16 h16 = (_Float16)0.0f, l16 = (_Float16)0.0f;
+      if (c < d) {
+        h16 = (_Float16)cs[c];
+        l16 = (_Float16)(cs[c] - (float)h16);
+      } else if (c < d + 3) {
+        h16 = (_Float16)1.0f;
+      }
+      hi[e] = h16;
+      lo[e] = l16;
+    }
+    f16x8* qrow = reinterpret_cast<f16x8*>(cent16) + (size_t)blockIdx.x * ((size_t)KB * 4);
+    qrow[g * 2 + 0] = hi;
+    qrow[g * 2 + 1] = lo;
+  }
 }
 
-// lb2[qb][t] = max(0, |cq - ct| (1 - eps) - rq - rt)^2 ; empty tiles get +inf (always pruned)
-__global__ __launch_bounds__(256) void bounds_table_kernel(const float* __restrict__ cq_t, const float* __restrict__ rq,
-                                                           int n_qb, const float* __restrict__ ct_t,
-                                                           const float* __restrict__ rt, int n_tiles, int d,
-                                                           float* __restrict__ lb2) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int qb = blockIdx.y;
-  if (t >= n_tiles) return;
-  float acc = 0.0f;
-  for (int k = 0; k < d; ++k) {
-    const float df = cq_t[(size_t)k * n_qb + qb] - ct_t[(size_t)k * n_tiles + t];
-    acc = fmaf(df, df, acc);
+// Workgroup = 256 centroids (4 waves x 2 groups of 32, B fragments, hi parts) x a slice of the query
+// workgroups; the cells of a query workgroup are its K16_BQ / K16_TS reference tiles (hi planes, staged
+// through LDS as in the search kernel).  err_abs covers the hi-only product error of the distances.
+template <int KB>
+__global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
+                                                                const float* __restrict__ Cr,
+                                                                const _Float16* __restrict__ Rt16, int n_tiles,
+                                                                int first_tile, int n_blocks, float err_coef,
+                                                                const float* __restrict__ norm2_max,
+                                                                const float* __restrict__ scale_info,
+                                                                float* __restrict__ lb2) {
+  constexpr int TPB = K16_BQ / K16_TS;  // reference tiles per query workgroup
+  constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
+  constexpr int NS = (HV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
+  const int c_base = blockIdx.x * 256 + wave * 64;
+  f16x8 bhi[2][KB];
+  float cn[2], cr[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f16x8* qrow = reinterpret_cast<const f16x8*>(C16 + (size_t)(c_base + g * 32 + jq) * (KB * 32));
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
+    cn[g] = Cn[c_base + g * 32 + jq];
+    cr[g] = Cr[c_base + g * 32 + jq];
   }
-  float out;
-  if (rt[t] < 0.0f) {
-    out = INFINITY;
-  } else if (rq[qb] < 0.0f) {
-    out = 0.0f;
-  } else {
-    const float lb = sqrtf(acc) * 0.9999f - rq[qb] - rt[t];
-    out = lb > 0.0f ? lb * lb : 0.0f;
+  const float err_abs = err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+  const int b_lo = (int)((long long)n_blocks * blockIdx.y / gridDim.y);
+  const int b_hi = (int)((long long)n_blocks * (blockIdx.y + 1) / gridDim.y);
+  const int n_steps = (b_hi - b_lo) * TPB;
+  const float4* R4 = reinterpret_cast<const float4*>(Rt16);
+  float4 p[NS];
+  auto load = [&](int step) __attribute__((always_inline)) {
+    const int t = first_tile + (b_lo * TPB + step);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int j = tid + 256 * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
+      if (j < HV) p[u] = t < n_tiles ? R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int j = tid + 256 * u;
+      if (j < HV) lds_a[buf][j] = p[u];
+    }
+  };
+  if (n_steps <= 0) return;
+  load(0);
+  store(0);
+  __syncthreads();
+  float m[2] = {INFINITY, INFINITY};
+  for (int step = 0; step < n_steps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < n_steps) load(step + 1);
+    const int t = first_tile + (b_lo * TPB + step);
+    if (t < n_tiles) {  // (tiles past the end of the references: nothing there)
+      const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_a[buf]);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const f16x8 ahi = a8[(kb * 2 + h) * K16_TS + sub * 32 + jq];
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
+        }
+        m[0] = fminf(m[0], min16(c0));
+        m[1] = fminf(m[1], min16(c1));
+      }
+    }
+    if ((step % TPB) == TPB - 1) {
+      const int b = b_lo + step / TPB;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float v = fminf(m[g], __shfl_xor(m[g], 32, 64)) + cn[g];  // min_p |p - c|^2, approximate
+        const float dist = sqrtf(fmaxf(v - err_abs, 0.0f)) * 0.9999f - cr[g];
+        const int c = c_base + g * 32 + jq;
+        if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = dist > 0.0f ? dist * dist : 0.0f;
+        m[g] = INFINITY;
+      }
+    }
+    if (step + 1 < n_steps) store(buf ^ 1);
+    __syncthreads();
   }
-  lb2[(size_t)qb * n_tiles + t] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,7 +938,6 @@ __global__ void finish_scale_kernel(float* scale_info) {
 //           norm2[i] = |x_i - mean|^2 (input units), norm2_max = their maximum.
 //   else  : query rows q_begin + (rows ? rows[q] : q) -> [q][kb][h][plane][8], values x~ and 1.0 in K slots
 //           d .. d+2; Qn[q] = |x~|^2.
-constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
 template <bool IS_REF>
 __global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict__ X, int64_t N, int d,
@@ -962,26 +1117,54 @@ extern "C" size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count) {
   return (size_t)ceil_div(q_count, K16_BQ) * (size_t)ceil_div(n_ref, K16_TS) * sizeof(float);
 }
 extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count) {
-  const size_t n_t = (size_t)ceil_div(n_ref, K16_TS), n_q = (size_t)ceil_div(q_count, K16_BQ);
-  return sizeof(float) * ((n_t + n_q) * (size_t)(d + 1)) + 256;
+  (void)q_count;
+  const int kb = meld_knn16_kblocks(d);
+  if (kb < 0) return 0;
+  const size_t n_c = (size_t)ceil_div(ceil_div(n_ref, K16_TS), 256) * 256;  // centroid rows, padded to whole workgroups
+  return n_c * ((size_t)kb * 64 + 2 * sizeof(float)) + 256;
 }
 
 extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                                 int64_t q_begin, int64_t q_count, void* temp, float* lb2, meld_stream_t stream) {
-  MELD_CHECK_ARG(X && mean && scale_info && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 && q_begin + q_count <= N,
+                                 const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count, void* temp,
+                                 float* lb2, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 &&
+                     q_begin + q_count <= N,
                  "meld_knn16_bounds: bad arguments");
+  MELD_CHECK_ARG(q_begin % K16_TS == 0, "meld_knn16_bounds: q_begin must be a multiple of the reference tile (64 cells)");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
   const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(q_count, K16_BQ);
-  float* ct = reinterpret_cast<float*>(temp);
-  float* rt = ct + (size_t)n_t * d;
-  float* cq = rt + n_t;
-  float* rq = cq + (size_t)n_q * d;
+  const size_t n_c = (size_t)ceil_div(n_t, 256) * 256;
   hipStream_t st = S(stream);
-  hipLaunchKernelGGL(group_spheres_kernel, dim3(n_t), dim3(64), 0, st, X, N, d, mean, scale_info, (int64_t)0, K16_TS, n_t,
-                     ct, rt);
-  hipLaunchKernelGGL(group_spheres_kernel, dim3(n_q), dim3(64), 0, st, X, q_begin + q_count, d, mean, scale_info, q_begin,
-                     K16_BQ, n_q, cq, rq);
-  hipLaunchKernelGGL(bounds_table_kernel, dim3((unsigned)ceil_div(n_t, 256), n_q), dim3(256), 0, st, cq, rq, n_q, ct, rt,
-                     n_t, d, lb2);
+  _Float16* c16 = reinterpret_cast<_Float16*>(temp);
+  float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
+  float* cr = cn + n_c;
+  MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr);
+  const int gx = (int)(n_c / 256);
+  const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
+  const float ec = (float)meld_knn16_error_coef(1);
+#define K16_BOUNDS_CASE(KBV)                                                                                              \
+  case KBV:                                                                                                               \
+    hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV>), dim3(gx, gy), dim3(256), 0, st, c16, cn, cr,                      \
+                       reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,         \
+                       scale_info, lb2);                                                                                  \
+    break;
+  switch (KB) {
+    K16_BOUNDS_CASE(1)
+    K16_BOUNDS_CASE(2)
+    K16_BOUNDS_CASE(3)
+    K16_BOUNDS_CASE(4)
+    K16_BOUNDS_CASE(5)
+    K16_BOUNDS_CASE(6)
+    K16_BOUNDS_CASE(7)
+    K16_BOUNDS_CASE(8)
+    K16_BOUNDS_CASE(9)
+    default:
+      set_err("meld_knn16_bounds: no kernel for %d K blocks", KB);
+      return MELD_ERR_UNSUPPORTED;
+  }
+#undef K16_BOUNDS_CASE
   MELD_LAUNCH_CHECK("meld_knn16_bounds");
   return MELD_OK;
 }
@@ -989,14 +1172,21 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                                int64_t n_ref, int d,
                                int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
-                               const float* norm2_max, int64_t q_begin, const float* thr_init, int32_t* cand_idx,
-                               float* cand_d2, int32_t* cand_cnt, meld_stream_t stream) {
+                               const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                               double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                               float* cand_thr, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
                  K16_MERGE_MAX);
   MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
+  // radius cut (cand_thr != NULL): rows are cut at the kernel radius implied by their knn-th neighbour so far
+  MELD_CHECK_ARG(cand_thr == nullptr || (norm2_max != nullptr && knn >= 1 && knn < ksel && radius_factor >= 1.0 && n_slices == 1),
+                 "meld_knn16_topk: the radius cut needs norm2_max, 1 <= knn < ksel, radius_factor >= 1 and one slice");
+  const int knn1 = cand_thr ? knn + 1 : 0;
+  const float rf2 = cand_thr ? (float)(radius_factor * radius_factor * (1.0 + 1e-6)) : 0.0f;
+  const float err_c = (float)meld_knn16_error_coef_const(nprod), err_l = (float)meld_knn16_error_coef_lin(nprod);
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
   const int cap = meld_knn16_row_capacity(ksel);
   if (cap < 0) return cap;
@@ -1035,7 +1225,8 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
 #define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
   hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, Qn, r,  \
                      scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
-                     tile_origin, batch_every, batch_slack, two_sided, stats, thr_init, cand_idx, cand_d2, cand_cnt)
+                     tile_origin, batch_every, batch_slack, two_sided, stats, thr_init, knn1, rf2, err_c, err_l, cand_idx, cand_d2, \
+                     cand_cnt, cand_thr)
 #define K16_LAUNCH(KBV, ABLV)        \
   do {                               \
     if (nprod == 1)                  \

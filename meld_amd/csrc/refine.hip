@@ -37,8 +37,8 @@ __device__ __forceinline__ double decay_kernel(double dist, double bw, double de
 // one wave per query row; lane c owns candidates c and c + 64
 __global__ __launch_bounds__(256) void refine_kernel(
     const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
-    const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, int ksel, int cap, int knn,
-    double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
+    const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, const float* __restrict__ cand_thr, int ksel,
+    int cap, int knn, double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
     const float* __restrict__ norm2, double err_coef_lin,
     double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
     int* __restrict__ flag_rows, int* __restrict__ n_flag, const int* __restrict__ rows, int out_cap,
@@ -128,11 +128,12 @@ __global__ __launch_bounds__(256) void refine_kernel(
 
   // completeness test in squared-distance space
   const double radius = bw * radius_factor;
-  bool complete = true;
-  if (cand_cnt[q] >= ksel) {
-    const double tau = (double)cand_d2[ro + ksel - 1];
-    complete = (radius * radius + E <= tau);
-  }
+  // tau: every reference that is not in the list has approximate d2 >= tau -- the last entry of a full
+  // list, or the threshold the search published for a row it cut at the kernel radius (cand_thr)
+  double tau = INFINITY;
+  if (cand_cnt[q] >= ksel) tau = (double)cand_d2[ro + ksel - 1];
+  if (cand_thr != nullptr) tau = fmin(tau, (double)cand_thr[q]);
+  bool complete = (radius * radius + E <= tau);
   if (n <= knn) complete = false;  // cannot even define the bandwidth from this list
 
   int kept = 0;
@@ -275,7 +276,8 @@ __global__ void radius_check_kernel(int* __restrict__ lt_then_cursor, int n_flag
 using namespace meld;
 
 extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t q_count,
-                               const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt, int ksel,
+                               const int32_t* cand_idx, const float* cand_d2, const int32_t* cand_cnt,
+                               const float* cand_thr, int ksel,
                                int cap, int knn, double decay, double thresh, const float* norm2_max, double err_coef,
                                const float* norm2, double err_coef_lin, double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
@@ -292,7 +294,7 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(err_coef >= 0 && err_coef_lin >= 0, "meld_knn_refine: error coefficients must be non-negative");
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
-                     q_count, cand_idx, cand_d2, cand_cnt, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
+                     q_count, cand_idx, cand_d2, cand_cnt, cand_thr, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
                      err_coef, norm2, err_coef_lin, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
                      cand_idx_out);
   MELD_LAUNCH_CHECK("refine_kernel");

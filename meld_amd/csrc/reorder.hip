@@ -102,6 +102,51 @@ __global__ __launch_bounds__(256) void assign_nearest_grouped_kernel(const doubl
   if (l == 0) out[i] = arg;
 }
 
+// Greedy nearest-neighbour chain over the m (<= 64) rows of every group P[g] ([n_groups][m][d]): one wave
+// per group, lane i = row i.  Starts at the row with the smallest first coordinate; rank[g][i] = position
+// of row i along the chain.  (Was a host loop: the device -> host copy, the NumPy walk and the copy back
+// cost 4.6 ms at 1M cells with three levels.)
+__global__ __launch_bounds__(64) void chain_order_kernel(const double* __restrict__ P, int m, int d,
+                                                         int* __restrict__ rank) {
+  const int lane = threadIdx.x;
+  const double* Pg = P + (size_t)blockIdx.x * m * d;
+  int* rg = rank + (size_t)blockIdx.x * m;
+  auto argmin = [&](double v) {  // lowest index among the minima
+    int i = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off, 64);
+      const int oi = __shfl_xor(i, off, 64);
+      if (ov < v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+      }
+    }
+    return i;
+  };
+  bool used = lane >= m;
+  int cur = argmin(lane < m ? Pg[(size_t)lane * d] : INFINITY);
+  if (lane == cur) {
+    used = true;
+    rg[lane] = 0;
+  }
+  for (int step = 1; step < m; ++step) {
+    double dist = INFINITY;
+    if (!used) {
+      dist = 0.0;
+      for (int k = 0; k < d; ++k) {
+        const double t = Pg[(size_t)lane * d + k] - Pg[(size_t)cur * d + k];
+        dist = fma(t, t, dist);
+      }
+    }
+    cur = argmin(dist);
+    if (lane == cur) {
+      used = true;
+      rg[lane] = step;
+    }
+  }
+}
+
 }  // namespace meld
 
 using namespace meld;
@@ -131,5 +176,12 @@ extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const doub
 #undef MELD_ASSIGN_GROUPED
   }
   MELD_LAUNCH_CHECK("assign_nearest_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream) {
+  MELD_CHECK_ARG(P && rank && n_groups > 0 && m >= 1 && m <= 64 && d > 0, "meld_chain_order: bad arguments (1 <= m <= 64)");
+  hipLaunchKernelGGL(chain_order_kernel, dim3((unsigned)n_groups), dim3(64), 0, S(stream), P, m, d, rank);
+  MELD_LAUNCH_CHECK("chain_order_kernel");
   return MELD_OK;
 }

@@ -253,7 +253,8 @@ class HipOps:
         # the bounding spheres of 64-cell tiles (radius 0.72) dwarf the neighbour radius (0.63), 98 % of
         # the (workgroup, tile) pairs stay live and the table costs 3 ms; it pays on low-dimensional or
         # well-separated data
-        self.prune = (os.environ.get("MELD_KNN_PRUNE", "0") != "0") if prune is None else bool(prune)
+        self.prune = (os.environ.get("MELD_KNN_PRUNE", "1") != "0") if prune is None else bool(prune)
+        self.radius_cut = os.environ.get("MELD_KNN_RADIUS_CUT", "1") != "0"
         # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
         # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
         # waves and the sliced launch costs more than the idle tail, so it is off
@@ -283,6 +284,7 @@ class HipOps:
         norm2 = torch.empty(N, dtype=torch.float32, device=dev)
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
+        cand_thr, rfac = None, 1.0
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if search == "wide":
@@ -350,12 +352,17 @@ class HipOps:
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
             cand_cnt = torch.empty(q_pad, dtype=torch.int32, device=dev)
+            if self.radius_cut and knn < ksel:
+                # rows are cut at the kernel radius their (knn+1)-th neighbour so far implies; the search
+                # publishes each row's final threshold for refine's completeness test
+                cand_thr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
+                rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
             lb2 = None
-            if self.prune:
+            if self.prune and q_begin % TS == 0 and N >= 16384:
                 tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
                 tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count) // 4, dtype=torch.float32, device=dev)
-                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
             # of the chip idle is searched separately with the references cut into slices, so that its
@@ -372,7 +379,7 @@ class HipOps:
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main
@@ -380,7 +387,7 @@ class HipOps:
                     t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
                     t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
                     t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, ptr(t_idx), ptr(t_d2), ptr(t_cnt), st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             del lb2
@@ -426,7 +433,7 @@ class HipOps:
             nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
         check(
             lib.meld_knn_refine(
-                ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ksel, cap, knn, float(decay),
+                ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ksel, cap, knn, float(decay),
                 float(thresh), ptr(nmax_used), float(err_coef), ptr(norm2), float(err_lin), ptr(bw), ptr(cand_val), ptr(keep_cnt),
                 ptr(flag_rows), ptr(n_flag), None, 0, None, st,
             ),
@@ -472,7 +479,7 @@ class HipOps:
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
@@ -482,7 +489,7 @@ class HipOps:
             n_flag.zero_()
             check(
                 lib.meld_knn_refine(
-                    ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), ksel, cap, knn, float(decay),
+                    ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, ksel, cap, knn, float(decay),
                     float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
                     ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), st,
                 ),

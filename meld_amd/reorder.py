@@ -19,28 +19,16 @@ __all__ = ["locality_permutation"]
 
 
 def _chain_order_batched(P):
-    """Greedy nearest-neighbour chain over the rows of every P[b] (torch [B, m, d], any device)
-    -> rank [B, m] int64 (on P's device): position of each row along its chain.  The centroid sets are
-    tiny (<= 64 x 16 rows), so the chain is walked on the host in one vectorised NumPy loop: the m-step
-    device version cost ~6 launches per step (3 ms of launch latency at 1M cells)."""
-    B, m, _ = P.shape
+    """Greedy nearest-neighbour chain over the rows of every P[b] (CUDA fp64 [B, m, d], m <= 64)
+    -> rank [B, m] int64: position of each row along its chain (one wave per group on the device)."""
+    B, m, d = P.shape
     dev = P.device
     if m <= 2:
         return torch.arange(m, device=dev, dtype=torch.int64)[None, :].repeat(B, 1)
-    Pf = P.detach().to(torch.float32).cpu().numpy()
-    sq = np.einsum("bik,bik->bi", Pf, Pf)
-    D = sq[:, :, None] + sq[:, None, :] - 2.0 * np.einsum("bik,bjk->bij", Pf, Pf)  # [B, m, m] squared distances
-    ar = np.arange(B)
-    rank = np.zeros((B, m), dtype=np.int64)
-    cur = np.argmin(Pf[:, :, 0], axis=1)  # start from an extreme point along the first coordinate
-    used = np.zeros((B, m), dtype=bool)
-    used[ar, cur] = True
-    for step in range(1, m):
-        row = np.where(used, np.inf, D[ar, cur])
-        cur = np.argmin(row, axis=1)
-        used[ar, cur] = True
-        rank[ar, cur] = step
-    return torch.from_numpy(rank).to(dev)
+    P = P.contiguous()
+    rank = torch.empty((B, m), dtype=torch.int32, device=dev)
+    check(get_lib().meld_chain_order(ptr(P), B, m, d, ptr(rank), torch.cuda.current_stream().cuda_stream), "meld_chain_order")
+    return rank.to(torch.int64)
 
 
 def _chain_order(P):
@@ -67,7 +55,7 @@ def _split_level(X, lib, st, group, n_groups, fanout):
     return child.to(torch.int64), rank
 
 
-def locality_permutation(X, c1=None, fanouts=(16,), seed=0):
+def locality_permutation(X, c1=None, fanouts=(16, 16), seed=0):
     """X: CUDA fp64 [N, d].  Returns perm (device int64 [N]) or None when N is too small to matter.
 
     Level 0: nearest of c1 (<= 64) random cells (coarse cells, ordered by a chain); each further

@@ -299,7 +299,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, ptr(ci), ptr(cd), ptr(cc), st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -448,17 +448,22 @@ def test_tile_pruning_is_exact():
     from meld_amd.graph import HipOps
     from meld_amd.reorder import locality_permutation
 
-    X, _ = mo.synthetic_cells(30000, n_dims=50, seed=31)
-    Xd = torch.from_numpy(X).cuda()
-    for ordered in (True, False):
-        Xs = Xd.index_select(0, locality_permutation(Xd)) if ordered else Xd
-        outs = []
-        for prune in (False, True):
-            ops = HipOps(prune=prune)
-            keys, vals, bw, info = ops.directed_kernel_coo(Xs, 0, 30000, 15, 40, 1e-4, 64)
-            outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
-        for a, b in zip(*outs):
-            assert torch.equal(a, b)
+    for dims, knn in ((50, 15), (3, 5)):  # (d <= 6 runs the full hi/lo split from the first pass)
+        X, _ = mo.synthetic_cells(30000, n_dims=dims, seed=31)
+        Xd = torch.from_numpy(X).cuda()
+        for ordered in (True, False):
+            Xs = Xd.index_select(0, locality_permutation(Xd)) if ordered else Xd
+            outs = []
+            # pruning and the radius cut (rows cut at the kernel radius their knn-th neighbour implies) are
+            # independent switches of the search; the graph must not depend on either
+            for prune, cut in ((False, False), (True, False), (False, True), (True, True)):
+                ops = HipOps(prune=prune)
+                ops.radius_cut = cut
+                keys, vals, bw, info = ops.directed_kernel_coo(Xs, 0, 30000, knn, 40, 1e-4, 64)
+                outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
+            for other in outs[1:]:
+                for a, b in zip(outs[0], other):
+                    assert torch.equal(a, b)
 
 
 def test_knn16_reference_slices_merge_to_the_same_rows():
@@ -496,7 +501,7 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
         cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
         cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
-        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, ptr(ci), ptr(cd), ptr(cc), st))
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, st))
         if S > 1:
             mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
             md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")

@@ -21,7 +21,7 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
     ops = HipOps()
     for r in range(reps):
         mg.record_events(True)
-        keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, n, 15, 40, 1e-4, int(os.environ.get("KSEL", "64")))
+        keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, n, int(os.environ.get("KNN", "15")), 40, 1e-4, int(os.environ.get("KSEL", "64")))
         torch.cuda.synchronize()
         ev = mg.event_times_ms()
         ms = ev["knn_topk"][0]
