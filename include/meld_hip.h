@@ -93,22 +93,23 @@ size_t meld_knn16_query_bytes(int d);    /* bytes of one query row of Q16 */
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
-/* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_workgroups][n_tiles] with a lower
- * bound (scaled space) on the squared distance between any query of a workgroup (BQ consecutive
- * cells) and any reference of a tile (TS consecutive cells): (min over the workgroup's cells of the
- * distance to the tile centroid - tile radius)^2, the minimum taken point by point by a cells x
- * centroids distance GEMM on the MFMA path (Rt16 = the reference operand of meld_knn16_prepare).
- * meld_knn16_topk skips -- without loading it -- every tile whose bound exceeds all thresholds of the
- * workgroup plus the search-error allowance, which cannot change the result.  It pays when
- * consecutive cells are spatially close (meld_assign_nearest ordering).  lb2 = NULL disables pruning.
- * q_begin (a multiple of TS) = global index of query 0 (the scan of every workgroup starts at its own
- * position among the references and wraps around).
+/* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_waves][n_tiles] (fp16, rounded towards
+ * zero) with a lower bound (scaled space) on the squared distance between any query of a wave of the
+ * search kernel (64 consecutive cells = one reference tile) and any reference of a tile (TS consecutive
+ * cells): (min over the wave's cells of the distance to the tile centroid - tile radius)^2, the minimum
+ * taken point by point by a cells x centroids distance GEMM on the MFMA path (Rt16 = the reference
+ * operand of meld_knn16_prepare).  In meld_knn16_topk a wave sits out every tile whose bound exceeds all
+ * of its thresholds plus the search-error allowance, and a tile no wave of the workgroup needs is not
+ * even loaded -- neither can change the result.  It pays when consecutive cells are spatially close
+ * (meld_assign_nearest ordering).  lb2 = NULL disables pruning.  q_begin (a multiple of TS) = global
+ * index of query 0 (the scan of every workgroup starts at its own position among the references and
+ * wraps around).
  * No reference counterpart: graphtools delegates the search to sklearn's trees. */
 size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                       const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count, void* temp,
-                      float* lb2, meld_stream_t stream);
+                      void* lb2, meld_stream_t stream);
 /* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are
@@ -126,9 +127,10 @@ int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mea
  * own workgroups into its own candidate rows (buffers of n_slices * roundup(q_count, BQ) rows);
  * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
 int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
-                    int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
+                    int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
                     const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,
-                    int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr, meld_stream_t stream);
+                    int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
+                    uint64_t* tiles_done /* += (wave, tile) pairs actually computed, or NULL */, meld_stream_t stream);
 /* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
  * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
  * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2

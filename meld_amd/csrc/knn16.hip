@@ -227,6 +227,32 @@ __device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_sca
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Kernel arguments of knn16_topk_kernel, one struct passed by value: its layout IS the kernel-argument
+// segment, which lets cold code re-read a field where it is needed instead of holding it in an SGPR for
+// the whole scan.
+struct K16Args {
+  const _Float16* Q16;
+  const float* Qn;
+  const _Float16* Rt16;
+  const float* scale_info;
+  int n_ref, n_tiles, ksel, cap;
+  const __half* lb2;
+  const float* norm2_max;
+  float err_coef;
+  int tile_origin, batch_every, batch_slack, two_sided;
+  unsigned long long* stats;
+  const float* thr_init;
+  int knn1;
+  float rf2, err_c, err_l;
+  int* cand_idx;
+  float* cand_d2;
+  int* cand_cnt;
+  float* cand_thr;
+  unsigned long long* tiles_done;
+};
+#define K16_COLD(FIELD) \
+  (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
+
 // Waves per SIMD the kernel is compiled for (min = max).  Pinning it (a) keeps the MFMA results in VGPRs
 // -- with a 512-register budget hipcc selects the AGPR form and every vote pays 32 v_accvgpr_read -- and
 // (b) lets the scheduler keep the interleaved MFMA / vote order instead of trading it for occupancy it
@@ -240,13 +266,19 @@ template <int KB, int ABL, int NPROD>  // 16 KB >= d + 3; ABL: 0 = product, 2 = 
                                       // only), 6 = product at two waves per SIMD where three are the default;
                                       // NPROD: split products (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
 __global__ __launch_bounds__(K16_THREADS)
-__attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(
-    const _Float16* __restrict__ Q16, const float* __restrict__ Qn, const _Float16* __restrict__ Rt16,
-    const float* __restrict__ scale_info, int n_ref, int n_tiles, int ksel, int cap, const float* __restrict__ lb2, const float* __restrict__ norm2_max,
-    float err_coef, int tile_origin, int batch_every, int batch_slack, int two_sided,
-    unsigned long long* __restrict__ stats, const float* __restrict__ thr_init, int knn1, float rf2, float err_c, float err_l,
-    int* __restrict__ cand_idx,
-    float* __restrict__ cand_d2, int* __restrict__ cand_cnt, float* __restrict__ cand_thr) {
+__attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(const K16Args a) {
+  // Arguments the scan loop needs stay in SGPRs; the cold ones (K16_COLD: compaction parameters, the outputs
+  // of the epilogue, profiling) are re-read from the kernel-argument segment where they are used -- kept live
+  // across the loop they pushed the kernel past its 102 SGPRs, the spills went to VGPR lanes and on to
+  // scratch, and the MFMA / vote interleaving fell apart (measured: 74 -> 81 ms).
+  const _Float16* __restrict__ Q16 = a.Q16;
+  const float* __restrict__ Qn = a.Qn;
+  const _Float16* __restrict__ Rt16 = a.Rt16;
+  const int n_tiles = a.n_tiles, ksel = a.ksel, cap = a.cap;
+  const __half* __restrict__ lb2 = a.lb2;
+  const int batch_every = a.batch_every, two_sided = a.two_sided;
+  int* __restrict__ cand_idx = a.cand_idx;
+  float* __restrict__ cand_d2 = a.cand_d2;
   // reference tile = KB K-blocks [kb][k-half][plane][ref][8 halves]; K slots d .. d+2 of the hi plane
   // hold |r|^2 as three fp16 pieces (against 1.0 on the query side), so the MFMAs deliver
   // |r|^2 - 2 q.r directly and no norm is read in the loop
@@ -255,11 +287,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
-  __shared__ float lds_wthr[2][K16_NWAVE];  // per-wave max threshold, double-buffered by step parity
+  __shared__ unsigned long long lds_wlive[3][K16_NWAVE];  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform by construction; the compiler cannot tell)
   const int jq = lane & 31;
   const int h = lane >> 5;
   const int q_base = blockIdx.x * K16_BQ + wave * 64;  // first query of this wave
@@ -287,15 +319,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 
   int cnt[2] = {0, 0};  // entries this lane has appended to its half of the rows of its two queries
   const int half = cap >> 1;
-  if (lane == 0) lds_wthr[0][wave] = lds_wthr[1][wave] = INFINITY;
+  if (lane == 0) lds_wlive[0][wave] = lds_wlive[1][wave] = lds_wlive[2][wave] = ~0ull;
   // thr_init (optional, scaled units): a bound the caller knows every wanted neighbour to lie below (the
   // re-search of rows whose first-pass list could not be certified knows one); it starts the thresholds
   // there instead of at +inf, so that only a handful of candidates per query ever take the slow path
   // (only thrp = thr - |q|^2 lives in registers: the kernel is compiled for a fixed register budget)
-  auto thr_start = [&](int g) __attribute__((always_inline)) { return thr_init ? thr_init[q_base + g * 32 + jq] : INFINITY; };
+  auto thr_start = [&](int g) __attribute__((always_inline)) { return a.thr_init ? a.thr_init[q_base + g * 32 + jq] : INFINITY; };
   float thrp[2] = {thr_start(0) - nq[0], thr_start(1) - nq[1]};
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
-  unsigned st_slow = 0, st_app = 0, st_sq = 0, st_vis = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
+  unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
   // the cells are in locality order) and wrapping around: step s -> tile (t0 + s) mod n_tiles.
@@ -303,9 +335,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // any query of the workgroup and any reference of the tile; a tile whose bound exceeds every
   // threshold of the workgroup cannot contribute a candidate and is skipped without being loaded.
   // search-error allowance in the scaled space: a skipped tile must fail `d2_approx < thr` for sure
-  const float prune_margin = lb2 ? err_coef * norm2_max[0] * scale_info[0] * scale_info[0] : 0.0f;
-  const int t0 = (int)(((long long)tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
-  const float* my_lb = lb2 ? lb2 + (size_t)blockIdx.x * n_tiles : nullptr;
+  const float prune_margin = lb2 ? a.err_coef * a.norm2_max[0] * a.scale_info[0] * a.scale_info[0] : 0.0f;
+  const int t0 = (int)(((long long)a.tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
+  const __half* my_lb = lb2 ? lb2 + (size_t)(blockIdx.x * K16_NWAVE + wave) * n_tiles : nullptr;
   // (A "convoy" order -- all resident workgroups sweeping the same tiles at the same time so that all but
   // the first find them in L2 -- was tried: the base loop gained 7 %, but the thresholds converge later and
   // the net was +3 %; its progress counter was also a returning atomic in the loop, whose pending result made
@@ -323,23 +355,38 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     t = t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
     return tile_lo + t;
   };
-  // Pruning window: lane i holds the bound of step win_base + i; win_mask = steps of the window still to
-  // visit.  The hot loop only intersects the mask with `bound` (one compare + ballot, no memory access);
-  // the table is read once per 64 steps, in a cold region at the loop top where no tile load is in flight.
+  // Pruning window (64 steps): lane i holds THIS WAVE's bound for step win_base + i (lb2 has one row per wave:
+  // the wave's 64 queries against every tile).  my_live = steps of the window whose tile may still hold a
+  // candidate for the wave (its bound <= the wave's largest threshold + the search-error allowance); the waves
+  // publish their masks in LDS before every tile barrier, the union decides which tile the workgroup stages
+  // next, and a wave whose own bit is clear sits the tile out (no MFMAs, no vote).  win_rem = steps not yet
+  // passed.  The hot loop touches no memory for this: the table is read once per 64 steps in a cold region at
+  // the loop top, where no tile load is in flight.  Thresholds only decrease, so a cleared bit stays clear.
   int win_base = 0;
   float win_lb = 0.0f;
-  unsigned long long win_mask = 0;
+  unsigned long long win_rem = 0, my_live = ~0ull;
   auto load_window = [&](int base) __attribute__((always_inline)) {
     const int ss = base + lane;
     win_base = base;
-    win_lb = ss < n_scan ? my_lb[tile_of(ss)] : INFINITY;
-    win_mask = __ballot(ss < n_scan);
+    win_lb = ss < n_scan ? __half2float(my_lb[tile_of(ss)]) : INFINITY;
+    win_rem = __ballot(ss < n_scan);
     asm volatile("" : "+v"(win_lb));
   };
   if (my_lb) {
     load_window(0);
-    win_mask &= ~1ull;  // step 0 is the first tile
+    win_rem &= ~1ull;  // step 0 is the first tile
   }
+  auto lds_union = [&](int buf) __attribute__((always_inline)) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int w = 0; w < K16_NWAVE; ++w) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&lds_wlive[buf][w]);
+      lo |= v.x;
+      hi |= v.y;
+    }
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+  };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   float4 p0, p1, p2, p3, p4, p5, p6, p7, p8;
@@ -459,11 +506,13 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
     int m0, m1;
     float rcut = INFINITY, err = 0.0f;
+    const int knn1 = K16_COLD(knn1);
     if (knn1 > 0) {  // search-error allowance of this row, scaled units (refine.hip's E, rounded up)
-      const float nmax_s = norm2_max[0] * scale_info[0] * scale_info[0];
-      err = (err_c * nmax_s + err_l * sqrtf(__shfl(g ? nq[1] : nq[0], j, 64) * nmax_s)) * 1.001f;
+      const float* sinfo = K16_COLD(scale_info);
+      const float nmax_s = K16_COLD(norm2_max)[0] * sinfo[0] * sinfo[0];
+      err = (K16_COLD(err_c) * nmax_s + K16_COLD(err_l) * sqrtf(__shfl(g ? nq[1] : nq[0], j, 64) * nmax_s)) * 1.001f;
     }
-    float nt = knn16_squeeze_row(n0, n1, half, ksel, knn1, rf2, err, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1, &rcut);
+    float nt = knn16_squeeze_row(n0, n1, half, ksel, knn1, K16_COLD(rf2), err, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1, &rcut);
     if (m0 > half - 32) {
       // pathological ties at the threshold: rank the row down to exactly ksel entries
       knn16_rank_row(m0, m1, half, ksel, 1.0f, (min(m0 + m1, ksel) + 1) >> 1, cand_d2 + ro, cand_idx + ro, lds_sd[wave],
@@ -479,7 +528,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       if (g) cnt[1] = mine; else cnt[0] = mine;
       // list threshold (the ksel-th smallest once the row has ksel entries) or the radius cut, whichever is
       // lower: the row holds every reference seen so far whose d2 is below it
-      const float t_list = (n0 + n1 >= ksel) ? nt : thr_start(g);
+      // (a row shorter than ksel keeps its threshold -- the start value -- unless the radius cut lowers it)
+      const float t_list = (n0 + n1 >= ksel) ? nt : INFINITY;
       thrp[g] = fminf(thrp[g], fminf(t_list, rcut) - nq[g]);
     }
     // every load of this cold region has landed when it ends: a result still pending at the join with
@@ -592,46 +642,65 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   int s_cur = 0;
   int cur = 0;
   int par = 0;
+  int it = 0;             // tiles the workgroup has staged so far
+  int n_done = 0;         // tiles this wave has taken part in
+  bool live_cur = true;   // does this wave take part in the current tile
+  bool pend = false;      // accB holds a block that has not been voted on yet
   int t_cur = tile_of(0);
   while (s_cur < n_scan) {
-    // block-uniform bound: every wave reads the values published before the last barrier
-    float bound = 0.0f;
-    if (my_lb) {
-      bound = lds_wthr[par][0];
-#pragma unroll
-      for (int w = 1; w < K16_NWAVE; ++w) bound = fmaxf(bound, lds_wthr[par][w]);
-      bound += prune_margin;
-    }
     int s_next = s_cur + 1;
+    bool live_next = true;  // does this wave take part in step s_next
     if (my_lb) {
-      unsigned long long live = win_mask & __ballot(win_lb <= bound);
-      if (__builtin_expect(live == 0, 0)) {
-        while (live == 0 && win_base + 64 < n_scan) {
+      // union of the masks the waves published before the last barrier (readfirstlane: the compiler cannot
+      // see that an LDS value is wave-uniform and would do the mask arithmetic in vector registers)
+      unsigned long long any = lds_union(par) & win_rem;
+      if (__builtin_expect(any == 0, 0)) {
+        // nothing left in this window for any wave: move on (every wave takes this branch together)
+        while (any == 0 && win_base + 64 < n_scan) {
           load_window(win_base + 64);
-          live = win_mask & __ballot(win_lb <= bound);
+          my_live = __ballot(win_lb <= wmax + prune_margin);
+          if (lane == 0) lds_wlive[2][wave] = my_live;
+          __syncthreads();
+          any = lds_union(2) & win_rem;
+          __syncthreads();
         }
         K16_COLD_REGION_END();
       }
-      s_next = live ? win_base + (int)__ffsll((long long)live) - 1 : n_scan;
-      win_mask = live & (live - 1);  // (the bound only decreases: a step that fails now fails later)
+      if (any) {
+        const int i = (int)__ffsll((long long)any) - 1;
+        s_next = win_base + i;
+        live_next = (my_live >> i) & 1ull;
+        win_rem &= ~((2ull << i) - 1ull);
+      } else {
+        s_next = n_scan;
+      }
     }
     // The tile index of the NEXT step is computed before its loads are issued and carried to the next
     // iteration: no control flow may sit between the loads and the first pipeline segment (at such a join
     // the compiler waits for all outstanding loads -- the ones just issued -- on every iteration).
-    if (ABL == 2) ++st_vis;
     const int t = t_cur;
     const int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
     t_cur = t_next;
     if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
       K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next));
     }
-    // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
-    segment(cur, 0, accA0, accA1, accB0, accB1, refB, true);
-    // sub-tile 1 on the pipe while sub-tile 0 is voted on
-    segment(cur, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
-    refB = t * K16_TS + 32 + 4 * h;
+    if (live_cur) {
+      // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
+      segment(cur, 0, accA0, accA1, accB0, accB1, refB, true);
+      // sub-tile 1 on the pipe while sub-tile 0 is voted on
+      segment(cur, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
+      refB = t * K16_TS + 32 + 4 * h;
+      pend = true;
+      ++n_done;
+    } else if (pend) {
+      // this wave sits the tile out (pruned for its 64 queries): only the vote it still owes
+      segment(0, 0, accA0, accA1, accB0, accB1, refB, false);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = INFINITY;
+      pend = false;
+    }
 
-    if (batch_every > 0 && (s_cur & (batch_every - 1)) == batch_every - 1) {
+    if (batch_every > 0 && (it & (batch_every - 1)) == batch_every - 1) {
       // (Placed here, in front of the staging store whose vmcnt(0) wait follows anyway: a cold region with
       // memory operations in front of a pipeline segment makes the compiler wait for ALL outstanding loads at
       // the join -- the tile loads just issued -- on every iteration.)
@@ -639,7 +708,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       // barrier per tile, so a compaction at a random moment in one wave stalls all four; done
       // together the stalls overlap): every row that has gathered more than batch_slack entries beyond
       // ksel.  Fresher thresholds also mean fewer candidates that cannot survive.
-      const int limit = ksel + batch_slack;
+      const int limit = ksel + K16_COLD(batch_slack);
       unsigned long long todo = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -660,20 +729,30 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     }
 
     if (s_next < n_scan && ABL != 9) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
-    if (my_lb && lane == 0) lds_wthr[par ^ 1][wave] = wmax;
+    if (my_lb) {
+      my_live = __ballot(win_lb <= wmax + prune_margin);
+      if (lane == 0) lds_wlive[par ^ 1][wave] = my_live;
+    }
     if (ABL != 4 || (s_cur & 1)) __syncthreads();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
     s_cur = s_next;
+    live_cur = live_next;
     cur ^= 1;
     par ^= 1;
+    ++it;
   }
-  segment(0, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
+  if (pend) segment(0, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
+  {
+    unsigned long long* tiles_done = K16_COLD(tiles_done);
+    if (tiles_done && lane == 0) atomicAdd(tiles_done, (unsigned long long)n_done);
+  }
 
+  unsigned long long* stats = ABL == 2 ? K16_COLD(stats) : nullptr;
   if (ABL == 2 && stats) {  // profiling counters requested (MELD_KNN16_STATS): wave-blocks, slow-path entries, appends, compactions
     unsigned a = st_app;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
     if (lane == 0) {
-      atomicAdd(stats + 0, (unsigned long long)(2 * st_vis));
+      atomicAdd(stats + 0, (unsigned long long)(2 * n_done));
       atomicAdd(stats + 1, (unsigned long long)st_slow);
       atomicAdd(stats + 2, (unsigned long long)a);
       atomicAdd(stats + 3, (unsigned long long)st_sq);
@@ -681,7 +760,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   }
   // final: sort every row, convert back to input units, publish its length and its threshold (the row
   // holds every reference whose approximate d2 is below it)
-  const float out_scale = scale_info[1];  // 1 / s^2
+  const float out_scale = K16_COLD(scale_info)[1];  // 1 / s^2
+  float* cand_thr = K16_COLD(cand_thr);
+  int* cand_cnt = K16_COLD(cand_cnt);
   if (cand_thr && h == 0) {
     cand_thr[row_base + jq] = (thrp[0] + nq[0]) * out_scale;
     cand_thr[row_base + 32 + jq] = (thrp[1] + nq[1]) * out_scale;
@@ -827,8 +908,8 @@ __global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* 
                                                                 int first_tile, int n_blocks, float err_coef,
                                                                 const float* __restrict__ norm2_max,
                                                                 const float* __restrict__ scale_info,
-                                                                float* __restrict__ lb2) {
-  constexpr int TPB = K16_BQ / K16_TS;  // reference tiles per query workgroup
+                                                                __half* __restrict__ lb2) {
+  constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
   constexpr int NS = (HV + 255) / 256;
   __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
@@ -898,7 +979,8 @@ __global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* 
         const float v = fminf(m[g], __shfl_xor(m[g], 32, 64)) + cn[g];  // min_p |p - c|^2, approximate
         const float dist = sqrtf(fmaxf(v - err_abs, 0.0f)) * 0.9999f - cr[g];
         const int c = c_base + g * 32 + jq;
-        if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = dist > 0.0f ? dist * dist : 0.0f;
+        // (fp16, rounded towards zero: a smaller bound only prunes less)
+        if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = __float2half_rz(dist > 0.0f ? fminf(dist * dist, 60000.0f) : 0.0f);
         m[g] = INFINITY;
       }
     }
@@ -1114,7 +1196,7 @@ extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const 
 }
 
 extern "C" size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count) {
-  return (size_t)ceil_div(q_count, K16_BQ) * (size_t)ceil_div(n_ref, K16_TS) * sizeof(float);
+  return (size_t)ceil_div(q_count, K16_BQ) * K16_NWAVE * (size_t)ceil_div(n_ref, K16_TS) * sizeof(__half);
 }
 extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count) {
   (void)q_count;
@@ -1126,14 +1208,14 @@ extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_c
 
 extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                                  const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count, void* temp,
-                                 float* lb2, meld_stream_t stream) {
+                                 void* lb2, meld_stream_t stream) {
   MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 &&
                      q_begin + q_count <= N,
                  "meld_knn16_bounds: bad arguments");
   MELD_CHECK_ARG(q_begin % K16_TS == 0, "meld_knn16_bounds: q_begin must be a multiple of the reference tile (64 cells)");
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
-  const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(q_count, K16_BQ);
+  const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(q_count, K16_BQ) * K16_NWAVE;  // table rows = waves
   const size_t n_c = (size_t)ceil_div(n_t, 256) * 256;
   hipStream_t st = S(stream);
   _Float16* c16 = reinterpret_cast<_Float16*>(temp);
@@ -1148,7 +1230,7 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   case KBV:                                                                                                               \
     hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV>), dim3(gx, gy), dim3(256), 0, st, c16, cn, cr,                      \
                        reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,         \
-                       scale_info, lb2);                                                                                  \
+                       scale_info, reinterpret_cast<__half*>(lb2));                                                       \
     break;
   switch (KB) {
     K16_BOUNDS_CASE(1)
@@ -1171,10 +1253,10 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 
 extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                                int64_t n_ref, int d,
-                               int64_t q_count, int ksel, int nprod, int n_slices, const float* lb2,
+                               int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
                                const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
                                double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                               float* cand_thr, meld_stream_t stream) {
+                               float* cand_thr, uint64_t* tiles_done, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
@@ -1222,11 +1304,35 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     MELD_HIP_CALL(hipMemsetAsync(counters[dev], 0, 256, S(stream)));
     stats = counters[dev];
   }
-#define K16_LAUNCH2(KBV, ABLV, NP)                                                                             \
-  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), q, Qn, r,  \
-                     scale_info, (int)n_ref, n_tiles, ksel, cap, lb2, norm2_max, (float)meld_knn16_error_coef(nprod), \
-                     tile_origin, batch_every, batch_slack, two_sided, stats, thr_init, knn1, rf2, err_c, err_l, cand_idx, cand_d2, \
-                     cand_cnt, cand_thr)
+  K16Args ka;
+  ka.Q16 = q;
+  ka.Qn = Qn;
+  ka.Rt16 = r;
+  ka.scale_info = scale_info;
+  ka.n_ref = (int)n_ref;
+  ka.n_tiles = n_tiles;
+  ka.ksel = ksel;
+  ka.cap = cap;
+  ka.lb2 = reinterpret_cast<const __half*>(lb2);
+  ka.norm2_max = norm2_max;
+  ka.err_coef = (float)meld_knn16_error_coef(nprod);
+  ka.tile_origin = tile_origin;
+  ka.batch_every = batch_every;
+  ka.batch_slack = batch_slack;
+  ka.two_sided = two_sided;
+  ka.stats = stats;
+  ka.thr_init = thr_init;
+  ka.knn1 = knn1;
+  ka.rf2 = rf2;
+  ka.err_c = err_c;
+  ka.err_l = err_l;
+  ka.cand_idx = cand_idx;
+  ka.cand_d2 = cand_d2;
+  ka.cand_cnt = cand_cnt;
+  ka.cand_thr = cand_thr;
+  ka.tiles_done = reinterpret_cast<unsigned long long*>(tiles_done);
+#define K16_LAUNCH2(KBV, ABLV, NP) \
+  hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka)
 #define K16_LAUNCH(KBV, ABLV)        \
   do {                               \
     if (nprod == 1)                  \

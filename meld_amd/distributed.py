@@ -76,6 +76,7 @@ class Comm:
 def shard_range(N, world, rank):
     """(rows_per_rank R, first row, number of real rows) of a rank."""
     R = (N + world - 1) // world
+    R = ((R + 255) // 256) * 256  # whole search workgroups: tile-aligned shards keep the pruning tables usable
     begin = min(rank * R, N)
     end = min(begin + R, N)
     return R, begin, end - begin

@@ -284,7 +284,7 @@ class HipOps:
         norm2 = torch.empty(N, dtype=torch.float32, device=dev)
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
-        cand_thr, rfac = None, 1.0
+        cand_thr, rfac, tiles_done = None, 1.0, None
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if search == "wide":
@@ -358,10 +358,11 @@ class HipOps:
                 cand_thr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
             lb2 = None
+            tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
             if self.prune and q_begin % TS == 0 and N >= 16384:
                 tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
                 tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
-                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count) // 4, dtype=torch.float32, device=dev)
+                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 tm.stop("bounds")
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
@@ -379,7 +380,7 @@ class HipOps:
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main
@@ -387,7 +388,7 @@ class HipOps:
                     t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
                     t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
                     t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             del lb2
@@ -479,7 +480,7 @@ class HipOps:
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, None, st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
@@ -550,7 +551,9 @@ class HipOps:
         tm.stop("coo_emit")
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
-                    n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M)
+                    n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
+                    # (wave, tile) pairs the first search pass computed (all of them without pruning)
+                    wave_tiles_done=int(tiles_done.item()) if tiles_done is not None else None)
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------

@@ -48,7 +48,8 @@ def test_sharded_fit_transform_equals_oracle(world, n, n_labels, tmp_path):
     W = sparse.vstack([
         sparse.csr_matrix((r["val"], r["col"], r["rowptr"][: int(r["n_rows"]) + 1]), shape=(int(r["n_rows"]), n)) for r in ranks
     ]).tocsr()
-    assert [int(r["row_begin"]) for r in ranks] == [i * (-(-n // world)) for i in range(world)]
+    per_rank = -(-(-(-n // world)) // 256) * 256  # shards are whole search workgroups (256 rows)
+    assert [int(r["row_begin"]) for r in ranks] == [min(i * per_rank, n) for i in range(world)]
     assert W.nnz == G.W.nnz == int(ranks[0]["nnz_global"])
     assert abs(W - G.W).max() < 1e-13
     np.testing.assert_allclose(np.concatenate([r["dw"][: int(r["n_rows"])] for r in ranks]), G.dw, rtol=1e-12)

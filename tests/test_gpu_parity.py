@@ -299,7 +299,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -410,7 +410,7 @@ def test_two_ranks_on_one_gpu(tmp_path):
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
     ref = single.fit_transform(X, labels)
-    assert [int(r["row_begin"]) for r in ranks] == [0, (n + 1) // 2]
+    assert [int(r["row_begin"]) for r in ranks] == [0, -(-((n + 1) // 2) // 256) * 256]  # shards = whole search workgroups
     assert int(ranks[0]["nnz_global"]) == single.graph.nnz
     assert bool(ranks[0]["device_resident"])  # the phase-wise Lanczos ran, not the host loop
     for r in ranks:
@@ -466,6 +466,33 @@ def test_tile_pruning_is_exact():
                     assert torch.equal(a, b)
 
 
+def test_pruned_search_on_shard_ranges():
+    """A rank of the sharded driver searches a tile-aligned query range against all references with its own
+    slice of the pruning table: same rows as the unpruned full-range search (ragged last range included)."""
+    from meld_amd.graph import HipOps
+    from meld_amd.reorder import locality_permutation
+
+    mo = _oracle()
+    N = 40000
+    X, _ = mo.synthetic_cells(N, n_dims=50, seed=33)
+    Xd = torch.from_numpy(X).cuda()
+    Xd = Xd.index_select(0, locality_permutation(Xd)).contiguous()
+    plain = HipOps(prune=False)
+    plain.radius_cut = False
+    keys, vals, bw, _ = plain.directed_kernel_coo(Xd, 0, N, 15, 40, 1e-4, 64)
+    M = keys.shape[0] // 2
+    full = dict(zip(keys[:M].tolist(), vals[:M].tolist()))
+    ops = HipOps(prune=True)
+    got = {}
+    for r0, n in ((0, 13568), (13568, 13568), (27136, N - 27136)):
+        k, v, b, info = ops.directed_kernel_coo(Xd, r0, n, 15, 40, 1e-4, 64)
+        m = k.shape[0] // 2
+        assert torch.equal(b, bw[r0 : r0 + n])
+        assert info["wave_tiles_done"] < 0.9 * ((n + 63) // 64) * ((N + 63) // 64)  # tiles really were skipped
+        got.update(zip(k[:m].tolist(), v[:m].tolist()))
+    assert got == full
+
+
 def test_knn16_reference_slices_merge_to_the_same_rows():
     """Cutting the references into slices + meld_knn16_merge_slices == one full scan."""
     mo = _oracle()
@@ -501,7 +528,7 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
         cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
         cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
-        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, st))
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, st))
         if S > 1:
             mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
             md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")

@@ -22,7 +22,7 @@ tmpb = torch.empty(lib.meld_knn16_bounds_temp_bytes(N, d, N), dtype=torch.uint8,
 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, N) // 4, dtype=torch.float32, device="cuda")
 check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), 0, N, ptr(tmpb), ptr(lb2), st))
 ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 3, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, st))
+check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 3, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, st))
 torch.cuda.synchronize()
 s = float(sinfo[0]); 
 thr = cd.view(q_pad, cap)[:N, ksel - 1] * s * s          # final 64th d2 in scaled units
