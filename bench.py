@@ -222,9 +222,9 @@ def main():
             "unit": "TFLOP/s",
             "frac": flops / t_knn / 1e12 / peak,
             "traffic": None,
-            "traffic_note": "not collected in this run (PMC needs its own rocprofv3 pass); profiles/pmc/r01_knn16_pmc_summary.txt: "
-            "TCC_EA0_RDREQ 3.62e9 x 64 B x 2 = 464 GB fabric-side reads per launch at 1M cells (0.26 GB compulsory: every "
-            "workgroup streams the whole reference set)",
+            "traffic_note": "not collected in this run (PMC needs its own rocprofv3 pass); profiles/pmc/r01_knn16_pruned_pmc_summary.txt: "
+            "TCC_EA0_RDREQ 1.64e9 x 64 B x 2 = 210 GB fabric-side reads per launch at 1M cells with pruning (464 GB without; "
+            "0.13 GB compulsory: every workgroup streams the reference tiles it cannot rule out)",
             "algorithmic": "2*Nq*N*d = {:.3e} flop per launch".format(flops),
             "executed_tflops": executed / t_knn / 1e12,
             "executed_frac_of_peak": executed / t_knn / 1e12 / peak,

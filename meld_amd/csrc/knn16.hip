@@ -284,7 +284,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // |r|^2 - 2 q.r directly and no norm is read in the loop
   constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
   constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
-  __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][TILE_H];
+  constexpr int LDS_TILE_H = (NPROD == 3) ? TILE_H : TILE_H / 2;  // (the hi-only search keeps just the hi planes in LDS)
+  __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][LDS_TILE_H];
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
   __shared__ unsigned long long lds_wlive[3][K16_NWAVE];  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch
@@ -430,15 +431,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   } while (0)
 #define K16_STORE(DST)                                                                      \
   do {                                                                                      \
-    if constexpr (NS > 0) if (K16_ROUND_OK(0)) (DST)[stage_off + 0 * STAGE_STRIDE] = p0;    \
-    if constexpr (NS > 1) if (K16_ROUND_OK(1)) (DST)[stage_off + 1 * STAGE_STRIDE] = p1;    \
-    if constexpr (NS > 2) if (K16_ROUND_OK(2)) (DST)[stage_off + 2 * STAGE_STRIDE] = p2;    \
-    if constexpr (NS > 3) if (K16_ROUND_OK(3)) (DST)[stage_off + 3 * STAGE_STRIDE] = p3;    \
-    if constexpr (NS > 4) if (K16_ROUND_OK(4)) (DST)[stage_off + 4 * STAGE_STRIDE] = p4;    \
-    if constexpr (NS > 5) if (K16_ROUND_OK(5)) (DST)[stage_off + 5 * STAGE_STRIDE] = p5;    \
-    if constexpr (NS > 6) if (K16_ROUND_OK(6)) (DST)[stage_off + 6 * STAGE_STRIDE] = p6;    \
-    if constexpr (NS > 7) if (K16_ROUND_OK(7)) (DST)[stage_off + 7 * STAGE_STRIDE] = p7;    \
-    if constexpr (NS > 8) if (K16_ROUND_OK(8)) (DST)[stage_off + 8 * STAGE_STRIDE] = p8;    \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) (DST)[tid + 0 * K16_THREADS] = p0;    \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) (DST)[tid + 1 * K16_THREADS] = p1;    \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) (DST)[tid + 2 * K16_THREADS] = p2;    \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) (DST)[tid + 3 * K16_THREADS] = p3;    \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) (DST)[tid + 4 * K16_THREADS] = p4;    \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) (DST)[tid + 5 * K16_THREADS] = p5;    \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) (DST)[tid + 6 * K16_THREADS] = p6;    \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) (DST)[tid + 7 * K16_THREADS] = p7;    \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) (DST)[tid + 8 * K16_THREADS] = p8;    \
   } while (0)
   K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)));
   K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
@@ -480,9 +481,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[buf]) + sub * 32 + jq;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      // hi parts alone (NPROD == 1, error <= 2^-9 |x~||y~|, see meld_knn16_error_coef) or the
-      // full hi/lo split
-      const f16x8 ahi = a8[((kb * 2 + h) * 2 + 0) * K16_TS];
+      // hi parts alone (NPROD == 1, error <= 2^-9 |x~||y~|, see meld_knn16_error_coef; LDS layout
+      // [kb][h][ref]) or the full hi/lo split (LDS layout = tile layout [kb][h][plane][ref])
+      const f16x8 ahi = NPROD == 3 ? a8[((kb * 2 + h) * 2 + 0) * K16_TS] : a8[(kb * 2 + h) * K16_TS];
       c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
       if (NPROD == 3) {
@@ -639,6 +640,42 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     if (__any(hit)) select(c0, c1, m0, m1, ref_base);
   };
 
+  // Which step follows `after`: the first one of the pruning window that some wave of the workgroup still
+  // needs (union of the masks the waves published before the last barrier; readfirstlane because the compiler
+  // cannot see that an LDS value is wave-uniform and would do the mask arithmetic in vector registers).
+  // Sets *live to whether THIS wave takes part in it.
+  auto next_step = [&](int after, int par_, bool* live) __attribute__((always_inline)) {
+    if (!my_lb) {
+      *live = true;
+      return after + 1;
+    }
+    unsigned long long any = lds_union(par_) & win_rem;
+    if (__builtin_expect(any == 0, 0)) {
+      // nothing left in this window for any wave: move on (every wave takes this branch together)
+      while (any == 0 && win_base + 64 < n_scan) {
+        load_window(win_base + 64);
+        my_live = __ballot(win_lb <= wmax + prune_margin);
+        if (lane == 0) lds_wlive[2][wave] = my_live;
+        __syncthreads();
+        any = lds_union(2) & win_rem;
+        __syncthreads();
+      }
+      K16_COLD_REGION_END();
+    }
+    if (any == 0) {
+      *live = false;
+      return n_scan;
+    }
+    const int i = (int)__ffsll((long long)any) - 1;
+    *live = (my_live >> i) & 1ull;
+    win_rem &= ~((2ull << i) - 1ull);
+    return win_base + i;
+  };
+
+  // The control flow runs one step ahead of the data: at the top of an iteration the next step (s_next,
+  // chosen during the previous iteration) is already known, so its tile loads go out at once and the
+  // LDS round trip + scalar work that picks the step after it overlaps with the MFMA segments instead of
+  // sitting in front of the loads.
   int s_cur = 0;
   int cur = 0;
   int par = 0;
@@ -647,40 +684,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   bool live_cur = true;   // does this wave take part in the current tile
   bool pend = false;      // accB holds a block that has not been voted on yet
   int t_cur = tile_of(0);
+  bool live_next = true;
+  int s_next = next_step(0, 0, &live_next);
+  int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
   while (s_cur < n_scan) {
-    int s_next = s_cur + 1;
-    bool live_next = true;  // does this wave take part in step s_next
-    if (my_lb) {
-      // union of the masks the waves published before the last barrier (readfirstlane: the compiler cannot
-      // see that an LDS value is wave-uniform and would do the mask arithmetic in vector registers)
-      unsigned long long any = lds_union(par) & win_rem;
-      if (__builtin_expect(any == 0, 0)) {
-        // nothing left in this window for any wave: move on (every wave takes this branch together)
-        while (any == 0 && win_base + 64 < n_scan) {
-          load_window(win_base + 64);
-          my_live = __ballot(win_lb <= wmax + prune_margin);
-          if (lane == 0) lds_wlive[2][wave] = my_live;
-          __syncthreads();
-          any = lds_union(2) & win_rem;
-          __syncthreads();
-        }
-        K16_COLD_REGION_END();
-      }
-      if (any) {
-        const int i = (int)__ffsll((long long)any) - 1;
-        s_next = win_base + i;
-        live_next = (my_live >> i) & 1ull;
-        win_rem &= ~((2ull << i) - 1ull);
-      } else {
-        s_next = n_scan;
-      }
-    }
-    // The tile index of the NEXT step is computed before its loads are issued and carried to the next
-    // iteration: no control flow may sit between the loads and the first pipeline segment (at such a join
-    // the compiler waits for all outstanding loads -- the ones just issued -- on every iteration).
     const int t = t_cur;
-    const int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
-    t_cur = t_next;
     if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
       K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next));
     }
@@ -728,6 +736,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       }
     }
 
+    // the step after s_next (masks published before the last barrier; the window may move on here)
+    bool live_nn = true;
+    const int s_nn = s_next < n_scan ? next_step(s_next, par, &live_nn) : n_scan;
+    const int t_nn = s_nn < n_scan ? tile_of(s_nn) : t_next;
+
     if (s_next < n_scan && ABL != 9) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
     if (my_lb) {
       my_live = __ballot(win_lb <= wmax + prune_margin);
@@ -735,7 +748,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     }
     if (ABL != 4 || (s_cur & 1)) __syncthreads();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
     s_cur = s_next;
+    t_cur = t_next;
     live_cur = live_next;
+    s_next = s_nn;
+    t_next = t_nn;
+    live_next = live_nn;
     cur ^= 1;
     par ^= 1;
     ++it;
@@ -756,6 +773,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       atomicAdd(stats + 1, (unsigned long long)st_slow);
       atomicAdd(stats + 2, (unsigned long long)a);
       atomicAdd(stats + 3, (unsigned long long)st_sq);
+      if (wave == 0) atomicAdd(stats + 4, (unsigned long long)it);
     }
   }
   // final: sort every row, convert back to input units, publish its length and its threshold (the row
@@ -1378,11 +1396,12 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
 #undef K16_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_topk_kernel");
   if (stats) {
-    unsigned long long st[4] = {0, 0, 0, 0};
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
     MELD_HIP_CALL(hipStreamSynchronize(S(stream)));
     MELD_HIP_CALL(hipMemcpy(st, stats, sizeof(st), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu\n",
-            st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3]);
+    fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu  tiles staged %llu (%.1f %% of workgroups x tiles)\n",
+            st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3], st[4],
+            100.0 * (double)st[4] / ((double)grid.x * (double)grid.y * (double)n_tiles / (double)grid.y));
   }
   return MELD_OK;
 }
