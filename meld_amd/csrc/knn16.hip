@@ -285,7 +285,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
   constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
   constexpr int LDS_TILE_H = (NPROD == 3) ? TILE_H : TILE_H / 2;  // (the hi-only search keeps just the hi planes in LDS)
-  __shared__ __attribute__((aligned(16))) _Float16 lds_tile[2][LDS_TILE_H];
+  // two separate arrays (and a scan loop unrolled by two, each copy reading one and filling the other): the
+  // LDS DMA of the next tile must be provably disjoint from the A-fragment reads of the current one, or the
+  // compiler's wait-count pass guards every ds_read with s_waitcnt vmcnt(0) -- i.e. waits for the tile it has
+  // just requested before touching the one it has
+  __shared__ __attribute__((aligned(16))) _Float16 lds_tile0[LDS_TILE_H];
+  __shared__ __attribute__((aligned(16))) _Float16 lds_tile1[LDS_TILE_H];
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
   __shared__ unsigned long long lds_wlive[3][K16_NWAVE];  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch
@@ -390,59 +395,45 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
-  float4 p0, p1, p2, p3, p4, p5, p6, p7, p8;
-  p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // Staging through registers, every thread the same number of 16-byte vectors.  NPROD == 3 copies the
-  // whole tile (vector tid + 256 u).  NPROD == 1 never reads the lo planes, so only the hi vectors are
-  // copied: the j-th of them, j = tid + 256 u, sits at ((j >> 6) << 7) + (j & 63) (one 64-vector plane
-  // out of every 128) -- half the staging traffic and no per-wave predication.
+  // Staging: global -> LDS directly (`buffer_load_dwordx4 ... lds`, gfx950's 16-byte LDS DMA): lane l of a wave
+  // writes LDS slot M0-base + 16 l, so a wave copies 64 consecutive LDS vectors per instruction from per-lane
+  // global offsets; no staging registers (8 VGPRs at d = 50 that now hold A fragments in flight), no ds_write,
+  // and the data never passes through the VALU.  NPROD == 3 copies the whole tile (vector tid + 256 u).
+  // NPROD == 1 never reads the lo planes, so only the hi vectors are copied: the j-th of them,
+  // j = tid + 256 u, sits at ((j >> 6) << 7) + (j & 63) in the tile (one 64-vector plane out of every 128)
+  // and lands at LDS slot j -- half the staging traffic and half the LDS.
   constexpr int N_STAGE = (NPROD == 3) ? KB * 256 : KB * 128;           // vectors to copy per tile
   constexpr int NS = (N_STAGE + K16_THREADS - 1) / K16_THREADS;         // rounds
   constexpr bool STAGE_TAIL = (N_STAGE % K16_THREADS) != 0;             // last round half empty (odd KB, NPROD == 1)
-  static_assert(NS <= 9, "tile too large for the staging registers");
+  static_assert(NS <= 9, "tile too large for the staging rounds");
   const int stage_off = (NPROD == 3) ? tid : (((tid >> 6) << 7) + (tid & 63));
   constexpr int STAGE_STRIDE = (NPROD == 3) ? K16_THREADS : 2 * K16_THREADS;  // offset step per round
-  const bool stage_last = !STAGE_TAIL || tid < (N_STAGE % K16_THREADS);
+  const bool stage_last = !STAGE_TAIL || wave < (N_STAGE % K16_THREADS) / 64;  // (wave-uniform)
 #define K16_ROUND_OK(U) ((U) + 1 < NS || stage_last)
-  // Tile loads are raw buffer loads: the descriptor (SGPRs) carries the tile base, the per-thread offset is
-  // one loop-invariant VGPR and the round offset an immediate/SGPR.  With flat global addressing the
-  // compiler materialises a 64-bit VGPR address per load and iteration, recycles those registers as
-  // A-fragment destinations and then guards the first ds_read of the iteration with s_waitcnt vmcnt(0) --
-  // i.e. waits for the loads it has just issued (measured: 134 -> 151 ms).
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  // The descriptor (SGPRs) carries the tile base, the per-thread offset is one loop-invariant VGPR and the
+  // round offset an SGPR.
   const int stage_voff = stage_off * 16;
-  auto as_f4 = [](u32x4 v) __attribute__((always_inline)) {
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-  };
-#define K16_BLOAD(U) as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsrc, stage_voff, (U) * STAGE_STRIDE * 16, 0))
-#define K16_LOAD(TILE)                                                                                             \
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define K16_DMA(U, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)((DST) + wave * 64 + (U) * K16_THREADS), 16, stage_voff, (U) * STAGE_STRIDE * 16, 0, 0)
+#define K16_LOAD(TILE, DST)                                                                                        \
   do {                                                                                                             \
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                         \
         const_cast<float4*>(R4 + (size_t)(TILE) * TILE_V4), 0, TILE_V4 * 16, 0x00020000);                          \
-    if constexpr (NS > 0) if (K16_ROUND_OK(0)) p0 = K16_BLOAD(0);                                                  \
-    if constexpr (NS > 1) if (K16_ROUND_OK(1)) p1 = K16_BLOAD(1);                                                  \
-    if constexpr (NS > 2) if (K16_ROUND_OK(2)) p2 = K16_BLOAD(2);                                                  \
-    if constexpr (NS > 3) if (K16_ROUND_OK(3)) p3 = K16_BLOAD(3);                                                  \
-    if constexpr (NS > 4) if (K16_ROUND_OK(4)) p4 = K16_BLOAD(4);                                                  \
-    if constexpr (NS > 5) if (K16_ROUND_OK(5)) p5 = K16_BLOAD(5);                                                  \
-    if constexpr (NS > 6) if (K16_ROUND_OK(6)) p6 = K16_BLOAD(6);                                                  \
-    if constexpr (NS > 7) if (K16_ROUND_OK(7)) p7 = K16_BLOAD(7);                                                  \
-    if constexpr (NS > 8) if (K16_ROUND_OK(8)) p8 = K16_BLOAD(8);                                                  \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) K16_DMA(0, DST);                                                    \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) K16_DMA(1, DST);                                                    \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) K16_DMA(2, DST);                                                    \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) K16_DMA(3, DST);                                                    \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) K16_DMA(4, DST);                                                    \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) K16_DMA(5, DST);                                                    \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) K16_DMA(6, DST);                                                    \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) K16_DMA(7, DST);                                                    \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) K16_DMA(8, DST);                                                    \
   } while (0)
-#define K16_STORE(DST)                                                                      \
-  do {                                                                                      \
-    if constexpr (NS > 0) if (K16_ROUND_OK(0)) (DST)[tid + 0 * K16_THREADS] = p0;    \
-    if constexpr (NS > 1) if (K16_ROUND_OK(1)) (DST)[tid + 1 * K16_THREADS] = p1;    \
-    if constexpr (NS > 2) if (K16_ROUND_OK(2)) (DST)[tid + 2 * K16_THREADS] = p2;    \
-    if constexpr (NS > 3) if (K16_ROUND_OK(3)) (DST)[tid + 3 * K16_THREADS] = p3;    \
-    if constexpr (NS > 4) if (K16_ROUND_OK(4)) (DST)[tid + 4 * K16_THREADS] = p4;    \
-    if constexpr (NS > 5) if (K16_ROUND_OK(5)) (DST)[tid + 5 * K16_THREADS] = p5;    \
-    if constexpr (NS > 6) if (K16_ROUND_OK(6)) (DST)[tid + 6 * K16_THREADS] = p6;    \
-    if constexpr (NS > 7) if (K16_ROUND_OK(7)) (DST)[tid + 7 * K16_THREADS] = p7;    \
-    if constexpr (NS > 8) if (K16_ROUND_OK(8)) (DST)[tid + 8 * K16_THREADS] = p8;    \
-  } while (0)
-  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)));
-  K16_STORE(reinterpret_cast<float4*>(lds_tile[0]));
+  // the copies of this wave have landed in LDS (then the tile barrier makes them visible to the others)
+#define K16_STAGED() __builtin_amdgcn_s_waitcnt(0x0F70)
+  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)), reinterpret_cast<float4*>(lds_tile0));
+  K16_STAGED();
   __syncthreads();
 
   // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
@@ -472,13 +463,13 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = INFINITY;  // nothing to vote on before the first tile
   int refB = 0;
 
-  // |r|^2 - 2 q.r of sub-tile `sub` of the tile in lds_tile[buf] (the norm rides in K slots d .. d+2,
+  // |r|^2 - 2 q.r of sub-tile `sub` of the tile at `tile` (the norm rides in K slots d .. d+2,
   // |q|^2 is folded into the threshold: thrp = thr - |q|^2)
-  auto mfma_block = [&](int buf, int sub, f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
+  auto mfma_block = [&](const _Float16* tile, int sub, f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
     // tile layout [kb][h][plane][i][8 halves]: lane reads 16 B at ((kb*2+h)*2+plane)*TS + i
-    const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_tile[buf]) + sub * 32 + jq;
+    const f16x8* a8 = reinterpret_cast<const f16x8*>(tile) + sub * 32 + jq;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       // hi parts alone (NPROD == 1, error <= 2^-9 |x~||y~|, see meld_knn16_error_coef; LDS layout
@@ -622,9 +613,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
   // MFMAs of (buf, sub) into (n0, n1) interleaved with the vote on the finished block (c0, c1);
   // then the slow path if any lane of the finished block has a candidate
-  auto segment = [&](int buf, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
+  auto segment = [&](const _Float16* tile, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
                      __attribute__((always_inline)) {
-    if (issue) mfma_block(buf, sub, n0, n1);
+    if (issue) mfma_block(tile, sub, n0, n1);
     if (ABL == 3 || ABL == 4 || ABL == 8 || ABL == 9) {  // profiling ablation: MFMAs only, accumulators kept live
       asm volatile("" ::"v"(c0[0]), "v"(c0[15]), "v"(c1[0]), "v"(c1[15]));
       return;
@@ -677,7 +668,6 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // LDS round trip + scalar work that picks the step after it overlaps with the MFMA segments instead of
   // sitting in front of the loads.
   int s_cur = 0;
-  int cur = 0;
   int par = 0;
   int it = 0;             // tiles the workgroup has staged so far
   int n_done = 0;         // tiles this wave has taken part in
@@ -687,22 +677,22 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   bool live_next = true;
   int s_next = next_step(0, 0, &live_next);
   int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
-  while (s_cur < n_scan) {
+  auto scan_step = [&](const _Float16* tile_r, _Float16* tile_w) __attribute__((always_inline)) {
     const int t = t_cur;
     if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
-      K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next));
+      K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), reinterpret_cast<float4*>(tile_w));
     }
     if (live_cur) {
       // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
-      segment(cur, 0, accA0, accA1, accB0, accB1, refB, true);
+      segment(tile_r, 0, accA0, accA1, accB0, accB1, refB, true);
       // sub-tile 1 on the pipe while sub-tile 0 is voted on
-      segment(cur, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
+      segment(tile_r, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
       refB = t * K16_TS + 32 + 4 * h;
       pend = true;
       ++n_done;
     } else if (pend) {
       // this wave sits the tile out (pruned for its 64 queries): only the vote it still owes
-      segment(0, 0, accA0, accA1, accB0, accB1, refB, false);
+      segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = INFINITY;
       pend = false;
@@ -741,7 +731,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const int s_nn = s_next < n_scan ? next_step(s_next, par, &live_nn) : n_scan;
     const int t_nn = s_nn < n_scan ? tile_of(s_nn) : t_next;
 
-    if (s_next < n_scan && ABL != 9) K16_STORE(reinterpret_cast<float4*>(lds_tile[cur ^ 1]));
+    if (s_next < n_scan && ABL != 9) K16_STAGED();
     if (my_lb) {
       my_live = __ballot(win_lb <= wmax + prune_margin);
       if (lane == 0) lds_wlive[par ^ 1][wave] = my_live;
@@ -753,11 +743,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     s_next = s_nn;
     t_next = t_nn;
     live_next = live_nn;
-    cur ^= 1;
     par ^= 1;
     ++it;
+  };
+  while (s_cur < n_scan) {
+    scan_step(lds_tile0, lds_tile1);
+    if (s_cur >= n_scan) break;
+    scan_step(lds_tile1, lds_tile0);
   }
-  if (pend) segment(0, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
+  if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
   {
     unsigned long long* tiles_done = K16_COLD(tiles_done);
     if (tiles_done && lane == 0) atomicAdd(tiles_done, (unsigned long long)n_done);
@@ -794,8 +788,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     if (lane == 0) cand_cnt[qr] = min(n0 + n1, ksel);
   }
 #undef K16_LOAD
-#undef K16_BLOAD
-#undef K16_STORE
+#undef K16_DMA
+#undef K16_STAGED
 #undef K16_ROUND_OK
 }
 
