@@ -114,7 +114,7 @@ class MELD(GraphEstimator):
 
         opts = dict(self.kwargs)
         opts.update(kwargs)
-        unsupported = [k for k in opts if k not in ("ksel", "profile")]
+        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx")]
         if unsupported:
             raise NotImplementedError(
                 "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
@@ -140,6 +140,16 @@ class MELD(GraphEstimator):
             self._log("Calculating PCA ({} components)...".format(self.n_pca))
             X = pca_project(X, self.n_pca, seed=42 if self.random_state is None else int(self.random_state))
             self.data_nu = X
+        if opts.get("sample_idx") is not None:
+            # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
+            if self.thresh == 0:
+                raise NotImplementedError("sample_idx (MNN graph) with thresh=0 is not implemented")
+            from .mnn import build_mnn_graph
+
+            return build_mnn_graph(
+                X, opts["sample_idx"], knn=self.knn, decay=float("inf") if self.decay is None else self.decay,
+                thresh=self.thresh, anisotropy=self.anisotropy, ksel=opts.get("ksel"),
+            )
         if self.thresh == 0:
             from .dense import build_dense_graph
 

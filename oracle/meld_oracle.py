@@ -393,12 +393,99 @@ def pca_reduce(X, n_pca, random_state=42, exact=True):
     return PCA(n_pca, svd_solver=solver, random_state=random_state).fit_transform(X)
 
 
-def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None):
+def kernel_to_data(Xq, Yref, knn=5, decay=40, thresh=1e-4, n_jobs=1, algorithm="ball_tree"):
+    """Alpha-decay kernel from the rows of ``Xq`` to the rows of ``Yref`` (CSR, len(Xq) x len(Yref)).
+
+    [UPSTREAM graphtools 1.5.x ``kNNGraph.build_kernel_to_data(Y, knn=knn)``] as ``MNNGraph.build_kernel``
+    calls it for two different samples: the queries are not among the references, so the bandwidth is the
+    distance to the knn-th nearest reference (``distances[:, knn - 1]``; the within-sample kernel uses
+    ``knn + 1`` because each point finds itself first), ``radius = bandwidth (-log thresh)^(1/decay)``,
+    ``K = exp(-(d / bandwidth)^decay)`` for every reference inside the radius (upstream re-searches rows whose
+    neighbour list ends inside the radius; restated here by its net effect, a radius query), values below
+    ``thresh`` dropped."""
+    from sklearn.neighbors import NearestNeighbors
+
+    Xq = np.ascontiguousarray(Xq, dtype=np.float64)
+    Yref = np.ascontiguousarray(Yref, dtype=np.float64)
+    if thresh < np.finfo(float).eps:
+        thresh = np.finfo(float).eps
+    knn = min(knn, Yref.shape[0])  # [UPSTREAM]: warns and clips knn to the size of the reference sample
+    tree = NearestNeighbors(n_neighbors=knn, algorithm=algorithm, metric="euclidean", n_jobs=n_jobs).fit(Yref)
+    if decay is None or thresh == 1:
+        return tree.kneighbors_graph(Xq, n_neighbors=knn, mode="connectivity").tocsr()
+    dist = tree.kneighbors(Xq, n_neighbors=knn)[0]
+    bandwidth = np.maximum(dist[:, knn - 1], np.finfo(float).eps)
+    radius = bandwidth * np.power(-1 * np.log(thresh), 1 / decay)
+    rows, cols, vals = [], [], []
+    for lo in range(0, Xq.shape[0], 4096):
+        hi = min(Xq.shape[0], lo + 4096)
+        dd, ii = tree.radius_neighbors(Xq[lo:hi], radius=float(np.max(radius[lo:hi])) * (1 + 1e-12))
+        for r in range(hi - lo):
+            v = np.exp(-1 * np.power(dd[r] / bandwidth[lo + r], decay))
+            v = np.where(np.isnan(v), 1, v)
+            keep = v >= thresh
+            rows.append(np.full(int(keep.sum()), lo + r, dtype=np.int64))
+            cols.append(ii[r][keep].astype(np.int64))
+            vals.append(v[keep])
+    K = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(Xq.shape[0], Yref.shape[0]))
+    K.sort_indices()
+    return K
+
+
+def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, algorithm="ball_tree"):
+    """Directed mutual-nearest-neighbours kernel of ``graphtools.Graph(data, sample_idx=...)`` (CSR, N x N).
+
+    [UPSTREAM graphtools 1.5.x ``MNNGraph.build_kernel``], reached from reference ``meld/meld.py:117-118``
+    when the caller forwards ``sample_idx`` (``test/test_meld.py:34``, ``test/test_utils.py:11``):
+      * one kNN graph per sample (``kernel_symm="+"``, no anisotropy): the diagonal block of sample i is its
+        symmetrised alpha-decay kernel ``(k_i + k_i^T) / 2`` (diagonal 1);
+      * the block from sample i to sample j != i is ``kernel_to_data(X_i, X_j, knn)`` with every row scaled by
+        ``min(1, within_i / between_ij) * beta`` -- row sum of the diagonal block over row sum of this block;
+    the assembled matrix then goes through the common ``symmetrize`` / ``apply_anisotropy`` steps.
+    PARITY: unpinned (the reference only checks that this path runs)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    sample_idx = np.asarray(sample_idx)
+    if sample_idx.shape[0] != X.shape[0]:
+        raise ValueError("sample_idx ({}) must be the same length as data ({})".format(sample_idx.shape[0], X.shape[0]))
+    samples = np.unique(sample_idx)
+    if len(samples) == 1:
+        raise ValueError("sample_idx must contain more than one unique value")
+    N = X.shape[0]
+    members = [np.nonzero(sample_idx == s)[0] for s in samples]
+    K = sparse.lil_matrix((N, N))
+    blocks = []
+    for i, mi in enumerate(members):
+        Kii = symmetrize(knn_kernel(X[mi], knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm)).tocsr()
+        within = np.asarray(Kii.sum(1)).ravel()
+        blocks.append((mi, mi, Kii.tocoo()))
+        for j, mj in enumerate(members):
+            if i == j:
+                continue
+            Kij = kernel_to_data(X[mi], X[mj], knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm)
+            between = np.asarray(Kij.sum(1)).ravel()
+            scale = np.minimum(1, within / between) * beta
+            blocks.append((mi, mj, Kij.multiply(scale[:, None]).tocoo()))
+    rows = np.concatenate([mi[b.row] for mi, mj, b in blocks])
+    cols = np.concatenate([mj[b.col] for mi, mj, b in blocks])
+    vals = np.concatenate([b.data for mi, mj, b in blocks])
+    K = sparse.csr_matrix((vals, (rows, cols)), shape=(N, N))
+    K.sort_indices()
+    return K
+
+
+def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
     ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
-    ``pca_reduce`` first."""
+    ``pca_reduce`` first.  ``sample_idx``: the MNN kernel between samples (``mnn_kernel``)."""
     if n_pca is not None:
         X = pca_reduce(X, n_pca)
+    if sample_idx is not None:
+        Kd = mnn_kernel(X, sample_idx, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm)
+        K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
+        K.sort_indices()
+        W = weights_from_kernel(K)
+        L, dw = laplacian(W)
+        return OracleGraph(Kd, K, W, L, dw)
     if thresh == 0:
         Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
         K = apply_anisotropy(symmetrize(Kd), anisotropy)

@@ -372,3 +372,64 @@ def test_beta_sweep_in_one_pass_equals_separate_transforms():
     R = mfilter.filter_sweep(s, op.graph, "laplacian", [1.0, 7.0], order=2, chebyshev_order=25)
     for b, beta in enumerate([1.0, 7.0]):
         np.testing.assert_allclose(R[b], mfilter.filter(s, op.graph, "laplacian", beta, order=2, chebyshev_order=25), rtol=0, atol=1e-13)
+
+
+def _two_batches(n_per=400, d=6, seed=0, shift=0.4):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n_per, d))
+    b = rng.normal(size=(n_per + 57, d)) + shift
+    X = np.concatenate([a, b])
+    batch = np.array(["batch_a"] * n_per + ["batch_b"] * (n_per + 57))
+    order = rng.permutation(X.shape[0])  # samples interleaved, as in real data
+    return X[order], batch[order]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decay", [40, None])
+def test_mnn_graph_matches_the_oracle(decay):
+    """sample_idx (reference test/test_meld.py:34, test/test_utils.py:11): graphtools' MNN kernel between
+    samples -- same graph (pattern, weights 1e-9, degrees) and densities (1e-5 rel) as the oracle."""
+    import meld_amd
+    from oracle import meld_oracle as mo
+
+    X, batch = _two_batches()
+    rng = np.random.default_rng(5)
+    labels = rng.choice(["ctrl", "expt"], size=X.shape[0])
+    op = meld_amd.MELD(knn=7, decay=decay, chebyshev_order=30, verbose=0)
+    dens = op.fit_transform(X, labels, sample_idx=batch)
+    assert op.graph.info["graph"] == "mnn" and op.graph.info["n_samples"] == 2
+    G = mo.build_graph(X, knn=7, decay=decay, sample_idx=batch, algorithm="brute")
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    op.graph.lmax = lmax
+    dens = op.transform(labels)
+    ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
+    assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_mnn_three_samples_and_argument_checks():
+    import meld_amd
+    from oracle import meld_oracle as mo
+
+    rng = np.random.default_rng(11)
+    X = np.concatenate([rng.normal(size=(150, 3)) + s for s in (0.0, 0.5, 1.0)])
+    batch = np.repeat([0, 1, 2], 150)
+    op = meld_amd.MELD(knn=4, verbose=0).fit(X, sample_idx=batch)
+    G = mo.build_graph(X, knn=4, sample_idx=batch, algorithm="brute")
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+    # the rest of the reference's test_mnn: likelihoods and vertex-frequency clustering on the MNN graph
+    labels = np.where(rng.random(450) < 0.5, "ctrl", "expt")
+    dens = op.transform(labels)
+    lik = meld_amd.utils.normalize_densities(dens)
+    spec = meld_amd.VertexFrequencyCluster(n_clusters=3, random_state=0).fit_transform(
+        G=op.graph, sample_indicator=op.sample_indicators["expt"], likelihood=lik["expt"])
+    ref_spec, _ = mo.vfc_transform(G.K, G.L, op.sample_indicators["expt"].values, likelihood=lik["expt"].values)
+    assert spec.shape == ref_spec.shape and np.abs(spec - ref_spec).max() <= 1e-6
+    with pytest.raises(ValueError, match="more than one unique value"):
+        meld_amd.MELD(verbose=0).fit(X, sample_idx=np.zeros(450))
+    with pytest.raises(ValueError, match="same length"):
+        meld_amd.MELD(verbose=0).fit(X, sample_idx=batch[:-1])
