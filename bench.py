@@ -266,10 +266,19 @@ def main():
         out["stages"] = dict(op2.graph.info["stage_seconds"], fit_total=t_fit, transform_total=time.perf_counter() - t0)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which (piped) is flushed at exit -- after Python's
+        # output; flush it now so that the JSON line is the last line on stdout
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
