@@ -466,6 +466,52 @@ def test_tile_pruning_is_exact():
                     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", ["outliers", "duplicates", "offset", "tiny", "grid_ties", "isotropic"])
+def test_pruning_and_radius_cut_on_awkward_data(case):
+    """The pruned / radius-cut search against the plain one (bit for bit) on data that stresses the bounds:
+    far outliers (huge error allowance), duplicated cells (zero-radius tiles, zero distances), a large offset,
+    tiny scale, an integer grid (masses of exact distance ties at every threshold) and full-rank isotropic
+    noise (nothing can be pruned)."""
+    from meld_amd.graph import HipOps
+    from meld_amd.reorder import locality_permutation
+
+    rng = np.random.default_rng(7)
+    N = 20000
+    if case == "outliers":
+        X = rng.normal(size=(N, 8))
+        X[:5] *= 1000.0
+    elif case == "duplicates":
+        base = rng.normal(size=(N // 4, 5))
+        X = np.concatenate([base, base, base[: N // 4], base[: N // 4] + 1e-9])
+    elif case == "offset":
+        X = rng.normal(size=(N, 10)) * 1.0e3 + 3.0e6
+    elif case == "tiny":
+        X = rng.normal(size=(N, 10)) * 1.0e-7
+    elif case == "grid_ties":
+        X = rng.integers(0, 12, size=(N, 4)).astype(np.float64)
+    else:
+        X = rng.normal(size=(N, 40))
+    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
+    perm = locality_permutation(Xd)
+    Xd = Xd.index_select(0, perm).contiguous()
+    knn = 5
+    outs = []
+    for prune, cut in ((False, False), (True, True)):
+        ops = HipOps(prune=prune)
+        ops.radius_cut = cut
+        try:
+            keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, N, knn, 40, 1e-4, 64)
+        except Exception as e:  # (degenerate ties are refused loudly by both variants, never answered wrongly)
+            outs.append(("raised", type(e).__name__))
+            continue
+        outs.append(ops.assemble_rows(keys, vals, 0, N, N) + (bw,))
+    if outs[0][0] == "raised" or outs[1][0] == "raised":
+        assert outs[0][0] == outs[1][0] == "raised", outs
+        return
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_pruned_search_on_shard_ranges():
     """A rank of the sharded driver searches a tile-aligned query range against all references with its own
     slice of the pruning table: same rows as the unpruned full-range search (ragged last range included)."""
