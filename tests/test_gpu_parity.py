@@ -172,7 +172,7 @@ def test_readme_toy_goes_through_radius_fallback():
 
 def test_fit_transform_parity_50k_config_scaled():
     """C2-shaped (d=50, knn=15, beta=60, M=30) at N=20k so the oracle finishes in seconds; the full
-    50k case is run by bench.py --parity.  Common injected lmax ('lmax')."""
+    50k case is test_fit_transform_parity_50k_config below.  Common injected lmax ('lmax')."""
     mo = _oracle()
     import meld_amd
 
@@ -338,6 +338,25 @@ def test_both_search_kernels_build_the_same_graph():
     for key in (("f16x3", 3), ("f16x3", 1)):
         for a, b in zip(graphs[("f32", 3)], graphs[key]):
             assert torch.equal(a, b)
+
+
+def test_fit_transform_parity_50k_config():
+    """BASELINE.json configs[1] at full size: 50k cells x 50 dims, knn=15, beta=60, Chebyshev order 30 on one
+    MI355X against the CPU oracle (brute-force kNN on all host cores so that it finishes in seconds): graph
+    weights / degrees to 1e-9, sample densities within the north star's 1e-5 relative (fp64), common lmax."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(50000, n_dims=50, seed=0)
+    samples, dens, G = mo.fit_transform(X, labels, knn=15, beta=60, chebyshev_order=30, return_graph=True,
+                                        algorithm="brute", n_jobs=-1)
+    op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, lmax=G.lmax)
+    out = op.fit_transform(X, labels)
+    assert list(out.columns) == list(samples)
+    assert op.graph.info["wave_tiles_done"] < (50000 / 64) ** 2  # the pruned search was the one that ran
+    _csr_close(op.graph.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+    assert _rel(out.values, dens) < 1e-5
 
 
 @pytest.mark.parametrize("search,nprod", [("f16x3", 1), ("f16x3", 3), ("f32", 3)])
