@@ -102,6 +102,91 @@ __global__ __launch_bounds__(256) void assign_nearest_grouped_kernel(const doubl
   if (l == 0) out[i] = arg;
 }
 
+// Tiled form of both assignments (the one the launcher uses): a workgroup takes 64 points in processing
+// order (`order`, sorted by group, or the identity), reads their rows with coalesced loads into LDS as fp32,
+// then stages the centroids of one group at a time ([k][c] in LDS) and lets thread (point p, part q) score
+// n_per_group / 4 of them from LDS -- both operands come from LDS, the only global traffic is one coalesced
+// pass over X (the team-per-point kernel above re-reads every point row and 16 strided centroid rows through
+// L1: 1.14 ms per level at 1M x 50, this one ~0.3 ms).  group == nullptr: one shared centroid set.
+constexpr int AT_PTS = 64;   // points per workgroup
+constexpr int AT_CMAX = 64;  // centroids per group (fan-out) at most
+template <int PER>  // centroids per quarter: n_per_group <= 4 PER
+__global__ __launch_bounds__(256) void assign_nearest_tiled_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                                   const double* __restrict__ cents, int n_per_group,
+                                                                   const int* __restrict__ group,
+                                                                   const int64_t* __restrict__ order,
+                                                                   int* __restrict__ out) {
+  __shared__ float xs[AT_PTS][AS_DMAX + 1];
+  __shared__ __attribute__((aligned(16))) float cs[AS_DMAX][AT_CMAX];
+  __shared__ int64_t s_idx[AT_PTS];
+  __shared__ int s_grp[AT_PTS];
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * AT_PTS;
+  const int n_here = (int)min((int64_t)AT_PTS, N - t0);
+  if (tid < AT_PTS) {
+    const int64_t i = tid < n_here ? (order ? order[t0 + tid] : t0 + tid) : -1;
+    s_idx[tid] = i;
+    s_grp[tid] = (i >= 0 && group) ? group[i] : 0;
+  }
+  __syncthreads();
+  for (int u = tid; u < AT_PTS * d; u += 256) {
+    const int r = u / d, k = u - r * d;
+    const int64_t i = s_idx[r];
+    xs[r][k] = i >= 0 ? (float)X[i * d + k] : 0.0f;
+  }
+  const int p = tid >> 2, q = tid & 3;           // point, quarter of the centroid set
+  constexpr int per = PER;
+  const int g_mine = s_grp[p];
+  // groups present in this workgroup: the points are sorted by group, so they form a range
+  int g_lo = s_grp[0], g_hi = s_grp[0];
+  for (int r = 1; r < n_here; ++r) {
+    g_lo = min(g_lo, s_grp[r]);
+    g_hi = max(g_hi, s_grp[r]);
+  }
+  float best = INFINITY;
+  int arg = 0x7fffffff;
+  for (int g = g_lo; g <= g_hi; ++g) {
+    __syncthreads();  // (also orders the xs stores before their first use)
+    const double* cb = cents + (int64_t)g * n_per_group * d;
+    for (int u = tid; u < n_per_group * d; u += 256) {
+      const int c = u / d, k = u - c * d;
+      cs[k][c] = (float)cb[u];
+    }
+    __syncthreads();
+    if (g_mine != g || s_idx[p] < 0) continue;
+    float acc[PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) acc[c] = 0.0f;
+    const int c_base = q * per;
+    for (int k = 0; k < d; ++k) {
+      const float xk = xs[p][k];
+#pragma unroll
+      for (int c = 0; c < PER; ++c) {
+        const float t = xk - cs[k][c_base + c];
+        acc[c] = fmaf(t, t, acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      if (c_base + c < n_per_group && acc[c] < best) {  // ascending c: the first minimum wins
+        best = acc[c];
+        arg = c_base + c;
+      }
+    }
+  }
+  // the four quarters of a point are adjacent lanes: argmin (ties -> smallest centroid index)
+#pragma unroll
+  for (int off = 1; off < 4; off <<= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oa = __shfl_xor(arg, off, 64);
+    if (ob < best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  if (q == 0 && s_idx[p] >= 0) out[s_idx[p]] = arg;
+}
+
 // Greedy nearest-neighbour chain over the m (<= 64) rows of every group P[g] ([n_groups][m][d]): one wave
 // per group, lane i = row i.  Starts at the row with the smallest first coordinate; rank[g][i] = position
 // of row i along the chain.  (Was a host loop: the device -> host copy, the NumPy walk and the copy back
@@ -154,6 +239,21 @@ using namespace meld;
 extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
                                    const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cents && out && N > 0 && d > 0 && n_per_group > 0, "meld_assign_nearest: bad arguments");
+  if (d <= AS_DMAX && n_per_group <= AT_CMAX && (group == nullptr || order != nullptr)) {
+#define MELD_ASSIGN_TILED(PERV)                                                                                         \
+  hipLaunchKernelGGL((assign_nearest_tiled_kernel<PERV>), dim3((unsigned)ceil_div(N, AT_PTS)), dim3(256), 0, S(stream), X, \
+                     N, d, cents, n_per_group, group, order, out)
+    if (n_per_group <= 16) {
+      MELD_ASSIGN_TILED(4);
+    } else if (n_per_group <= 32) {
+      MELD_ASSIGN_TILED(8);
+    } else {
+      MELD_ASSIGN_TILED(16);
+    }
+#undef MELD_ASSIGN_TILED
+    MELD_LAUNCH_CHECK("assign_nearest_tiled_kernel");
+    return MELD_OK;
+  }
   if (group == nullptr) {
     MELD_CHECK_ARG(d <= AS_DMAX, "meld_assign_nearest: d=%d exceeds %d", d, AS_DMAX);
     hipLaunchKernelGGL(assign_nearest_shared_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, S(stream), X, N,
