@@ -121,10 +121,14 @@ def test_unsupported_options_fail_loudly():
     meld = _meld()
     data = np.random.normal(size=(100, 2))
     labels = np.random.choice(["a", "b"], size=100)
-    with pytest.raises(NotImplementedError):
-        meld.MELD().fit_transform(data, labels, sample_idx=labels)  # MNN graph (reference test_mnn)
+    out = meld.MELD(verbose=0).fit_transform(data, labels, sample_idx=labels)  # MNN graph (reference test_mnn): supported
+    assert out.shape == (100, 2) and np.isfinite(out.values).all()
     with pytest.raises(NotImplementedError):
         meld.MELD(n_landmark=50).fit(data)
+    with pytest.raises(NotImplementedError):
+        meld.MELD(verbose=0).fit(data, bandwidth=1.0)  # graph kwargs the builder does not know
+    with pytest.raises(NotImplementedError):
+        meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
         meld.MELD(distance="cosine")
 
