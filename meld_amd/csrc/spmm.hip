@@ -58,6 +58,10 @@ __device__ __forceinline__ void store_row(double* __restrict__ base, int64_t row
   }
 }
 
+#ifndef SPMM_U
+#define SPMM_U 8  // (value, column, gather) chains in flight per thread (measured at 1M, P = 2: 2 -> 224, 4 -> 206, 8 -> 194 us)
+#endif
+
 template <int P, int RB>
 __global__ __launch_bounds__(256) void cheby_step_kernel(
     const int64_t* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
@@ -113,23 +117,23 @@ __global__ __launch_bounds__(256) void cheby_step_kernel(
 
   for (int64_t cs = e0; cs < e1; cs += chunk) {
     const int64_t ce = min(cs + (int64_t)chunk, e1);
-    // stream the span: 4 independent (value, column, gather) chains per thread per trip
-    for (int64_t eb = cs + tid; eb < ce; eb += 4 * 256) {
-      double v[4];
-      int j[4];
+    // stream the span: SPMM_U independent (value, column, gather) chains per thread per trip
+    for (int64_t eb = cs + tid; eb < ce; eb += SPMM_U * 256) {
+      double v[SPMM_U];
+      int j[SPMM_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SPMM_U; ++u) {
         const int64_t e = eb + u * 256;
         const bool ok = e < ce;
         // streamed once: non-temporal loads keep the CSR arrays out of the L1 the gathers live in
         v[u] = ok ? __builtin_nontemporal_load(val + e) : 0.0;
         j[u] = ok ? __builtin_nontemporal_load(col + e) : 0;
       }
-      Vec<P> xj[4];
+      Vec<P> xj[SPMM_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xj[u] = load_row<P>(x_full, j[u], ld, colofs);
+      for (int u = 0; u < SPMM_U; ++u) xj[u] = load_row<P>(x_full, j[u], ld, colofs);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SPMM_U; ++u) {
         const int64_t e = eb + u * 256;
         if (e < ce) {
           Vec<P> pr;
