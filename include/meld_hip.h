@@ -85,8 +85,9 @@ int meld_knn16_kblocks(int d);           /* KB = ceil((d+3)/16); <0 if d unsuppo
 int meld_knn16_tile_refs(void);          /* TS */
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
-double meld_knn16_error_coef(int nprod);       /* worst case: E <= coef * max|x~|^2 */
-double meld_knn16_error_coef_const(int nprod); /* per-row form: E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~| */
+double meld_knn16_error_coef(int nprod, int d);       /* worst case: E <= coef * max|x~|^2 (depends on the dimension:
+                                                        the accumulators sum nprod * d + 3 terms) */
+double meld_knn16_error_coef_const(int nprod, int d); /* per-row form: E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~| */
 double meld_knn16_error_coef_lin(int nprod);
 size_t meld_knn16_tile_bytes(int d);     /* bytes of one reference tile (KB * 4096) */
 size_t meld_knn16_query_bytes(int d);    /* bytes of one query row of Q16 */

@@ -37,8 +37,8 @@ SIGNATURES = {
     "meld_knn16_tile_refs": (_i32, []),
     "meld_knn16_block_queries": (_i32, []),
     "meld_knn16_row_capacity": (_i32, [_i32]),
-    "meld_knn16_error_coef": (_f64, [_i32]),
-    "meld_knn16_error_coef_const": (_f64, [_i32]),
+    "meld_knn16_error_coef": (_f64, [_i32, _i32]),
+    "meld_knn16_error_coef_const": (_f64, [_i32, _i32]),
     "meld_knn16_error_coef_lin": (_f64, [_i32]),
     "meld_knn16_resident_blocks": (_i32, [_i32, _i32]),
     "meld_knn16_tile_bytes": (_sz, [_i32]),

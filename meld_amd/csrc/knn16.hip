@@ -1145,27 +1145,40 @@ extern "C" int meld_knn16_row_capacity(int ksel) {
   }
   return ksel + K16_SLACK;
 }
-// Bound on |d2_approx - d2_exact| / max_i |x~_i|^2 (n_max) that meld_knn_refine budgets for.
-// d2 = sum_c q_c r_c with sum |q_c r_c| <= |x~_q|^2 + |x~_r|^2 + 2 |x~_q||x~_r| <= 4 n_max.
-//   The kernel accumulates |r|^2 - 2 q.r, sum of |terms| <= |r|^2 + 2 |q||r| <= 3 n_max, over <= 144 K
-//   slots (x3 products with the full split): fp32 accumulation error <= gamma_432 * 3 n_max < 2^-14.3 n_max;
-//   |r|^2 itself enters as three exact fp16 pieces (residual <= 2^-33 n_max + 2^-25);
-//   nprod = 3: every operand is hi + lo (|v - hi - lo| <= 2^-22 |v|), dropped lo.lo terms
-//              <= 3 * 2^-22 * 2 n_max: total < 2^-14 n_max            (measured: 7.6e-7 n_max)
-//   nprod = 1: coordinate blocks on the fp16 hi parts only:
-//              |q.r - qhi.rhi| <= |qlo.r| + |qhi.rlo| <= 2 * 2^-11 |x~_q| |2 x~_r| <= 2^-9 n_max
-//              (Cauchy-Schwarz)                                        (measured: 5.4e-4 n_max)
-extern "C" double meld_knn16_error_coef(int nprod) {
-  const double full = 6.103515625e-05;  // 2^-14
-  return nprod == 1 ? (0.001953125 + full) : full;
+// Bound on |d2_approx - d2_exact| / max_i |x~_i|^2 (n_max) that meld_knn_refine budgets for, as a function
+// of the dimension (the number of terms an accumulator really sums).  Per result the kernel accumulates
+// |r|^2 - 2 q.r, T = nprod * d + 3 non-zero products (zero K slots add exactly), sum of |terms| <= |r|^2 +
+// 2 |q||r| <= 3 n_max:
+//   fp32 accumulation          <= 1.01 T u * 3 n_max with u = 2^-23 (one ulp per addition: also covers a
+//                                 truncating adder tree inside the MFMA)
+//   scaled operands in fp32    points are rounded to fp32 before the split: <= 2^-21 n_max on d2
+//   |q|^2 and the threshold    fp32 FMA chain over d terms + one subtraction: (d + 2) 2^-24 n_max
+//   |r|^2 pieces               three exact fp16 pieces, residual <= 2^-33 n_max + 2^-25 <= 2^-24 n_max
+//   nprod = 3 only             operands are hi + lo: |v - hi - lo| <= 2^-22 |v| + 2^-25 (fp16 subnormal floor;
+//                              the data are scaled to max |coordinate| = 1, so n_max >= 1): <= (2^-20 + 3 * 2^-25
+//                              sqrt(d)) n_max; dropped lo.lo products <= 2^-21 n_max
+//   nprod = 1 only             coordinate blocks on the fp16 hi parts: |q.r - qhi.rhi| <= |qlo.r| + |qhi.rlo|
+//                              <= 2 * 2^-11 |x~_q| |2 x~_r| = 2^-9 |x~_q||x~_r| (Cauchy-Schwarz) -- the "lin" part,
+//                              charged per row through its own norm
+// d = 50: 6.1e-5 (nprod 3), 2.3e-5 + 2^-9 |q||r| (nprod 1); d = 2: 5.6e-6 -- what lets a million cells in the plane
+// be certified (neighbour distances^2 ~ 1e-5 n_max) instead of going through the exact sweep row by row.
+// Measured worst error: 7.6e-7 n_max (nprod 3), 5.4e-4 n_max (nprod 1) at d = 50.
+static double k16_const_coef(int nprod, int d) {
+  const double T = (double)(nprod == 3 ? 3 * d : d) + 3.0;
+  double c = 1.01 * T * 1.1920928955078125e-07 * 3.0  // accumulation, u = 2^-23
+             + 4.76837158203125e-07                    // 2^-21: fp32 rounding of the scaled points
+             + (double)(d + 2) * 5.9604644775390625e-08  // (d + 2) 2^-24
+             + 5.9604644775390625e-08;                 // 2^-24: norm pieces
+  if (nprod == 3) c += 9.5367431640625e-07 + 3.0 * 2.98023223876953125e-08 * sqrt((double)d) + 4.76837158203125e-07;
+  return c;
+}
+extern "C" double meld_knn16_error_coef(int nprod, int d) {
+  return k16_const_coef(nprod, d) + (nprod == 1 ? 0.001953125 : 0.0);  // + 2^-9 (global worst case of the lin part)
 }
 // The same bound split for a per-row allowance  E_i = c_const max|x~|^2 + c_lin |x~_i| max|x~|
 // (the nprod = 1 term is |qlo.r| + |qhi.rlo| <= 2^-9 |x~_q| |x~_r|): rows near the centre of
 // the data get a tighter allowance than the global worst case.
-extern "C" double meld_knn16_error_coef_const(int nprod) {
-  (void)nprod;
-  return 6.103515625e-05;  // 2^-14
-}
+extern "C" double meld_knn16_error_coef_const(int nprod, int d) { return k16_const_coef(nprod, d); }
 extern "C" double meld_knn16_error_coef_lin(int nprod) { return nprod == 1 ? 0.001953125 : 0.0; }
 
 extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
@@ -1237,7 +1250,7 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr);
   const int gx = (int)(n_c / 256);
   const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
-  const float ec = (float)meld_knn16_error_coef(1);
+  const float ec = (float)meld_knn16_error_coef(1, d);
 #define K16_BOUNDS_CASE(KBV)                                                                                              \
   case KBV:                                                                                                               \
     hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV>), dim3(gx, gy), dim3(256), 0, st, c16, cn, cr,                      \
@@ -1280,7 +1293,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
                  "meld_knn16_topk: the radius cut needs norm2_max, 1 <= knn < ksel, radius_factor >= 1 and one slice");
   const int knn1 = cand_thr ? knn + 1 : 0;
   const float rf2 = cand_thr ? (float)(radius_factor * radius_factor * (1.0 + 1e-6)) : 0.0f;
-  const float err_c = (float)meld_knn16_error_coef_const(nprod), err_l = (float)meld_knn16_error_coef_lin(nprod);
+  const float err_c = (float)meld_knn16_error_coef_const(nprod, d), err_l = (float)meld_knn16_error_coef_lin(nprod);
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
   const int cap = meld_knn16_row_capacity(ksel);
   if (cap < 0) return cap;
@@ -1327,7 +1340,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   ka.cap = cap;
   ka.lb2 = reinterpret_cast<const __half*>(lb2);
   ka.norm2_max = norm2_max;
-  ka.err_coef = (float)meld_knn16_error_coef(nprod);
+  ka.err_coef = (float)meld_knn16_error_coef(nprod, d);
   ka.tile_origin = tile_origin;
   ka.batch_every = batch_every;
   ka.batch_slack = batch_slack;

@@ -339,7 +339,7 @@ class HipOps:
             cap = lib.meld_knn16_row_capacity(ksel)
             if cap < 0:
                 check(cap, "meld_knn16_row_capacity")
-            err_coef = lib.meld_knn16_error_coef_const(nprod)
+            err_coef = lib.meld_knn16_error_coef_const(nprod, d)
             err_lin = lib.meld_knn16_error_coef_lin(nprod)
             n_tiles = (N + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
@@ -469,7 +469,7 @@ class HipOps:
             tau = cand_d2[r64 * cap + (cnt1 - 1).clamp_(min=0)].to(torch.float64)
             nmx = nmax.to(torch.float64)
             e1 = float(err_coef) * nmx + float(err_lin) * torch.sqrt(norm2[q_begin + r64].to(torch.float64) * nmx)
-            e3 = float(lib.meld_knn16_error_coef(3)) * nmx
+            e3 = float(lib.meld_knn16_error_coef(3, d)) * nmx
             s2 = research["scale_info"][0].to(torch.float64) ** 2
             bound = ((tau + e1 + e3) * s2 * (1.0 + 1e-5)).to(torch.float32)
             bound = torch.where(cnt1 >= ksel, bound, torch.full_like(bound, float("inf")))
@@ -491,7 +491,7 @@ class HipOps:
             check(
                 lib.meld_knn_refine(
                     ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, ksel, cap, knn, float(decay),
-                    float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
+                    float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3, d)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
                     ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), st,
                 ),
                 "meld_knn_refine(stage 2)",

@@ -317,8 +317,8 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     assert np.all(np.diff(cd, axis=1) >= 0)
     exact = np.take_along_axis(D, ci.astype(np.int64), axis=1)
     err = np.abs(cd - exact).max() / n2.max()
-    print("knn16 nprod=%d max |d2 - exact| / max|x|^2 = %.3e (budget %.3e)" % (nprod, err, lib.meld_knn16_error_coef(nprod)))
-    assert err < 0.5 * lib.meld_knn16_error_coef(nprod)  # the budget is a worst-case bound
+    print("knn16 nprod=%d max |d2 - exact| / max|x|^2 = %.3e (budget %.3e)" % (nprod, err, lib.meld_knn16_error_coef(nprod, d)))
+    assert err < 0.5 * lib.meld_knn16_error_coef(nprod, d)  # the budget is a worst-case bound
 
 
 def test_both_search_kernels_build_the_same_graph():

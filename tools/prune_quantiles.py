@@ -36,7 +36,7 @@ s2 = float(sinfo[0]) ** 2
 n_w = q_pad // 64
 print("kernel computed %.3f of the (wave, tile) pairs" % (float(done) / (n_w * n_tiles)))
 thr = (cthr * s2).view(n_w, 64)                      # final thresholds, scaled units
-margin = float(lib.meld_knn16_error_coef(1)) * float(nmax) * s2
+margin = float(lib.meld_knn16_error_coef(1, d)) * float(nmax) * s2
 L = lb2.view(torch.float16).view(n_w, n_tiles)
 srt = torch.sort(thr, dim=1).values
 for name, col in (("max", 63), ("2nd largest", 62), ("4th largest", 60), ("p90 (7th largest)", 57), ("median", 32)):
