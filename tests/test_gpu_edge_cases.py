@@ -163,3 +163,21 @@ def test_wide_data_beyond_the_mfma_kernels(n, d):
     dens = op.transform(labels)
     ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
     assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_many_uncertified_rows_trigger_one_search_with_the_longest_list():
+    """A candidate list too short for the data (here forced with ksel = knn + 2; in the wild: a million cells in
+    the plane) leaves most rows uncertified; instead of sweeping them one by one the builder searches once more
+    with ksel = 128.  Same graph as the oracle."""
+    from oracle import meld_oracle as mo
+
+    import meld_amd
+
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(20000, 2))
+    op = meld_amd.MELD(knn=10, verbose=0).fit(X, ksel=12)
+    info = op.graph.info
+    assert info.get("ksel_retry_from") == 12 and info["ksel"] == 128 and info["n_flagged_rows_first_try"] > 1024
+    G = mo.build_graph(X, knn=10)
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
