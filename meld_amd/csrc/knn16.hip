@@ -333,6 +333,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto thr_start = [&](int g) __attribute__((always_inline)) { return a.thr_init ? a.thr_init[q_base + g * 32 + jq] : INFINITY; };
   float thrp[2] = {thr_start(0) - nq[0], thr_start(1) - nq[1]};
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
+  if (a.thr_init) {  // seeded thresholds also seed the pruning bound (and let the timing ablations prune realistically)
+    float w = fmaxf(thr_start(0), thr_start(1));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
+    wmax = w;
+  }
   unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when

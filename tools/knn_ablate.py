@@ -1,0 +1,53 @@
+"""Where the pruned search spends its time: run it once, feed the final per-row thresholds back as seeds and time the
+timing-only ablations of the kernel with realistic pruning (MELD_KNN16_ABLATION: 1 = no selection, 3 = MFMAs only,
+9 = no tile loads).   python tools/knn_ablate.py [N]"""
+import os, sys, math, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from meld_amd._lib import get_lib, ptr, check
+from meld_amd.reorder import locality_permutation
+from bench import synthetic_cells
+
+lib = get_lib()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+X, _ = synthetic_cells(n, 50, seed=0)
+Xd = torch.from_numpy(X).cuda()
+Xd = Xd.index_select(0, locality_permutation(Xd)).contiguous()
+N, d = Xd.shape
+st = torch.cuda.current_stream().cuda_stream
+TS, BQ = lib.meld_knn16_tile_refs(), lib.meld_knn16_block_queries()
+ksel, knn = 64, 15; cap = lib.meld_knn16_row_capacity(ksel)
+sums = torch.empty(d, dtype=torch.float64, device="cuda"); check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st)); mean = sums / N
+n_tiles = (N + TS - 1) // TS; q_pad = ((N + BQ - 1) // BQ) * BQ
+Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda")
+Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda"); Qn = torch.empty(q_pad, dtype=torch.float32, device="cuda")
+norm2 = torch.empty(N, dtype=torch.float32, device="cuda"); nmax = torch.zeros(1, dtype=torch.float32, device="cuda"); sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
+check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+tmpb = torch.empty(lib.meld_knn16_bounds_temp_bytes(N, d, N), dtype=torch.uint8, device="cuda")
+lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, N), dtype=torch.uint8, device="cuda")
+check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(tmpb), ptr(lb2), st))
+ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
+cthr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device="cuda"); done = torch.zeros(1, dtype=torch.int64, device="cuda")
+rf = (-math.log(1e-4)) ** (1 / 40)
+
+def run(seed, label):
+    done.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, ptr(seed) if seed is not None else None,
+                              knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), st))
+    e1.record(); torch.cuda.synchronize()
+    print("%-44s %.2f ms   blocks computed %.3f" % (label, e0.elapsed_time(e1), float(done) / ((q_pad // 64) * n_tiles)))
+
+abl = os.environ.get("MELD_KNN16_ABLATION")
+if abl is None:
+    run(None, "product"); run(None, "product")
+    seed = (cthr * float(sinfo[0]) ** 2 * 1.0001).contiguous()
+    torch.save(seed.cpu(), "/tmp/knn_seed.pt")
+    run(seed, "product, thresholds seeded with the final ones")
+    for a, name in (("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("9", "MFMAs only, no tile loads")):
+        env = dict(os.environ, MELD_KNN16_ABLATION=a)
+        subprocess.run([sys.executable, __file__, str(n)], env=env)
+else:
+    seed = torch.load("/tmp/knn_seed.pt").cuda()
+    run(seed, "ablation %s" % abl); run(seed, "ablation %s" % abl)
