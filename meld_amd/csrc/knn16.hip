@@ -13,17 +13,24 @@
 // budgets for (err_coef below).
 //
 // Decomposition: workgroup = 4 waves = 256 queries (each wave: 2 groups of 32 queries held as
-// B fragments, 64 VGPRs); the waves share the reference tile stream (64 refs, 16 KiB: hi and lo
-// planes) double-buffered in LDS.  One A fragment (ds_read_b128 x2) feeds two MFMA chains
-// (the two query groups), so the matrix pipe never waits on a dependent accumulator.  Three
-// workgroups are resident per CU (157 VGPRs, 47 KiB LDS): a selection slow path in one
-// workgroup stalls its four waves at the tile barrier, and the other workgroups keep the matrix
-// pipe fed (measured: 8-wave workgroups, one per CU, left the pipe 65 % idle).  L2 -> LDS: each
-// tile is read once per workgroup: 16 KiB per 1536 matrix-pipe cycles x 3 ~ 32 B/clk/CU.
+// B fragments, 64 VGPRs); the waves share the reference tile stream (64 refs; the hi-only first pass
+// keeps just the hi planes, 8 KiB at d = 50), copied global -> LDS by LDS DMA into two alternating
+// buffers.  One A fragment (ds_read_b128) feeds two MFMA chains (the two query groups), so the matrix
+// pipe never waits on a dependent accumulator.  Three workgroups are resident per CU (165 VGPRs,
+// 27 KiB LDS): a selection slow path in one workgroup stalls its four waves at the tile barrier, and
+// the other workgroups keep the matrix pipe fed (measured: 8-wave workgroups, one per CU, left the
+// pipe 65 % idle).
+//
+// Exact tile pruning (meld_knn16_bounds): every wave owns a row of lower bounds (its 64 queries against
+// every reference tile); a wave sits out the tiles whose bound exceeds all of its thresholds, and a tile no
+// wave of the workgroup needs is not staged at all.  With the cells in locality order 65 % of the
+// 64 x 64 distance blocks are never computed; the candidate lists are bit-identical.
 //
 // Selection: as in knn.hip (threshold per query, append to the row buffer, compact when full),
 // but compaction finds the new threshold by a 32-step radix select on the ordered float bits and
 // squeezes the survivors with ballots (~5x cheaper than ranking); rows are ranked once, at the end.
+// Radius cut: once a row holds knn + 1 entries its threshold drops to the kernel radius that entry
+// implies (knn16_squeeze_row), and the final threshold is published for refine's completeness test.
 #include "common.hpp"
 
 #include <hip/hip_fp16.h>
