@@ -127,6 +127,13 @@ int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mea
  * n_slices > 1 (small query sets): the references are cut into n_slices ranges, each scanned by its
  * own workgroups into its own candidate rows (buffers of n_slices * roundup(q_count, BQ) rows);
  * meld_knn16_merge_slices then writes the ksel smallest of the union to the final rows. */
+/* Start values for the thresholds of meld_knn16_topk's first pass (thr_init, scaled units, roundup(q_count, BQ)
+ * floats): the (knn+1)-th smallest distance of a query within its own block of BQ cells bounds its bandwidth from
+ * above, so nothing beyond radius_factor^2 times that (plus the error allowance) can be wanted.  Spares the scan the
+ * wholesale appends of its first tiles.  q_begin must be a multiple of BQ.  No reference counterpart. */
+int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                               const float* norm2_max, int64_t q_begin, int64_t q_count, int knn, double radius_factor,
+                               int nprod, float* thr_init, meld_stream_t stream);
 int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                     int64_t n_ref, int d, int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
                     const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,

@@ -1127,6 +1127,84 @@ __global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict
   }
 }
 
+// Threshold seeds.  The scan starts with every threshold at +inf, so the first tiles of a workgroup -- its own
+// 256 cells -- are appended wholesale (256 appends and ~3 compactions per row, a third of what learning the
+// thresholds costs the search).  A valid start value is cheap: the (knn+1)-th smallest distance of a cell *within its
+// own block of 256* (self included) bounds its bandwidth from above, hence
+//     thr_init = rf^2 (A (1 + 1e-5) + 2^-20 n_max) + 1.01 E_row
+// bounds the approximate d2 of every reference the kernel radius can reach (A is computed here by direct fp32
+// differences of the same centred, scaled coordinates the search uses: relative error ~3e-6 plus the fp32 rounding of
+// the inputs, 2^-21 n_max).  One workgroup per block: the 256 cells in LDS, thread i scans them keeping its knn+1
+// smallest values in registers.
+constexpr int SEED_KMAX = 64;  // largest knn + 1 a register list holds (longer: no seed)
+constexpr int SEED_DMAX = 60;  // rows are padded to 60 coordinates: 256 x 60 floats of dynamic LDS = 60 KiB
+constexpr int SEED_LD = 60;    // (row stride; the rows are read as broadcast float4, the own row once)
+template <int SEED_K>  // register list length >= knn + 1
+__global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                         const double* __restrict__ mean,
+                                                         const float* __restrict__ scale_info,
+                                                         const float* __restrict__ norm2_max, int64_t q_begin,
+                                                         int64_t q_count, int knn1, float rf2, float err_c, float err_l,
+                                                         float* __restrict__ thr_init) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [256][SEED_LD]: rows zero-padded to SEED_DMAX coordinates
+  const int tid = threadIdx.x;
+  constexpr int ldx = SEED_LD;
+  const int64_t row0 = q_begin + (int64_t)blockIdx.x * K16_BQ;
+  const int n_here = (int)max((int64_t)0, min((int64_t)K16_BQ, q_begin + q_count - row0));
+  const float s = scale_info[0];
+  for (int u = tid; u < K16_BQ * SEED_LD; u += 256) xs[u] = 0.0f;
+  __syncthreads();
+  for (int u = tid; u < K16_BQ * d; u += 256) {
+    const int r = u / d, k = u - r * d;
+    if (r < n_here) xs[r * ldx + k] = s * (float)(X[(row0 + r) * d + k] - mean[k]);
+  }
+  __syncthreads();
+  // the SEED_K smallest values seen so far, ascending; inserting v and dropping the largest is one median per slot:
+  // new[e] = med3(old[e - 1], v, old[e])
+  float best[SEED_K];
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) best[e] = INFINITY;
+  // own row in registers (padded coordinates are zero on both sides and add nothing)
+  float xr[SEED_DMAX];
+#pragma unroll
+  for (int k = 0; k < SEED_DMAX; ++k) xr[k] = xs[tid * ldx + k];
+  float nq = 0.0f;
+#pragma unroll
+  for (int k = 0; k < SEED_DMAX; ++k) nq = fmaf(xr[k], xr[k], nq);
+  for (int j = 0; j < n_here; ++j) {
+    const float4* xj = reinterpret_cast<const float4*>(xs + j * ldx);  // (same address in every lane: LDS broadcast)
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < SEED_DMAX / 4; ++k4) {
+      const float4 c = xj[k4];
+      const float t0 = xr[4 * k4] - c.x, t1 = xr[4 * k4 + 1] - c.y, t2 = xr[4 * k4 + 2] - c.z, t3 = xr[4 * k4 + 3] - c.w;
+      acc0 = fmaf(t0, t0, acc0);
+      acc1 = fmaf(t1, t1, acc1);
+      acc0 = fmaf(t2, t2, acc0);
+      acc1 = fmaf(t3, t3, acc1);
+    }
+    const float acc = acc0 + acc1;
+    if (acc < best[SEED_K - 1]) {
+#pragma unroll
+      for (int e = SEED_K - 1; e > 0; --e) best[e] = __builtin_amdgcn_fmed3f(best[e - 1], acc, best[e]);
+      best[0] = fminf(best[0], acc);
+    }
+  }
+  float worst = INFINITY;  // the knn1-th smallest
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e)
+    if (e == knn1 - 1) worst = best[e];
+  if (tid < K16_BQ) {
+    float out = INFINITY;
+    if (tid < n_here && n_here >= knn1 && worst < INFINITY) {
+      const float nmax_s = norm2_max[0] * s * s;
+      const float e_row = (err_c * nmax_s + err_l * sqrtf(nq * nmax_s)) * 1.01f;
+      out = (rf2 * (worst * 1.00001f + 9.5367431640625e-07f * nmax_s) + e_row) * 1.000001f + 1e-30f;
+    }
+    thr_init[(int64_t)blockIdx.x * K16_BQ + tid] = out;
+  }
+}
+
 }  // namespace meld
 
 using namespace meld;
@@ -1286,6 +1364,45 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   }
 #undef K16_BOUNDS_CASE
   MELD_LAUNCH_CHECK("meld_knn16_bounds");
+  return MELD_OK;
+}
+
+// Start values for the thresholds of meld_knn16_topk's first pass (thr_init, scaled units, roundup(q_count, BQ)
+// floats) from every query's own block of BQ cells; q_begin must be a multiple of BQ.  knn, radius_factor as for the
+// radius cut.  Rows whose block holds fewer than knn + 1 cells (or knn + 1 > 64) get +inf.
+extern "C" int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                          const float* norm2_max, int64_t q_begin, int64_t q_count, int knn,
+                                          double radius_factor, int nprod, float* thr_init, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && scale_info && norm2_max && thr_init && N > 0 && q_count > 0 && q_begin >= 0 &&
+                     q_begin + q_count <= N,
+                 "meld_knn16_seed_thresholds: bad arguments");
+  MELD_CHECK_ARG(q_begin % K16_BQ == 0, "meld_knn16_seed_thresholds: q_begin must be a multiple of the query block (%d)", K16_BQ);
+  MELD_CHECK_ARG(knn >= 1 && radius_factor >= 1.0 && (nprod == 1 || nprod == 3), "meld_knn16_seed_thresholds: bad kernel parameters");
+  if (meld_knn16_kblocks(d) < 0) return MELD_ERR_UNSUPPORTED;
+  const int n_b = (int)ceil_div(q_count, K16_BQ);
+  hipStream_t st = S(stream);
+  if (knn + 1 > SEED_KMAX || d > SEED_DMAX) {  // no seed: the search starts at +inf as before
+    const size_t n = (size_t)n_b * K16_BQ;
+    MELD_HIP_CALL(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(thr_init), 0x7f800000, n, st));
+    return MELD_OK;
+  }
+  const float rf2 = (float)(radius_factor * radius_factor * (1.0 + 1e-6));
+  const size_t lds = sizeof(float) * (size_t)K16_BQ * SEED_LD;
+#define K16_SEED_LAUNCH(KV)                                                                                             \
+  hipLaunchKernelGGL((knn16_seed_kernel<KV>), dim3(n_b), dim3(256), lds, st, X, N, d, mean, scale_info, norm2_max, q_begin, \
+                     q_count, knn + 1, rf2, (float)meld_knn16_error_coef_const(nprod, d),                               \
+                     (float)meld_knn16_error_coef_lin(nprod), thr_init)
+  if (knn + 1 <= 8) {
+    K16_SEED_LAUNCH(8);
+  } else if (knn + 1 <= 16) {
+    K16_SEED_LAUNCH(16);
+  } else if (knn + 1 <= 32) {
+    K16_SEED_LAUNCH(32);
+  } else {
+    K16_SEED_LAUNCH(64);
+  }
+#undef K16_SEED_LAUNCH
+  MELD_LAUNCH_CHECK("knn16_seed_kernel");
   return MELD_OK;
 }
 

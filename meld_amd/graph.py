@@ -255,6 +255,8 @@ class HipOps:
         # well-separated data
         self.prune = (os.environ.get("MELD_KNN_PRUNE", "1") != "0") if prune is None else bool(prune)
         self.radius_cut = os.environ.get("MELD_KNN_RADIUS_CUT", "1") != "0"
+        # thresholds of the first pass seeded from every row's own block (meld_knn16_seed_thresholds)
+        self.seed = os.environ.get("MELD_KNN_SEED", "1") != "0"
         # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
         # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
         # waves and the sliced launch costs more than the idle tail, so it is off
@@ -379,8 +381,14 @@ class HipOps:
                     tail_slices = int(max(1, min(lib.meld_knn16_max_slices(ksel), resident // tail_blocks, n_tiles)))
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
+            seeds = None
+            if self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1:
+                # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
+                seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
+                check(lib.meld_knn16_seed_thresholds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
+                tm.stop("seed")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, None, knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main

@@ -475,9 +475,11 @@ def test_tile_pruning_is_exact():
             outs = []
             # pruning and the radius cut (rows cut at the kernel radius their knn-th neighbour implies) are
             # independent switches of the search; the graph must not depend on either
-            for prune, cut in ((False, False), (True, False), (False, True), (True, True)):
+            for prune, cut, seed in ((False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                     (True, True, True), (False, True, True)):
                 ops = HipOps(prune=prune)
                 ops.radius_cut = cut
+                ops.seed = seed  # thresholds started from every row's own block (meld_knn16_seed_thresholds)
                 keys, vals, bw, info = ops.directed_kernel_coo(Xs, 0, 30000, knn, 40, 1e-4, 64)
                 outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
             for other in outs[1:]:
@@ -518,6 +520,7 @@ def test_pruning_and_radius_cut_on_awkward_data(case):
     for prune, cut in ((False, False), (True, True)):
         ops = HipOps(prune=prune)
         ops.radius_cut = cut
+        ops.seed = cut
         try:
             keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, N, knn, 40, 1e-4, 64)
         except Exception as e:  # (degenerate ties are refused loudly by both variants, never answered wrongly)
@@ -529,6 +532,47 @@ def test_pruning_and_radius_cut_on_awkward_data(case):
         return
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_threshold_seeds_bound_the_kernel_radius():
+    """meld_knn16_seed_thresholds: every seed is at least the squared kernel radius of its row (scaled units), so no
+    wanted neighbour can fail `d2 < threshold`; and it is tight enough to be useful (within 3x of it in locality order)."""
+    from meld_amd._lib import check, get_lib, ptr
+
+    mo = _oracle()
+    lib = get_lib()
+    from meld_amd.reorder import locality_permutation
+
+    N, d, knn = 16500, 50, 15
+    X, _ = mo.synthetic_cells(N, n_dims=d, seed=8)
+    Xd = torch.from_numpy(X).cuda()
+    Xd = Xd.index_select(0, locality_permutation(Xd)).contiguous()  # blocks = spatial neighbourhoods, as in fit
+    st = torch.cuda.current_stream().cuda_stream
+    BQ = lib.meld_knn16_block_queries()
+    sums = torch.empty(d, dtype=torch.float64, device="cuda")
+    check(lib.meld_col_sums_f64(ptr(Xd), N, d, ptr(sums), st))
+    mean = sums / N
+    n_tiles = (N + 63) // 64
+    q_pad = ((N + BQ - 1) // BQ) * BQ
+    Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda")
+    Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda")
+    Qn = torch.empty(q_pad, dtype=torch.float32, device="cuda")
+    norm2 = torch.empty(N, dtype=torch.float32, device="cuda")
+    nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+    sinfo = torch.empty(4, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+    rf = (-np.log(1e-4)) ** (1 / 40)
+    seeds = torch.empty(q_pad, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_seed_thresholds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), 0, N, knn, rf, 1, ptr(seeds), st))
+    torch.cuda.synchronize()
+    s2 = float(sinfo[0]) ** 2
+    D = torch.cdist(Xd, Xd)
+    bw = torch.kthvalue(D, knn + 1, dim=1).values  # true bandwidth (self counted)
+    radius2 = ((bw * rf) ** 2 * s2).to(torch.float32)
+    got = seeds[:N]
+    assert bool((got >= radius2).all())
+    assert float((got / radius2).median()) < 3.0
+    assert bool(torch.isinf(seeds[N:]).all())  # padding rows of the last block
 
 
 def test_pruned_search_on_shard_ranges():
