@@ -1137,22 +1137,22 @@ __global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict
 // the inputs, 2^-21 n_max).  One workgroup per block: the 256 cells in LDS, thread i scans them keeping its knn+1
 // smallest values in registers.
 constexpr int SEED_KMAX = 64;  // largest knn + 1 a register list holds (longer: no seed)
-constexpr int SEED_DMAX = 60;  // rows are padded to 60 coordinates: 256 x 60 floats of dynamic LDS = 60 KiB
-constexpr int SEED_LD = 60;    // (row stride; the rows are read as broadcast float4, the own row once)
-template <int SEED_K>  // register list length >= knn + 1
+// (rows are zero-padded to SEED_D coordinates -- 60 / 104 / 144: 60 / 104 / 144 KiB of dynamic LDS -- and read as
+// broadcast float4, the thread's own row once into registers)
+template <int SEED_K, int SEED_D>  // register list length >= knn + 1; padded dimension >= d
 __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restrict__ X, int64_t N, int d,
                                                          const double* __restrict__ mean,
                                                          const float* __restrict__ scale_info,
                                                          const float* __restrict__ norm2_max, int64_t q_begin,
                                                          int64_t q_count, int knn1, float rf2, float err_c, float err_l,
                                                          float* __restrict__ thr_init) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [256][SEED_LD]: rows zero-padded to SEED_DMAX coordinates
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [256][SEED_D]: rows zero-padded to SEED_D coordinates
   const int tid = threadIdx.x;
-  constexpr int ldx = SEED_LD;
+  constexpr int ldx = SEED_D;
   const int64_t row0 = q_begin + (int64_t)blockIdx.x * K16_BQ;
   const int n_here = (int)max((int64_t)0, min((int64_t)K16_BQ, q_begin + q_count - row0));
   const float s = scale_info[0];
-  for (int u = tid; u < K16_BQ * SEED_LD; u += 256) xs[u] = 0.0f;
+  for (int u = tid; u < K16_BQ * SEED_D; u += 256) xs[u] = 0.0f;
   __syncthreads();
   for (int u = tid; u < K16_BQ * d; u += 256) {
     const int r = u / d, k = u - r * d;
@@ -1165,17 +1165,17 @@ __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restric
 #pragma unroll
   for (int e = 0; e < SEED_K; ++e) best[e] = INFINITY;
   // own row in registers (padded coordinates are zero on both sides and add nothing)
-  float xr[SEED_DMAX];
+  float xr[SEED_D];
 #pragma unroll
-  for (int k = 0; k < SEED_DMAX; ++k) xr[k] = xs[tid * ldx + k];
+  for (int k = 0; k < SEED_D; ++k) xr[k] = xs[tid * ldx + k];
   float nq = 0.0f;
 #pragma unroll
-  for (int k = 0; k < SEED_DMAX; ++k) nq = fmaf(xr[k], xr[k], nq);
+  for (int k = 0; k < SEED_D; ++k) nq = fmaf(xr[k], xr[k], nq);
   for (int j = 0; j < n_here; ++j) {
     const float4* xj = reinterpret_cast<const float4*>(xs + j * ldx);  // (same address in every lane: LDS broadcast)
     float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-    for (int k4 = 0; k4 < SEED_DMAX / 4; ++k4) {
+    for (int k4 = 0; k4 < SEED_D / 4; ++k4) {
       const float4 c = xj[k4];
       const float t0 = xr[4 * k4] - c.x, t1 = xr[4 * k4 + 1] - c.y, t2 = xr[4 * k4 + 2] - c.z, t3 = xr[4 * k4 + 3] - c.w;
       acc0 = fmaf(t0, t0, acc0);
@@ -1381,17 +1381,31 @@ extern "C" int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, con
   if (meld_knn16_kblocks(d) < 0) return MELD_ERR_UNSUPPORTED;
   const int n_b = (int)ceil_div(q_count, K16_BQ);
   hipStream_t st = S(stream);
-  if (knn + 1 > SEED_KMAX || d > SEED_DMAX) {  // no seed: the search starts at +inf as before
+  if (knn + 1 > SEED_KMAX || d > 144) {  // no seed: the search starts at +inf as before
     const size_t n = (size_t)n_b * K16_BQ;
     MELD_HIP_CALL(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(thr_init), 0x7f800000, n, st));
     return MELD_OK;
   }
   const float rf2 = (float)(radius_factor * radius_factor * (1.0 + 1e-6));
-  const size_t lds = sizeof(float) * (size_t)K16_BQ * SEED_LD;
-#define K16_SEED_LAUNCH(KV)                                                                                             \
-  hipLaunchKernelGGL((knn16_seed_kernel<KV>), dim3(n_b), dim3(256), lds, st, X, N, d, mean, scale_info, norm2_max, q_begin, \
-                     q_count, knn + 1, rf2, (float)meld_knn16_error_coef_const(nprod, d),                               \
-                     (float)meld_knn16_error_coef_lin(nprod), thr_init)
+#define K16_SEED_LAUNCH2(KV, DV)                                                                                          \
+  do {                                                                                                                    \
+    const size_t lds = sizeof(float) * (size_t)K16_BQ * DV;                                                               \
+    if (lds > 64 * 1024)                                                                                                  \
+      MELD_HIP_CALL(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn16_seed_kernel<KV, DV>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    hipLaunchKernelGGL((knn16_seed_kernel<KV, DV>), dim3(n_b), dim3(256), lds, st, X, N, d, mean, scale_info, norm2_max,   \
+                       q_begin, q_count, knn + 1, rf2, (float)meld_knn16_error_coef_const(nprod, d),                      \
+                       (float)meld_knn16_error_coef_lin(nprod), thr_init);                                                \
+  } while (0)
+#define K16_SEED_LAUNCH(KV)        \
+  do {                             \
+    if (d <= 60)                   \
+      K16_SEED_LAUNCH2(KV, 60);    \
+    else if (d <= 104)             \
+      K16_SEED_LAUNCH2(KV, 104);   \
+    else                           \
+      K16_SEED_LAUNCH2(KV, 144);   \
+  } while (0)
   if (knn + 1 <= 8) {
     K16_SEED_LAUNCH(8);
   } else if (knn + 1 <= 16) {
@@ -1402,6 +1416,7 @@ extern "C" int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, con
     K16_SEED_LAUNCH(64);
   }
 #undef K16_SEED_LAUNCH
+#undef K16_SEED_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_seed_kernel");
   return MELD_OK;
 }
