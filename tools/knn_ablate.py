@@ -45,6 +45,12 @@ if abl is None:
     seed = (cthr * float(sinfo[0]) ** 2 * 1.0001).contiguous()
     torch.save(seed.cpu(), "/tmp/knn_seed.pt")
     run(seed, "product, thresholds seeded with the final ones")
+    for f in (1.2, 1.5, 2.0, 3.0):
+        run((seed * f).contiguous(), "product, seeds = %.1f x the final thresholds" % f)
+    own = torch.empty(q_pad, dtype=torch.float32, device="cuda")
+    check(lib.meld_knn16_seed_thresholds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), 0, N, knn, rf, 1, ptr(own), st))
+    run(own, "product, seeds from the own block (the default)")
+    print("own-block seed / final threshold: median %.2f, p90 %.2f" % (float((own[:N] / seed[:N]).median()), float(torch.quantile((own[:N] / seed[:N])[:200000], 0.9))))
     for a, name in (("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
         subprocess.run([sys.executable, __file__, str(n)], env=env)
