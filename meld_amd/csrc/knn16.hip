@@ -1205,6 +1205,110 @@ __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restric
   }
 }
 
+// The same seeds from a wider neighbourhood on the matrix pipe: a workgroup takes its 256 queries (B fragments, as in
+// the search) against its own four reference tiles and the four on either side in index order (768 cells: in locality
+// order the next leaves along the chain) -- 192 MFMAs per wave -- and every lane keeps the SEED_K smallest approximate
+// d2 of its two queries sorted in registers (one v_med3 per slot and insertion); the two half-lanes of a query then
+// merge their lists.  The approximate distance may fall short of the exact one by the row's search-error allowance, so
+//     thr_init = rf^2 (A~ + 1.01 E_row + 2^-20 n_max) + 1.01 E_row.
+// More cells than the fp32 kernel above looks at (768 vs 256: a tighter bound) for a tenth of its time.
+constexpr int SEED_SIDE = 4;  // tiles on either side of the workgroup's own K16_BQ / K16_TS tiles
+template <int KB, int SEED_K>
+__global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
+                                                              const _Float16* __restrict__ Rt16,
+                                                              const float* __restrict__ scale_info,
+                                                              const float* __restrict__ norm2_max, int n_tiles,
+                                                              int first_tile, int knn1, float rf2, float err_c, float err_l,
+                                                              float* __restrict__ thr_init) {
+  constexpr int HV = KB * 2 * K16_TS;  // hi vectors per tile
+  constexpr int NS = (HV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float4 lds_a[HV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
+  const int q_base = blockIdx.x * K16_BQ + wave * 64;
+  f16x8 bhi[2][KB];
+  float nq[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f16x8* qrow = reinterpret_cast<const f16x8*>(Q16 + (size_t)(q_base + g * 32 + jq) * (KB * 32));
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
+    nq[g] = Qn[q_base + g * 32 + jq];
+  }
+  float best0[SEED_K], best1[SEED_K];
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) best0[e] = best1[e] = INFINITY;
+  auto insert = [&](float (&best)[SEED_K], float v) __attribute__((always_inline)) {
+    if (v < best[SEED_K - 1]) {
+#pragma unroll
+      for (int e = SEED_K - 1; e > 0; --e) best[e] = __builtin_amdgcn_fmed3f(best[e - 1], v, best[e]);
+      best[0] = fminf(best[0], v);
+    }
+  };
+  const float4* R4 = reinterpret_cast<const float4*>(Rt16);
+  const int t_own = first_tile + blockIdx.x * (K16_BQ / K16_TS);
+  for (int tt = -SEED_SIDE; tt < K16_BQ / K16_TS + SEED_SIDE; ++tt) {
+    const int t = t_own + tt;
+    if (t < 0 || t >= n_tiles) continue;  // (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int j = tid + 256 * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
+      if (j < HV) lds_a[j] = R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)];
+    }
+    __syncthreads();
+    const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_a);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 c0, c1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const f16x8 ahi = a8[(kb * 2 + h) * K16_TS + sub * 32 + jq];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        insert(best0, c0[r] + nq[0]);
+        insert(best1, c1[r] + nq[1]);
+      }
+    }
+  }
+  // the other half-lane holds the other half of each query's references: merge its list
+  float other[SEED_K];
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) other[e] = __shfl_xor(best0[e], 32, 64);
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) insert(best0, other[e]);
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) other[e] = __shfl_xor(best1[e], 32, 64);
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) insert(best1, other[e]);
+  float a0 = INFINITY, a1 = INFINITY;  // the knn1-th smallest
+#pragma unroll
+  for (int e = 0; e < SEED_K; ++e) {
+    if (e == knn1 - 1) {
+      a0 = best0[e];
+      a1 = best1[e];
+    }
+  }
+  if (h == 0) {
+    const float s = scale_info[0];
+    const float nmax_s = norm2_max[0] * s * s;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float a = g ? a1 : a0;
+      float out = INFINITY;
+      if (a < INFINITY) {
+        const float e_row = (err_c * nmax_s + err_l * sqrtf(nq[g] * nmax_s)) * 1.01f;
+        out = (rf2 * (fmaxf(a, 0.0f) + e_row + 9.5367431640625e-07f * nmax_s) + e_row) * 1.000001f + 1e-30f;
+      }
+      thr_init[q_base + g * 32 + jq] = out;
+    }
+  }
+}
+
 }  // namespace meld
 
 using namespace meld;
@@ -1418,6 +1522,60 @@ extern "C" int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, con
 #undef K16_SEED_LAUNCH
 #undef K16_SEED_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_seed_kernel");
+  return MELD_OK;
+}
+
+// The same from the fp16 operands of meld_knn16_prepare, on the matrix pipe, over the query block's own tiles and four
+// on either side (see knn16_seed_mfma_kernel).  Q16 / Qn / Rt16 / scale_info / norm2_max as for meld_knn16_topk.
+extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
+                                               const float* norm2_max, int64_t n_ref, int d, int64_t q_begin,
+                                               int64_t q_count, int knn, double radius_factor, int nprod, float* thr_init,
+                                               meld_stream_t stream) {
+  MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && norm2_max && thr_init && n_ref > 0 && q_count > 0 && q_begin >= 0,
+                 "meld_knn16_seed_thresholds_mfma: bad arguments");
+  MELD_CHECK_ARG(q_begin % K16_BQ == 0, "meld_knn16_seed_thresholds_mfma: q_begin must be a multiple of the query block (%d)", K16_BQ);
+  MELD_CHECK_ARG(knn >= 1 && radius_factor >= 1.0 && (nprod == 1 || nprod == 3), "meld_knn16_seed_thresholds_mfma: bad kernel parameters");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int n_b = (int)ceil_div(q_count, K16_BQ);
+  hipStream_t st = S(stream);
+  if (knn + 1 > SEED_KMAX) {
+    MELD_HIP_CALL(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(thr_init), 0x7f800000, (size_t)n_b * K16_BQ, st));
+    return MELD_OK;
+  }
+  const float rf2 = (float)(radius_factor * radius_factor * (1.0 + 1e-6));
+  const int n_tiles = (int)ceil_div(n_ref, K16_TS);
+  // the hi-only products are what the kernel computes, whatever the search's nprod: charge the hi-only allowance
+  const float ec = (float)meld_knn16_error_coef_const(1, d), el = (float)meld_knn16_error_coef_lin(1);
+  (void)nprod;
+#define K16_SEEDM_LAUNCH(KBV, KV)                                                                                       \
+  hipLaunchKernelGGL((knn16_seed_mfma_kernel<KBV, KV>), dim3(n_b), dim3(256), 0, st,                                     \
+                     reinterpret_cast<const _Float16*>(Q16), Qn, reinterpret_cast<const _Float16*>(Rt16), scale_info,    \
+                     norm2_max, n_tiles, (int)(q_begin / K16_TS), knn + 1, rf2, ec, el, thr_init)
+#define K16_SEEDM_CASE(KBV)          \
+  case KBV:                          \
+    if (knn + 1 <= 16)               \
+      K16_SEEDM_LAUNCH(KBV, 16);     \
+    else                             \
+      K16_SEEDM_LAUNCH(KBV, 64);     \
+    break;
+  switch (KB) {
+    K16_SEEDM_CASE(1)
+    K16_SEEDM_CASE(2)
+    K16_SEEDM_CASE(3)
+    K16_SEEDM_CASE(4)
+    K16_SEEDM_CASE(5)
+    K16_SEEDM_CASE(6)
+    K16_SEEDM_CASE(7)
+    K16_SEEDM_CASE(8)
+    K16_SEEDM_CASE(9)
+    default:
+      set_err("meld_knn16_seed_thresholds_mfma: no kernel for %d K blocks", KB);
+      return MELD_ERR_UNSUPPORTED;
+  }
+#undef K16_SEEDM_CASE
+#undef K16_SEEDM_LAUNCH
+  MELD_LAUNCH_CHECK("knn16_seed_mfma_kernel");
   return MELD_OK;
 }
 

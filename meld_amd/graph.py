@@ -385,7 +385,10 @@ class HipOps:
             if self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
-                check(lib.meld_knn16_seed_thresholds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
+                if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
+                    check(lib.meld_knn16_seed_thresholds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
+                else:
+                    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
