@@ -268,10 +268,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints its version banner through C stdio, which (piped) is flushed at exit -- after Python's
-        # output; flush it now so that the JSON line is the last line on stdout
+        # RCCL prints its version banner through C stdio at communicator set-up, which (piped) would only be
+        # flushed at exit -- after Python's output; flush it now so that the JSON line is the last line on stdout.
+        # (Printed before the process group is torn down: a rank that is slow to leave cannot hold the result back.)
         import ctypes
 
         try:
@@ -279,6 +279,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
