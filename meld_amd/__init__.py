@@ -17,6 +17,7 @@ __all__ = [
     "build_knn_graph",
     "get_meld_cmap",
     "normalize_densities",
+    "VertexFrequencyCluster",
     "utils",
     "filter",
     "__version__",
@@ -29,8 +30,4 @@ def __getattr__(name):
         from .cluster import VertexFrequencyCluster
 
         return VertexFrequencyCluster
-    if name == "Benchmarker":
-        from .benchmark import Benchmarker
-
-        return Benchmarker
     raise AttributeError("module 'meld_amd' has no attribute {!r}".format(name))

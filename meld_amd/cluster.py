@@ -154,7 +154,7 @@ class VertexFrequencyCluster:
         if getattr(G, "_kdiag", None) is not None:
             kdiag = G._kdiag.to(dev)
         else:
-            kdiag = 1.0 / (G.ksum[:n] * G.ksum[:n]) ** G.anisotropy
+            kdiag = G.kernel_diagonal()[:n]
         K = W + torch.diag(kdiag)
         self._basewindow = K / K.sum(dim=1, keepdim=True)  # graphtools diff_op
         if np.all(np.diff(np.log2(self.window_sizes)) == 1):

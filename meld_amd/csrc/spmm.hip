@@ -278,11 +278,13 @@ extern "C" int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const 
                                int64_t n_rows, int64_t nnz_hint, int p, const double* x_full, int64_t x_row_offset,
                                const double* z, double* y, double* r, double alpha, double beta, double gamma,
                                double coef, double* dots, meld_stream_t stream) {
-  MELD_CHECK_ARG(rowptr && dw && x_full && y && n_rows > 0 && p >= 1, "meld_cheby_step: bad arguments");
+  MELD_CHECK_ARG(rowptr && dw && x_full && y && n_rows >= 0 && p >= 1, "meld_cheby_step: bad arguments");
   MELD_CHECK_ARG(gamma == 0.0 || z != nullptr, "meld_cheby_step: z is required when gamma != 0");
   MELD_CHECK_ARG(dots == nullptr || p == 1, "meld_cheby_step: dots are only produced for p == 1");
   hipStream_t st = S(stream);
   if (dots) MELD_HIP_CALL(hipMemsetAsync(dots, 0, sizeof(double) * 2 * DOT_SLOTS, st));
+  if (n_rows == 0) return MELD_OK;  // a rank of the row-sharded driver that owns no rows: nothing to compute, the
+                                    // partial sums stay zero and the caller still takes part in every collective
   constexpr int RB = 32;
   // LDS chunk: ~1.3x the mean span of RB rows, multiple of 256, within [512, 3072] entries
   const double mean_span = (nnz_hint > 0) ? (double)nnz_hint / (double)n_rows * RB : 1024.0;
@@ -356,7 +358,8 @@ extern "C" int meld_lanczos_spmv(const int64_t* rowptr, const int32_t* col, cons
                                  int64_t n_rows, int64_t nnz_hint, const double* x_full, int64_t x_row_offset,
                                  const double* z_local, double* y_local, const double* state, double* dots,
                                  meld_stream_t stream) {
-  MELD_CHECK_ARG(rowptr && dw && x_full && z_local && y_local && state && dots && n_rows > 0, "meld_lanczos_spmv: bad arguments");
+  MELD_CHECK_ARG(rowptr && dw && x_full && z_local && y_local && state && dots && n_rows >= 0, "meld_lanczos_spmv: bad arguments");
+  if (n_rows == 0) return MELD_OK;  // empty shard (the beta phase has zeroed the partial sums)
   constexpr int RB = 32;
   const double mean_span = (nnz_hint > 0) ? (double)nnz_hint / (double)n_rows * RB : 1024.0;
   const int chunk = (int)std::max<int64_t>(512, std::min<int64_t>((int64_t)(mean_span * 1.3) / 256 * 256 + 256, (48 * 1024) / 8 / 256 * 256));

@@ -60,11 +60,12 @@ class Comm:
         bounds = (torch.arange(1, self.world, dtype=torch.int64, device=dev) * rows_per_rank) << 32
         cuts = torch.searchsorted(keys_sorted, bounds)
         edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cuts, torch.tensor([keys_sorted.shape[0]], dtype=torch.int64, device=dev)])
-        send_counts = (edges[1:] - edges[:-1]).contiguous()
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        send_l = [int(v) for v in send_counts.cpu()]
-        recv_l = [int(v) for v in recv_counts.cpu()]
+        counts = torch.empty(2, self.world, dtype=torch.int64, device=dev)  # [0] what I send, [1] what I receive
+        counts[0] = edges[1:] - edges[:-1]
+        dist.all_to_all_single(counts[1], counts[0], group=self.group)
+        # the split sizes of the variable-length exchange have to be host integers: ONE read-back for both
+        counts_h = counts.cpu().tolist()
+        send_l, recv_l = counts_h[0], counts_h[1]
         n_recv = sum(recv_l)
         rk = torch.empty(n_recv, dtype=keys_sorted.dtype, device=dev)
         rv = torch.empty(n_recv, dtype=vals_sorted.dtype, device=dev)
@@ -157,6 +158,23 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     X = X.to(device=ops.device, dtype=torch.float64).contiguous()
     if op.thresh == 0 or op.n_landmark is not None or op.decay is None:
         raise NotImplementedError("the sharded builder supports the sparse alpha-decay kNN graph only")
+    unsupported = sorted(k for k in op.kwargs if k not in ("ksel",))
+    if unsupported:  # e.g. sample_idx (MNN graph): single-GPU only
+        raise NotImplementedError("graph options {} are not implemented by the row-sharded builder".format(unsupported))
+    # the same front end as the single-GPU path (MELD._build_graph): reject NaN / infinity, and build the
+    # graph on the PCA scores when n_pca < min(X.shape) (graphtools' Data._reduce_data; the reference's
+    # default n_pca=100 triggers it on wide data).  Every rank holds all of X and computes the same
+    # deterministic projection, so no communication is needed.
+    if X.dim() != 2:
+        raise ValueError("Expected a 2D data matrix, got shape {}".format(tuple(X.shape)))
+    if not bool(torch.isfinite(X).all()):
+        raise ValueError("Input data contains NaN or infinity")
+    op.data_nu = None
+    if op.n_pca is not None and op.n_pca < min(tuple(X.shape)):
+        from .pca import pca_project
+
+        X = pca_project(X, op.n_pca, seed=42 if op.random_state is None else int(op.random_state)).contiguous()
+        op.data_nu = X
     op.X = X
     op.graph = build_sharded_graph(
         X, ops, comm, knn=op.knn, decay=op.decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")

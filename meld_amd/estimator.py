@@ -148,11 +148,22 @@ class GraphEstimator(object):
         DataFrame, anything with ``.X`` like AnnData) or an already built ``DeviceGraph``."""
         from . import graph as _graph
 
-        if isinstance(X, _graph.DeviceGraph):
+        from .utils import _foreign_weights
+
+        if isinstance(X, _graph.DeviceGraph) or _foreign_weights(X) is not None:
+            # a prebuilt graph (reference meld/benchmark.py:194-195): ours, or one built elsewhere
+            # (graphtools / pygsp: uploaded once by utils._check_pygsp_graph)
+            from .utils import _check_pygsp_graph
+
             self._log("Using precomputed graph and diffusion operator...")
             self.X = None
-            self.graph = X
+            self.graph = _check_pygsp_graph(X)
+            self._graph_precomputed = True
             return self
+        if getattr(self, "_graph_precomputed", False):
+            # raw data after an adopted graph: that graph says nothing about these cells
+            self.graph = None
+            self._graph_precomputed = False
         try:
             import torch
         except ImportError:  # pragma: no cover

@@ -139,6 +139,36 @@ class DeviceGraph:
         dw = torch.from_numpy(np.ravel(W.sum(1)).astype(np.float64)).to(device)
         return cls(rowptr, col, val, dw, ksum=None, anisotropy=0.0)
 
+    @classmethod
+    def from_foreign(cls, G, W=None, device="cuda"):
+        """Adopt a graph object built elsewhere (graphtools / pygsp: anything with a square
+        scipy-sparse ``.W``): upload its weights, keep the spectral bound it already carries
+        (pygsp caches ``estimate_lmax`` in ``_lmax``; its ``estimate_lmax`` is then a no-op, and so
+        is ours) and, when it exposes graphtools' kernel ``.K``, the kernel's diagonal (used by
+        ``VertexFrequencyCluster``'s diffusion operator)."""
+        from scipy import sparse
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        W = sparse.csr_matrix(G.W if W is None else W)
+        if W.diagonal().any():
+            W = (W - sparse.diags(W.diagonal(), 0)).tocsr()  # weights carry no self loops (pygsp's W)
+            W.eliminate_zeros()
+        out = cls.from_scipy(W, device=device)
+        lm = getattr(G, "_lmax", None)
+        if lm is None and isinstance(getattr(type(G), "lmax", None), property) is False:
+            lm = getattr(G, "lmax", None)  # a plain attribute (not pygsp's computing property)
+        if lm is not None and np.isfinite(lm) and lm > 0:
+            out.lmax = float(lm)
+        try:
+            K = getattr(G, "K", None)
+        except Exception:
+            K = None
+        if K is not None and sparse.issparse(K) and K.shape == W.shape:
+            out._kdiag = torch.from_numpy(np.ascontiguousarray(K.diagonal(), dtype=np.float64)).to(device)
+        out.info["adopted_from"] = type(G).__name__
+        return out
+
     # -- pygsp-like surface -------------------------------------------------------------------
     @property
     def lmax(self):
@@ -150,7 +180,7 @@ class DeviceGraph:
     def lmax(self, value):
         self._lmax = None if value is None else float(value)
 
-    def estimate_lmax(self, recompute=False, tol=3e-4, max_iter=300):
+    def estimate_lmax(self, recompute=False, tol=3e-4, max_iter=300, method="lanczos"):
         """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
         ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
         tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos
@@ -160,11 +190,37 @@ class DeviceGraph:
         (same as pygsp), which is how parity tests inject a common lmax."""
         if self._lmax is not None and not recompute:
             return self._lmax
+        if method == "arpack":
+            return self._estimate_lmax_arpack()
+        if method != "lanczos":
+            raise ValueError("lmax method {!r} not recognized. Choose from ['lanczos', 'arpack']".format(method))
         from .filter import lanczos_lmax
 
         lam, info = lanczos_lmax(self, tol=tol, max_iter=max_iter)
         self._lmax = 1.01 * lam
         self.lmax_info = info
+        return self._lmax
+
+    def _estimate_lmax_arpack(self):
+        """The reference's own estimate, call for call ([UPSTREAM pygsp 0.5.1 ``Graph.estimate_lmax``] at
+        reference ``meld/filter.py:39``): the Laplacian is copied to the host once and
+        ``1.01 * scipy.sparse.linalg.eigsh(L, k=1, tol=5e-3, ncv=min(N, 10))`` is evaluated there
+        (``2 max(dw)`` if ARPACK does not converge).  Opt-in (``MELD(lmax="arpack")``): slower than the
+        device Lanczos and only converged to ARPACK's 5e-3, but it is the number the reference stack
+        computes -- with it an un-injected ``fit_transform`` meets the reference within its own
+        run-to-run spread (ARPACK's start vector comes from process-global state)."""
+        from scipy.sparse.linalg import ArpackNoConvergence, eigsh
+
+        if self.n_rows != self.N:
+            raise NotImplementedError("lmax='arpack' needs an unsharded graph")
+        L = self.L
+        try:
+            lam = eigsh(L, k=1, tol=5e-3, ncv=min(self.N, 10), return_eigenvectors=False)
+            self._lmax = 1.01 * float(lam[0])
+            self.lmax_info = dict(method="arpack", tol=5e-3)
+        except ArpackNoConvergence:  # pragma: no cover
+            self._lmax = 2.0 * float(np.max(self.dw))
+            self.lmax_info = dict(method="arpack", converged=False)
         return self._lmax
 
     # -- host exports in the caller's cell order (tests / inspection; not used by the hot path) -----
@@ -222,9 +278,18 @@ class DeviceGraph:
             raise ValueError("K is only defined for an unsharded graph")
         if getattr(self, "_kdiag", None) is not None:  # dense graph: the diagonal was computed explicitly
             return (self.W + sparse.diags(self._vec_host(self._kdiag), 0)).tocsr()
-        ks = self._vec_host(self.ksum)
-        diag = 1.0 / (ks * ks) ** self.anisotropy
-        return (self.W + sparse.diags(diag, 0)).tocsr()
+        return (self.W + sparse.diags(self._vec_host(self.kernel_diagonal()), 0)).tocsr()
+
+    def kernel_diagonal(self):
+        """Diagonal of the kernel matrix K in the device order: K_ii = 1 / (ksum_i^2)^anisotropy for a
+        graph built here (the alpha-decay kernel has 1 on its diagonal before the anisotropy
+        normalisation); 1 for an uploaded weight matrix that came without its kernel
+        (``from_scipy``: the kernel's own diagonal before any normalisation)."""
+        if getattr(self, "_kdiag", None) is not None:
+            return self._kdiag
+        if self.ksum is None:
+            return torch.ones(self.N, dtype=torch.float64, device=self.val.device)
+        return 1.0 / (self.ksum * self.ksum) ** self.anisotropy
 
 
 def _scan_i32(lib, x, st):

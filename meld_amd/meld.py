@@ -41,7 +41,9 @@ class MELD(GraphEstimator):
     anisotropy : default 1;  n_landmark : default None (landmarking is not implemented)
     **kwargs : graph parameters -- knn=5, decay=40, n_pca=100, thresh=1e-4,
         distance='euclidean', n_jobs, random_state, verbose; ``ksel`` (candidate list length of the
-        GPU search) and ``lmax`` (inject the Laplacian's spectral bound) are extensions.
+        GPU search) and ``lmax`` are extensions: a number injects the Laplacian's spectral bound,
+        ``"arpack"`` computes it exactly as the reference stack does (pygsp's ``eigsh`` call, on the
+        host), default: a tightly converged Lanczos recurrence on the device.
     """
 
     # class-level defaults differ from the __init__ defaults exactly as in reference meld/meld.py:42-92
@@ -306,7 +308,10 @@ class MELD(GraphEstimator):
             self._indicator_scale = 1.0 / counts
             self._sample_indicators = None
 
-        if self._lmax_override is not None:
+        if isinstance(self._lmax_override, str):
+            # "arpack": the reference's own estimate on the host (pygsp's eigsh call); "lanczos": the default
+            self.graph.estimate_lmax(method=self._lmax_override)
+        elif self._lmax_override is not None:
             self.graph.lmax = self._lmax_override
         # the signal is a scaled one-hot: hand the filter the label codes (4 B per cell over PCIe instead
         # of 8p) and let it assemble the [N, p] matrix on the device

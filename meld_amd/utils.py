@@ -7,14 +7,40 @@ import pandas as pd
 __all__ = ["_check_pygsp_graph", "get_meld_cmap", "normalize_densities"]
 
 
+def _foreign_weights(G):
+    """The scipy-sparse weight matrix of a graph object built elsewhere (graphtools / pygsp graphs
+    expose it as ``.W``), or None when ``G`` does not look like such a graph."""
+    from scipy import sparse
+
+    if isinstance(G, np.ndarray) or sparse.issparse(G):
+        return None
+    try:
+        W = getattr(G, "W", None)
+    except Exception:  # a property that fails is not a graph we can adopt
+        return None
+    if W is None or not sparse.issparse(W) or W.shape[0] != W.shape[1]:
+        return None
+    n = getattr(G, "N", None)
+    if n is not None and int(n) != W.shape[0]:
+        return None
+    return W
+
+
 def _check_pygsp_graph(G):
     """Type guard of reference ``meld/utils.py:11-20``.  The reference accepts graphtools graphs
-    (converting non-PyGSP ones); here the accepted type is the device-resident ``DeviceGraph``.
-    Anything else raises the reference's ``TypeError`` (message pinned by ``test/test_meld.py:22-28``)."""
+    (converting non-PyGSP ones with ``to_pygsp()``); here the graph the filter runs on is the
+    device-resident ``DeviceGraph``, and a graph built elsewhere -- anything exposing a square
+    scipy-sparse ``.W`` (graphtools / pygsp graphs do; reference ``meld/benchmark.py:194-195``,
+    ``test/test_utils.py:11-13``) -- is uploaded once (``DeviceGraph.from_scipy``), keeping an
+    ``lmax`` the graph already carries.  Anything else raises the reference's ``TypeError``
+    (message pinned by ``test/test_meld.py:22-28``)."""
     from .graph import DeviceGraph
 
     if isinstance(G, DeviceGraph):
         return G
+    W = _foreign_weights(G)
+    if W is not None:
+        return DeviceGraph.from_foreign(G, W)
     raise TypeError(
         "Input graph should be of type graphtools.base.BaseGraph."
         " With graphtools, use the `use_pygsp=True` flag."

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out_path, n, d, knn, n_labels):
+def main(out_path, n, d, knn, n_labels, n_pca=0):
     dist.init_process_group("gloo")
     import meld_amd
     from meld_amd import distributed as mdist
@@ -21,7 +21,7 @@ def main(out_path, n, d, knn, n_labels):
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     if n_labels == 3:
         labels = np.random.default_rng(1).choice(["A", "B", "C"], size=n)
-    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
     G = op.graph
     np.savez(
@@ -33,4 +33,4 @@ def main(out_path, n, d, knn, n_labels):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]) if len(sys.argv) > 6 else 0)

@@ -117,6 +117,87 @@ def test_prebuilt_graph_and_repeated_transform():
     np.testing.assert_allclose(lik.values.sum(1), 1.0)
 
 
+def test_fit_adopts_a_graph_built_elsewhere():
+    """reference meld/utils.py:11-20, meld/benchmark.py:194-195, test/test_utils.py:11-13: ``fit(G)`` /
+    ``fit_transform(G, labels)`` with a graphtools / pygsp graph object.  Here any object exposing a square
+    scipy-sparse ``.W`` (and optionally a cached ``_lmax``) is uploaded; the oracle-built graph stands in for
+    the foreign one.  The result equals the oracle's filter on that very graph."""
+    meld = _meld()
+    from oracle import meld_oracle as mo
+
+    X, labels = mo.synthetic_cells(2500, n_dims=20, seed=6)
+    G = mo.build_graph(X, knn=10, algorithm="brute")
+    lmax = mo.estimate_lmax(G.L, G.dw)
+
+    class ForeignGraph:  # what graphtools' PyGSP graph offers on this path
+        def __init__(self, W, lm):
+            self.W, self.N, self._lmax = W, W.shape[0], lm
+
+    fg = ForeignGraph(G.W, lmax)
+    op = meld.MELD(chebyshev_order=30)
+    out = op.fit_transform(fg, labels)
+    assert isinstance(op.graph, meld.DeviceGraph) and op.graph.N == 2500 and op.graph.lmax == lmax
+    samples, ind = mo.sample_indicators(labels)
+    ref = mo.meld_filter(ind, G, beta=60, chebyshev_order=30, lmax=lmax)
+    assert list(out.columns) == list(samples)
+    assert np.abs(out.values - ref).max() <= 1e-5 * np.abs(ref).max()
+    # the guard itself: converts, and keeps raising the reference's TypeError for non-graphs
+    assert isinstance(meld.utils._check_pygsp_graph(fg), meld.DeviceGraph)
+    for bad in ("hello world", np.zeros((3, 3)), G.W):
+        with pytest.raises(TypeError, match="Input graph should be of type graphtools.base.BaseGraph"):
+            meld.utils._check_pygsp_graph(bad)
+    # VertexFrequencyCluster on an uploaded graph without its kernel (ksum unknown: diagonal 1)
+    sub = ForeignGraph(G.W[:600][:, :600].tocsr(), None)
+    vfc = meld.VertexFrequencyCluster(n_clusters=2, window_sizes=[1, 2]).fit(sub)
+    assert vfc.N == 600
+    # raw data after an adopted graph rebuilds instead of keeping the stale graph
+    X2, _ = mo.synthetic_cells(2500, n_dims=20, seed=7)
+    op.fit(X2)
+    assert op.graph.info.get("adopted_from") is None and op.graph.N == 2500
+    assert abs(op.graph.W - mo.build_graph(X2, knn=5, algorithm="brute").W).max() < 1e-9
+
+
+def test_arpack_lmax_mode_reproduces_the_reference_estimate():
+    """``MELD(lmax="arpack")``: pygsp's estimate itself (eigsh(L, k=1, tol=5e-3, ncv=10) * 1.01, reference
+    meld/filter.py:39) evaluated on the host, so that an UN-injected fit_transform lands on the reference's
+    numbers.  ARPACK's start vector comes from process-global state, so both sides are evaluated in fresh
+    processes (first eigsh call of the process each): they then agree to rounding and the densities meet the
+    1e-5 bar without a common injected lmax."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code_ref = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "from oracle import meld_oracle as mo\n"
+        "X, labels = mo.synthetic_cells(3000, n_dims=50, seed=3)\n"
+        "s, d, G = mo.fit_transform(X, labels, knn=15, chebyshev_order=30, return_graph=True, algorithm='brute')\n"
+        "np.save(sys.argv[1], d); print(repr(G.lmax))\n" % root)
+    code_dev = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "import meld_amd\nfrom bench import synthetic_cells\n"
+        "X, labels = synthetic_cells(3000, 50, seed=3)\n"
+        "op = meld_amd.MELD(knn=15, chebyshev_order=30, lmax='arpack')\n"
+        "d = op.fit_transform(X, labels)\n"
+        "np.save(sys.argv[1], d.values); print(repr(op.graph.lmax)); print(op.graph.lmax_info['method'])\n" % root)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        a = subprocess.run([sys.executable, "-c", code_ref, os.path.join(tmp, "ref.npy")], capture_output=True, text=True, timeout=600)
+        b = subprocess.run([sys.executable, "-c", code_dev, os.path.join(tmp, "dev.npy")], capture_output=True, text=True, timeout=600)
+        assert a.returncode == 0, a.stderr[-2000:]
+        assert b.returncode == 0, b.stderr[-2000:]
+        lm_ref = float(a.stdout.strip().splitlines()[-1])
+        lines = [ln for ln in b.stdout.strip().splitlines() if ln.strip()]
+        lm_dev = float(lines[-2])
+        assert lines[-1] == "arpack"
+        ref, dev = np.load(os.path.join(tmp, "ref.npy")), np.load(os.path.join(tmp, "dev.npy"))
+    assert abs(lm_dev - lm_ref) <= 1e-9 * lm_ref, (lm_dev, lm_ref)
+    assert np.abs(dev - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(ValueError, match="not recognized"):
+        _meld().MELD(lmax="power").fit_transform(np.random.default_rng(0).normal(size=(200, 3)), np.arange(200) % 2)
+
+
 def test_unsupported_options_fail_loudly():
     meld = _meld()
     data = np.random.normal(size=(100, 2))
@@ -319,40 +400,6 @@ def test_non_finite_input_is_rejected():
     Xt = torch.from_numpy(np.where(np.isnan(X), np.inf, X)).cuda()
     with pytest.raises(ValueError, match="NaN or infinity"):
         meld.MELD(verbose=0).fit(Xt)
-
-
-@pytest.mark.gpu
-def test_benchmarker_pipeline_matches_the_oracle():
-    """reference test/test_benchmark.py:9-29 without PHATE (absent here: the 3-D embedding is supplied):
-    ground-truth pdf -> labels -> graph with graphtools' defaults (n_pca=100, anisotropy=0) -> MELD
-    likelihood -> MSE, against the same pipeline on the oracle."""
-    meld = _meld()
-    mo = _oracle()
-    np.random.seed(0)
-    data = np.random.normal(0, 2, (300, 200)) + np.outer(np.linspace(-3, 3, 300), np.ones(200))
-    emb = mo.pca_reduce(data, 3)
-    b = meld.Benchmarker(seed=0)
-    b.set_phate(emb)
-    pdf = b.generate_ground_truth_pdf()
-    b.generate_sample_labels()
-    lik = b.calculate_MELD_likelihood(data=data)  # implicitly fits the graph
-    mse = b.calculate_mse(b.expt_likelihood)
-    assert lik.shape == (300,) and 0.0 <= mse < 0.25
-    G = mo.build_graph(mo.pca_reduce(data, 100), knn=5, anisotropy=0)
-    assert abs(b.graph.W - G.W).max() <= 1e-8
-    lmax = mo.estimate_lmax(G.L, G.dw)
-    b2 = meld.Benchmarker(seed=0)
-    b2.set_phate(emb)
-    b2.generate_ground_truth_pdf()
-    b2.generate_sample_labels()
-    b2.fit_graph(data)
-    b2.graph.lmax = lmax
-    lik2 = b2.calculate_MELD_likelihood()
-    ind = mo.sample_indicators(b2.sample_labels)
-    dens = mo.meld_filter(ind[1], G, beta=60, chebyshev_order=50, lmax=lmax)
-    ref = mo.normalize_densities(dens)[:, list(ind[0]).index("expt")]
-    assert np.abs(lik2 - ref).max() <= 1e-5 * np.abs(ref).max()
-    assert b2.calculate_mse(lik2) == pytest.approx(float(np.mean((pdf - ref) ** 2)), rel=1e-6)
 
 
 @pytest.mark.gpu
