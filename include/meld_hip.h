@@ -286,6 +286,53 @@ int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_
 int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, double* nrm2,
                    meld_stream_t stream);
 
+/* ---- panel-tiled layout of W for the recurrence (csrc/spmm_tiled.hip) --------------------------
+ * Same operator and same call sites as meld_cheby_step / meld_lanczos_* ([UPSTREAM pygsp cheby_op /
+ * estimate_lmax] at reference meld/filter.py:59 / :39), on a copy of W laid out so that the iterate is
+ * staged in LDS tile by tile instead of being gathered per nonzero: rows in nb nnz-balanced blocks (one
+ * per CU), per block the sorted list of the distinct columns it touches cut into tiles of tile_cols
+ * columns, the block's nonzeros re-ordered by (owner wave, tile, row, column).  Built once per graph.
+ * All arrays are device memory owned by the caller:
+ *   blk_row   [nb + 1]  int32   first row of every block
+ *   blk_ntile [nb]      int32   tiles of the block (-1: the block could not be laid out, see status)
+ *   blk_ndist [nb]      int32   distinct columns of the block
+ *   seg       [meld_pt_seg_len(nb)] int32  per (block, wave, tile) entry offsets
+ *   list_cols [nnz]     int32   block b's sorted distinct columns start at rowptr[blk_row[b]]
+ *   pval      [nnz]     fp64    values in layout order
+ *   pidx      [nnz]     uint32  tile-local column | row slot << log2(tile_cols)                   */
+typedef struct meld_pt_layout {
+  const int32_t* blk_row;
+  const int32_t* blk_ntile;
+  const int32_t* blk_ndist;
+  const int32_t* seg;
+  const int32_t* list_cols;
+  const double* pval;
+  const uint32_t* pidx;
+  int32_t nb;
+} meld_pt_layout_t;
+int meld_pt_geometry(int* consumer_waves, int* rows_max, int* tile_cols, int* tiles_max);
+int meld_pt_num_blocks(int64_t n_rows); /* nb the builder wants for n_rows local rows */
+int64_t meld_pt_seg_len(int nb);
+/* timing-only ablations of the step kernel (tools/spmm_compare.py); results are wrong while mask != 0 */
+int meld_pt_debug_ablate(int mask);
+/* Build the layout of the local rows [0, n_rows) of a CSR matrix with n_cols columns (the arrays of
+ * `layout` are written).  status[1] (device) receives 0, or the reason the layout cannot be used:
+ * 1 = a block touches too many column panels, 2 = too many distinct columns in a block,
+ * 3 = n_cols beyond the builder's index range -- the caller then stays on meld_cheby_step. */
+int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, int64_t n_rows, int64_t n_cols,
+                  const meld_pt_layout_t* layout, int32_t* status, meld_stream_t stream);
+/* meld_cheby_step on the layout (p = 1, 2 or any p as passes of 2 + 1 columns; dots as there). */
+int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
+                       const double* x_full, int64_t x_row_offset, const double* z, double* y, double* r,
+                       double alpha, double beta, double gamma, double coef, double* dots, meld_stream_t stream);
+/* meld_lanczos_steps / meld_lanczos_spmv on the layout (same contracts). */
+int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
+                          double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,
+                          int it_begin, int n_iter, double* scratch, meld_stream_t stream);
+int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
+                         const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
+                         const double* state, double* dots, meld_stream_t stream);
+
 /* ---- cache-locality ordering helper (no reference counterpart; csrc/reorder.hip) ---------- */
 /* out[i] = index (within its group) of the centroid nearest to X[i]; cents holds n_per_group
  * centroids per group, group[i] selects the group of point i (NULL = one shared set).  order

@@ -80,12 +80,29 @@ SIGNATURES = {
     "meld_lanczos_alpha": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_lanczos_axpy": (_i32, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_lanczos_beta": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "meld_pt_geometry": (_i32, [_ptr, _ptr, _ptr, _ptr]),
+    "meld_pt_num_blocks": (_i32, [_i64]),
+    "meld_pt_seg_len": (_i64, [_i32]),
+    "meld_pt_debug_ablate": (_i32, [_i32]),
+    "meld_pt_build": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr]),
+    "meld_pt_cheby_step": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr]),
+    "meld_pt_lanczos_steps": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
+    "meld_pt_lanczos_spmv": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
     "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
 }
+
+
+
+class PtLayout(C.Structure):
+    """``meld_pt_layout_t`` of include/meld_hip.h (device pointers of the panel-tiled copy of W)."""
+
+    _fields_ = [("blk_row", _ptr), ("blk_ntile", _ptr), ("blk_ndist", _ptr), ("seg", _ptr), ("list_cols", _ptr),
+                ("pval", _ptr), ("pidx", _ptr), ("nb", C.c_int32)]
+
 
 _lib = None
 

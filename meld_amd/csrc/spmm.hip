@@ -368,6 +368,43 @@ extern "C" int meld_lanczos_spmv(const int64_t* rowptr, const int32_t* col, cons
   MELD_LAUNCH_CHECK("meld_lanczos_spmv");
   return MELD_OK;
 }
+// The same two drivers on the panel-tiled layout (spmm_tiled.hip).
+extern "C" int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
+                                     double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,
+                                     int it_begin, int n_iter, double* scratch, meld_stream_t stream) {
+  MELD_CHECK_ARG(layout && rowptr && dw && v0 && v1 && v2 && state && alphas && betas && scratch && n_rows > 0 &&
+                     it_begin >= 0 && n_iter >= 0,
+                 "meld_pt_lanczos_steps: bad arguments");
+  hipStream_t st = S(stream);
+  double* V[3] = {v0, v1, v2};
+  double* dots = scratch;
+  double* nrm2 = scratch + 2 * DOT_SLOTS;
+  const unsigned grid_ax = (unsigned)std::min<int64_t>(2048, ceil_div(n_rows, 256));
+  for (int it = it_begin; it < it_begin + n_iter; ++it) {
+    double* u_prev = V[it % 3];
+    double* u = V[(it + 1) % 3];
+    double* y = V[(it + 2) % 3];
+    const int rc = pt_step(layout, rowptr, dw, 1, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots, state, st);
+    if (rc != MELD_OK) return rc;
+    hipLaunchKernelGGL(lanczos_alpha_kernel, dim3(1), dim3(64), 0, st, state, dots, nrm2, alphas, it);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_ax), dim3(256), 0, st, 0.0, u, 1.0, y, n_rows, nrm2, state + 5);
+    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it);
+  }
+  MELD_LAUNCH_CHECK("meld_pt_lanczos_steps");
+  return MELD_OK;
+}
+extern "C" int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
+                                    const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
+                                    const double* state, double* dots, meld_stream_t stream) {
+  MELD_CHECK_ARG(layout && rowptr && dw && x_full && z_local && y_local && state && dots && n_rows >= 0,
+                 "meld_pt_lanczos_spmv: bad arguments");
+  if (n_rows == 0) return MELD_OK;
+  const int rc = pt_step(layout, rowptr, dw, 1, x_full, x_row_offset, z_local, y_local, nullptr, 0.0, 0.0, 0.0, 0.0, dots,
+                         state, S(stream));
+  if (rc != MELD_OK) return rc;
+  MELD_LAUNCH_CHECK("meld_pt_lanczos_spmv");
+  return MELD_OK;
+}
 extern "C" int meld_lanczos_alpha(double* state, const double* dots, double* nrm2, double* alphas, int it,
                                   meld_stream_t stream) {
   MELD_CHECK_ARG(state && dots && nrm2 && alphas && it >= 0, "meld_lanczos_alpha: bad arguments");

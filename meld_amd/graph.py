@@ -308,8 +308,11 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device=None, search=None, prune=None, nprod=None):
+    def __init__(self, device=None, search=None, prune=None, nprod=None, spmm=None):
         self.lib = get_lib()
+        # recurrence kernel: "auto" (panel-tiled layout for graphs of at least PT_MIN_ROWS local rows),
+        # "tiled" (always), "csr" (the CSR-stream kernel of spmm.hip)
+        self.spmm = spmm
         # precision of the f16x3 search on the coordinate K blocks: 1 = fp16 hi parts only (half the MFMAs,
         # error bound 2^-9 max|x|^2), 3 = full hi/lo split (2^-16).  Either way the result is exact: rows
         # the bound cannot certify go through the exact sweep.
@@ -686,7 +689,59 @@ class HipOps:
     def dot_slots(self):
         return self.lib.meld_spmm_dot_slots()
 
+    # ---- panel-tiled copy of W for the recurrence (csrc/spmm_tiled.hip) -----------------------------
+    PT_MIN_ROWS = 65536  # below this the CSR-stream kernel is launch-bound anyway and the layout does not pay
+
+    def pt_layout(self, G):
+        """The panel-tiled layout of ``G``'s local rows, built on first use and kept on the graph
+        (``G.pt``); None when the graph stays on the CSR-stream kernel (small graphs, ``spmm="csr"``, or a
+        graph the builder cannot lay out -- recorded in ``G.info["spmm"]``)."""
+        pt = getattr(G, "pt", None)
+        if pt is not None:
+            return pt if pt is not False else None
+        mode = getattr(self, "spmm", None) or os.environ.get("MELD_SPMM", "auto")
+        G.info["spmm"] = "csr"
+        G.pt = False
+        if mode == "csr" or G.n_rows == 0 or G.nnz == 0 or not G.val.is_cuda:
+            return None
+        if mode == "auto" and G.n_rows < self.PT_MIN_ROWS:
+            return None
+        from ._lib import PtLayout
+        import ctypes as C
+
+        lib, dev = self.lib, G.val.device
+        nb = int(lib.meld_pt_num_blocks(G.n_rows))
+        i32 = dict(dtype=torch.int32, device=dev)
+        t = dict(
+            blk_row=torch.empty(nb + 1, **i32), blk_ntile=torch.empty(nb, **i32), blk_ndist=torch.empty(nb, **i32),
+            seg=torch.empty(int(lib.meld_pt_seg_len(nb)), **i32), list_cols=torch.empty(G.nnz, **i32),
+            pval=torch.empty(G.nnz, dtype=torch.float64, device=dev), pidx=torch.empty(G.nnz, **i32),
+        )
+        status = torch.zeros(1, **i32)
+        lay = PtLayout(*(t[k].data_ptr() for k in ("blk_row", "blk_ntile", "blk_ndist", "seg", "list_cols", "pval", "pidx")), nb)
+        with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
+            check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, C.byref(lay), ptr(status), _stream()),
+                  "meld_pt_build")
+        st = int(status.item())
+        if st != 0:  # cannot be laid out (see include/meld_hip.h): stay on the CSR-stream kernel
+            G.info["spmm"] = "csr (tiled layout refused: status {})".format(st)
+            return None
+        G.pt = dict(struct=lay, tensors=t, nb=nb)
+        G.info["spmm"] = "tiled"
+        return G.pt
+
     def cheby_step(self, G, p, x_full, x_row_off, z, y, r, alpha, beta, gamma, coef, dots=None):
+        pt = self.pt_layout(G)
+        if pt is not None:
+            import ctypes as C
+
+            check(
+                self.lib.meld_pt_cheby_step(C.byref(pt["struct"]), ptr(G.rowptr), ptr(G.dw_dev), G.n_rows, p, ptr(x_full), x_row_off,
+                                            ptr(z), ptr(y), ptr(r), float(alpha), float(beta), float(gamma), float(coef),
+                                            ptr(dots), _stream()),
+                "meld_pt_cheby_step",
+            )
+            return
         check(
             self.lib.meld_cheby_step(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz, p, ptr(x_full),
                                      x_row_off, ptr(z), ptr(y), ptr(r), float(alpha), float(beta), float(gamma),
@@ -697,6 +752,17 @@ class HipOps:
     def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch):
         """Iterations [it_begin, it_begin + n_iter) of the device-resident Lanczos recurrence
         (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors."""
+        pt = self.pt_layout(G)
+        if pt is not None:
+            import ctypes as C
+
+            check(
+                self.lib.meld_pt_lanczos_steps(C.byref(pt["struct"]), ptr(G.rowptr), ptr(G.dw_dev), G.n_rows, ptr(V[0]), ptr(V[1]),
+                                               ptr(V[2]), ptr(state), ptr(alphas), ptr(betas), int(it_begin), int(n_iter),
+                                               ptr(scratch), _stream()),
+                "meld_pt_lanczos_steps",
+            )
+            return
         check(
             self.lib.meld_lanczos_steps(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz, ptr(V[0]), ptr(V[1]),
                                         ptr(V[2]), ptr(state), ptr(alphas), ptr(betas), int(it_begin), int(n_iter), ptr(scratch), _stream()),
@@ -705,6 +771,13 @@ class HipOps:
 
     # the same iteration as four stream-ordered phases (row-sharded driver; see filter._lanczos_lmax_phases)
     def lanczos_spmv(self, G, x_full, z_local, y_local, state, dots):
+        pt = self.pt_layout(G)
+        if pt is not None:
+            import ctypes as C
+
+            check(self.lib.meld_pt_lanczos_spmv(C.byref(pt["struct"]), ptr(G.rowptr), ptr(G.dw_dev), G.n_rows, ptr(x_full), G.row_begin,
+                                                ptr(z_local), ptr(y_local), ptr(state), ptr(dots), _stream()), "meld_pt_lanczos_spmv")
+            return
         check(self.lib.meld_lanczos_spmv(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, G.nnz, ptr(x_full), G.row_begin,
                                          ptr(z_local), ptr(y_local), ptr(state), ptr(dots), _stream()), "meld_lanczos_spmv")
 
