@@ -62,45 +62,112 @@ def synthetic_cells(n_cells, n_dims=50, seed=0, latent_dim=10, n_clusters=20):
     return np.ascontiguousarray(X, dtype=np.float64), labels
 
 
-def cpu_baseline(sample_cells, dims, knn, beta, order):
-    """Oracle (kind='port') on a bounded sample, faithful configuration of the reference stack:
-    sklearn ball_tree kNN with n_jobs=1 (graphtools' defaults) and single-threaded scipy SpMM."""
+def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=False):
+    """Oracle (kind='port': the in-repo scipy/sklearn restatement of the reference path, oracle/meld_oracle.py)
+    timed on this box's host cores, SURVEY.md section 8(d): the reference stack's own configuration -- sklearn
+    ball_tree kNN with n_jobs=1 (graphtools' defaults) and single-threaded scipy CSR products -- on three
+    sample sizes; the kNN is super-linear in N, so the exponent is fitted and the figure at the benchmark size
+    is EXTRAPOLATED and labelled as such.  `value` is the measured rate of the largest sample."""
     from oracle import meld_oracle as mo
 
-    X, labels = mo.synthetic_cells(sample_cells, n_dims=dims, seed=0)
-    t0 = time.perf_counter()
-    mo.fit_transform(X, labels, knn=knn, beta=beta, chebyshev_order=order, algorithm="ball_tree", n_jobs=1)
-    t_ref = time.perf_counter() - t0
+    sizes = [50_000, 100_000, 200_000] if full_protocol else [sample_cells // 4, sample_cells // 2, sample_cells]
+    runs = []
+    for n in sizes:
+        X, labels = mo.synthetic_cells(n, n_dims=dims, seed=0)
+        t0 = time.perf_counter()
+        mo.fit_transform(X, labels, knn=knn, beta=beta, chebyshev_order=order, algorithm="ball_tree", n_jobs=1)
+        runs.append((n, time.perf_counter() - t0))
+    ln = np.log([r[0] for r in runs])
+    lt = np.log([r[1] for r in runs])
+    expo, icpt = np.polyfit(ln, lt, 1)
+    t_target = float(np.exp(icpt + expo * math.log(n_target)))
+    n_big, t_big = runs[-1]
+    X, labels = mo.synthetic_cells(n_big, n_dims=dims, seed=0)
     t0 = time.perf_counter()
     mo.fit_transform(X, labels, knn=knn, beta=beta, chebyshev_order=order, algorithm="brute", n_jobs=-1)
     t_best = time.perf_counter() - t0
     return {
-        "value": sample_cells / t_ref,
+        "value": n_big / t_big,
         "unit": "cells/s",
         "cores": 1,
         "kind": "port",
         "sample": "N={} cells x {} dims, full fit_transform, sklearn ball_tree n_jobs=1 + scipy CSR (the reference "
-        "stack's defaults); {:.1f} s".format(sample_cells, dims, t_ref),
+        "stack's defaults); {:.1f} s".format(n_big, dims, t_big),
+        "runs": [{"cells": n, "seconds": round(t, 2), "cells_per_s": n / t} for n, t in runs],
+        "fitted_exponent": float(expo),
+        "extrapolated": {
+            "cells": int(n_target),
+            "seconds": t_target,
+            "cells_per_s": n_target / t_target,
+            "note": "EXTRAPOLATED from the three runs above with t ~ N^{:.2f}; not measured".format(expo),
+        },
+        "host_cores_available": os.cpu_count(),
         "best_effort": {
-            "value": sample_cells / t_best,
+            "value": n_big / t_best,
             "cores": os.cpu_count(),
-            "note": "same sample with sklearn brute-force kNN on all host cores (n_jobs=-1); {:.1f} s; "
-            "kNN is O(N^2): cells/s at 1M cells would be ~{}x lower".format(t_best, int(1_000_000 / sample_cells)),
+            "note": "same {}-cell sample with sklearn brute-force kNN on all host cores (n_jobs=-1); {:.1f} s".format(n_big, t_best),
         },
     }
+
+
+def cpu_chebyshev_full_size(G, labels, beta, order):
+    """The filter stage of the CPU oracle at the FULL benchmark size, on the device-built CSR: D2H of
+    W, pygsp-style recurrence in scipy (single-threaded CSR x dense), checked against the device result."""
+    from scipy import sparse
+
+    from meld_amd import filter as mfilter
+    from oracle import meld_oracle as mo
+
+    import torch
+
+    n = G.N
+    W = sparse.csr_matrix((G.val.cpu().numpy(), G.col.cpu().numpy(), G.rowptr.cpu().numpy()), shape=(n, n))
+    L = (sparse.diags(G.dw_dev.cpu().numpy(), 0) - W).tocsr()
+    lmax = G.lmax
+    c = mo.cheby_coeff(mo.filter_kernel_fn("heat", beta, 0, 1, lmax), lmax, order)
+    _, ind = mo.sample_indicators(labels)
+    perm = G.perm.cpu().numpy() if G.perm is not None else np.arange(n)
+    s_int = np.ascontiguousarray(ind[perm])
+    t0 = time.perf_counter()
+    ref = mo.cheby_op(L, lmax, c, s_int)
+    t_cpu = time.perf_counter() - t0
+    out = mfilter.chebyshev_apply(G, torch.from_numpy(s_int).cuda(), c, lmax).cpu().numpy()
+    return {
+        "cells": n,
+        "seconds": t_cpu,
+        "cores": 1,
+        "what": "oracle cheby_op (scipy CSR x dense, {} products) on the device-built W, measured at full size".format(order),
+        "max_rel_diff_vs_device": float(np.abs(out - ref).max() / np.abs(ref).max()),
+    }
+
+
+def measured_traffic(kernel, n_cells, dims):
+    """HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/pmc/traffic.json, written by
+    tools/pmc_traffic.py from TCC_EA0_RDREQ / WRREQ as MI355X_MICROARCH.md prescribes), when one was taken for this
+    kernel at this problem size; None otherwise (a bench run itself collects no counters)."""
+    path = os.path.join(ROOT, "profiles", "pmc", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec = table.get("{}@{}x{}".format(kernel, n_cells, dims))
+    return rec
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=1_000_000)
     ap.add_argument("--dims", type=int, default=50)
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--beta", type=float, default=60)
     ap.add_argument("--order", type=int, default=30)
-    ap.add_argument("--cpu-sample", type=int, default=40000, help="cells in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=40000, help="largest CPU-baseline sample (0 = skip); also run at 1/2 and 1/4 of it")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline at 50k / 100k / 200k cells (SURVEY 8d protocol; minutes)")
+    ap.add_argument("--no-host-input", action="store_true", help="skip the extra untimed-region passes with X on the host")
     ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded driver even with one rank (testing)")
     args = ap.parse_args()
@@ -150,12 +217,25 @@ def main():
     mgraph.record_events(True)
     barrier()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
-        op, dens = one_step()
+        ts = time.perf_counter()
+        op, dens = one_step()  # (synchronous: the densities come back as a host DataFrame)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     elapsed = time.perf_counter() - t0
     ev = mgraph.event_times_ms()
     mgraph.record_events(False)
+    # the same step with X handed over as a HOST array (SURVEY 8d counts the H2D copy; `value` does not)
+    host_ms = []
+    if world == 1 and not args.no_host_input:
+        X_host = X.cpu().numpy()
+        for i in range(4):
+            ts = time.perf_counter()
+            meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0).fit_transform(X_host, labels)
+            if i > 0:
+                host_ms.append(1e3 * (time.perf_counter() - ts))
+        del X_host
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -164,6 +244,7 @@ def main():
     G = op.graph
     nnz = int(G.info.get("nnz_global", G.nnz))
     p = dens.shape[1]
+    G.estimate_lmax()
     out = {
         "metric": "cells/sec through MELD.fit_transform (kNN+Chebyshev)",
         "value": N * args.steps / elapsed,
@@ -172,15 +253,21 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_median": float(np.median(step_ms)),
+        "ms_per_step_all": [round(t, 3) for t in step_ms],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "{} cells x {} dims (BASELINE configs[3] size), 20-cluster 10-d latent mixture, seed 0; "
+            "workload": "{} cells x {} dims ({}), 20-cluster 10-d latent mixture, seed 0; X resident in HBM (fp64) when the "
+            "timed region starts, labels host strings, densities back as a host DataFrame; "
             "knn={}, decay=40, thresh=1e-4, anisotropy=1, beta={}, heat filter, chebyshev_order={}, p={} labels".format(
-                N, d, args.knn, args.beta, args.order, p),
+                N, d, {1_000_000: "BASELINE configs[3] size, the size the metric is quoted on", 500_000: "BASELINE configs[2]",
+                       50_000: "BASELINE configs[1]"}.get(N, "custom size"), args.knn, args.beta, args.order, p),
+            "spmm_kernel": G.info.get("spmm"),
+            "search_options": {k: G.info.get(k) for k in ("search", "nprod", "prune", "radius_cut", "seed") if k in G.info},
             "parallelism": "single GPU" if world == 1 else "rows sharded over {} GPUs, all-gather per Chebyshev step".format(world),
             "nnz_W": nnz,
             "mean_degree": nnz / N,
@@ -217,17 +304,20 @@ def main():
         out["roofline"] = {
             "kernel": kname,
             "bound": "mfma",
-            "achieved": flops / t_knn / 1e12,
+            # achieved / frac = flops ISSUED to the matrix pipe per kernel time (the kernel's own count of computed
+            # 64 x 64 blocks x K padded to a multiple of 16): a utilisation.  The brute-force-equivalent rate
+            # 2 N^2 d / t (SURVEY 8d's algorithmic figure) is kept beside it: with exact pruning it says how much
+            # faster than the specified GEMM the kernel is, not how busy the pipe is.
+            "achieved": executed / t_knn / 1e12,
             "peak": peak,
             "unit": "TFLOP/s",
-            "frac": flops / t_knn / 1e12 / peak,
-            "traffic": None,
-            "traffic_note": "not collected in this run (PMC needs its own rocprofv3 pass); profiles/pmc/r01_knn16_pruned_pmc_summary.txt: "
-            "TCC_EA0_RDREQ 1.64e9 x 64 B x 2 = 210 GB fabric-side reads per launch at 1M cells with pruning (464 GB without; "
-            "0.13 GB compulsory: every workgroup streams the reference tiles it cannot rule out)",
+            "frac": executed / t_knn / 1e12 / peak,
+            "traffic": (measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch"),
+            "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
+                "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
             "algorithmic": "2*Nq*N*d = {:.3e} flop per launch".format(flops),
-            "executed_tflops": executed / t_knn / 1e12,
-            "executed_frac_of_peak": executed / t_knn / 1e12 / peak,
+            "algorithmic_equiv_tflops": flops / t_knn / 1e12,
+            "algorithmic_equiv_frac_of_peak": flops / t_knn / 1e12 / peak,
             "note": "executed = flops issued to the matrix pipe (K padded to {}{}); algorithmic rate is {:.2f}x the "
             "157.3 TF fp32-MFMA peak; first-pass kernel only, the re-search of {} uncertified rows is reported under "
             "stages".format(kp, ", split-fp16 products nprod={}".format(G.info.get("nprod")) if search == "f16x3" else "",
@@ -243,14 +333,18 @@ def main():
         steps = args.order - 1
         rows = G.info.get("rows_local", N)
         byts = cheby_bytes_per_step(G.nnz, rows, p)
+        tiled = G.info.get("spmm") == "tiled"
         out["roofline_cheby"] = {
-            "kernel": "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence), {} launches".format(steps),
+            "kernel": ("pt_step_kernel<P=2> (panel-tiled Laplacian recurrence, iterate staged in LDS)" if tiled else
+                       "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence)") + ", {} launches".format(steps),
             "bound": "hbm",
             "achieved": byts * steps / t_ch / 1e9,
             "peak": PEAK_HBM_GBS,
             "unit": "GB/s",
             "frac": byts * steps / t_ch / 1e9 / PEAK_HBM_GBS,
-            "traffic": None,
+            "traffic": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get("bytes_per_launch"),
+            "traffic_note": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get(
+                "note", "no PMC pass on record for this size (profiles/pmc/traffic.json)"),
             "algorithmic": "{} B per launch (12*nnz + 4(N+1) + 8N + 40*N*p)".format(byts),
             "us_per_launch": 1e6 * t_ch / steps,
         }
@@ -264,8 +358,20 @@ def main():
         op2.transform(labels)
         torch.cuda.synchronize()
         out["stages"] = dict(op2.graph.info["stage_seconds"], fit_total=t_fit, transform_total=time.perf_counter() - t0)
+    if host_ms:
+        out["host_input"] = {
+            "ms_per_step_median": float(np.median(host_ms)),
+            "value": N / (1e-3 * float(np.median(host_ms))),
+            "unit": "cells/s",
+            "note": "same step with X as a host ndarray (the {:.0f} MB H2D copy over PCIe inside the step), median of {}; "
+            "SURVEY 8d's host-visible definition -- reported beside `value`, which starts with X resident".format(N * d * 8 / 1e6, len(host_ms)),
+        }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order, N, full_protocol=args.cpu_full)
+        out["cpu_baseline"]["chebyshev_at_full_size"] = cpu_chebyshev_full_size(G, labels, args.beta, args.order)
+        ch = out["cpu_baseline"]["chebyshev_at_full_size"]
+        if "cheby_steps" in ev:
+            ch["device_seconds_same_stage"] = float(np.mean(ev["cheby_steps"])) * 1e-3 * args.order / max(args.order - 1, 1)
     if dist is not None:
         dist.barrier()
     if rank == 0:

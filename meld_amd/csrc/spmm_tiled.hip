@@ -504,7 +504,10 @@ __device__ __forceinline__ int block_exscan(int v, int* s_wave /* [THREADS/64 + 
   return s_wave[w] + inc - v;
 }
 
-constexpr int GROUPS_MAX = TP_MAX * 8;  // bitmap words are summed in groups of 8
+constexpr int GW = 4;                            // bitmap words per prefix group
+constexpr int GPP = (BP / 32) / GW;              // groups per bitmap panel (16)
+constexpr int GROUPS_MAX = TP_MAX * GPP;
+constexpr int GPT = (GROUPS_MAX + THREADS - 1) / THREADS;  // groups per thread in the prefix pass
 
 // One workgroup per row block: distinct-column list, per-(wave, tile) segment offsets, and the block's
 // nonzeros re-ordered by (owner wave, tile, row, column).  status[0] = max over blocks of an error code
@@ -516,13 +519,14 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     int32_t* __restrict__ status, int stop /* timing only: leave after stage `stop` (0 = run everything) */) {
   __shared__ int16_t s_pmap[NPAN_MAX];          // panel -> compact index of the touched panels (ascending), -1
   __shared__ uint32_t s_bits[TP_MAX][BP / 32];  // one bit per column of every touched panel
-  __shared__ int32_t s_gpre[GROUPS_MAX + 1];    // distinct columns before each group of 8 bitmap words
+  __shared__ int32_t s_gpre[GROUPS_MAX + 1];    // distinct columns before each group of GW bitmap words
   __shared__ int16_t s_cpan[TP_MAX];            // compact index -> panel
   __shared__ int32_t s_cnt[NW][SEGW];           // entries per (wave, tile), then running cursors
   __shared__ int s_scan[THREADS / 64 + 1];
   __shared__ int32_t s_rp[RMAX + 1];            // row pointers of the block, relative to its first entry
   __shared__ int s_ord[SEGW], s_inv[SEGW];      // processing order of the tiles <-> chunk of the column list
   __shared__ int s_tmp[3][SEGW];
+  __shared__ int s_len[NW][SEGW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -599,27 +603,27 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
   __syncthreads();
   if (stop == 1) return;
   int ndist;
-  {  // distinct columns before every group of 8 words (<= GROUPS_MAX groups, 4 per thread)
-    const int ngroups = tp * 8;
-    int cnt4[4], c = 0;
+  {  // distinct columns before every group of GW words (<= GROUPS_MAX groups, GPT consecutive ones per thread)
+    const int ngroups = tp * GPP;
+    int cntk[GPT], c = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int g = tid * 4 + k;
-      int s = 0;
+    for (int k = 0; k < GPT; ++k) {
+      const int g = tid * GPT + k;
+      int sgrp = 0;
       if (g < ngroups) {
-        const uint32_t* wp = &s_bits[g >> 3][(g & 7) * 8];
+        const uint32_t* wp = &s_bits[g / GPP][(g % GPP) * GW];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += __popc(wp[q]);
+        for (int q = 0; q < GW; ++q) sgrp += __popc(wp[q]);
       }
-      cnt4[k] = s;
-      c += s;
+      cntk[k] = sgrp;
+      c += sgrp;
     }
     int pre = block_exscan(c, s_scan, &ndist);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int g = tid * 4 + k;
+    for (int k = 0; k < GPT; ++k) {
+      const int g = tid * GPT + k;
       if (g < ngroups) s_gpre[g] = pre;
-      pre += cnt4[k];
+      pre += cntk[k];
     }
     if (tid == 0) s_gpre[ngroups] = ndist;
   }
@@ -637,10 +641,12 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
   auto col_rank = [&](int c) -> int {
     const int ci = s_pmap[c >> BP_BITS];
     const int wd = (c & (BP - 1)) >> 5;
-    int g = s_gpre[ci * 8 + (wd >> 3)];
-    const uint32_t* wp = &s_bits[ci][wd & ~7];
-    for (int q = 0; q < (wd & 7); ++q) g += __popc(wp[q]);
-    g += __popc(wp[wd & 7] & ((1u << (c & 31)) - 1u));
+    int g = s_gpre[ci * GPP + wd / GW];
+    const uint32_t* wp = &s_bits[ci][wd & ~(GW - 1)];
+    // words of the group below wd, branch-free (GW - 1 reads, masked)
+#pragma unroll
+    for (int q = 0; q < GW - 1; ++q) g += (q < (wd & (GW - 1))) ? __popc(wp[q]) : 0;
+    g += __popc(s_bits[ci][wd] & ((1u << (c & 31)) - 1u));
     return g;
   };
   // the sorted list of distinct columns (thread per bitmap word)
@@ -648,9 +654,9 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     const int ci = i / (BP / 32), wd = i % (BP / 32);
     uint32_t bits = s_bits[ci][wd];
     if (bits) {
-      int g = s_gpre[ci * 8 + (wd >> 3)];
-      const uint32_t* wp = &s_bits[ci][wd & ~7];
-      for (int q = 0; q < (wd & 7); ++q) g += __popc(wp[q]);
+      int g = s_gpre[ci * GPP + wd / GW];
+      const uint32_t* wp = &s_bits[ci][wd & ~(GW - 1)];
+      for (int q = 0; q < (wd & (GW - 1)); ++q) g += __popc(wp[q]);
       const int cbase = ((int)s_cpan[ci] << BP_BITS) + wd * 32;
       while (bits) {
         const int bit = __ffs(bits) - 1;
@@ -663,74 +669,110 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
   if (stop == 2) return;
   // Passes B2 and C: every owner wave walks ITS rows in order, lanes = the row's entries (one coalesced load per
   // row, RU rows in flight).  B2 counts the wave's entries per tile, C appends every entry to its (wave, tile)
-  // segment.  The per-tile counters / cursors of a wave live in ONE VGPR (lane t = tile t; T <= 63), read with
-  // v_readlane: no LDS round trip in the dependent chain of the walk.
-  const uint64_t lt = ((uint64_t)1 << lane) - 1;
+  // segment.  A row's entries are sorted by column, so the entries of one tile are a run of consecutive lanes; the
+  // per-tile counters / cursors of a wave live in ONE VGPR (lane t = tile t; T <= 63) that the entry lanes read with
+  // ds_bpermute and the run heads update with ds_permute -- no loop over the tiles of a row, no LDS memory in the
+  // dependent chain of the walk.
   constexpr int RU = 8;  // rows in flight
   const int nmine = (w < NW && nrows > w) ? (nrows - w + NW - 1) / NW : 0;
   const int64_t elast = max(e1 - 1, e0);
+  const uint64_t le = ((uint64_t)2 << lane) - 1;  // lanes <= mine
   int seg_start = 0;  // lane j: start of this wave's segment of the j-th processed tile
+  int inv_v = lane;   // lane c: processing position of list chunk c (pass 1)
+  int seg_len = 0;    // lane j: entries of this wave in the j-th processed tile
   for (int pass = 0; pass < 2; ++pass) {
     int curs = 0;  // lane t: entries of tile t seen so far
     if (w < NW && e1 > e0) {
-      int64_t rs[RU], re[RU];
+      // Work items = (row, 64-entry part of it), in order; RU of them are in flight.  The fetch cursor runs ahead of
+      // the walk on its own (row bounds come from LDS), so the walk itself is ONE loop without inner loops or loads
+      // behind branches -- hipcc's wait-count pass puts s_waitcnt vmcnt(0) at every loop header / join it cannot see
+      // through, which made every row wait for the row fetched last (1.5 us per row, 0.47 ms per pass).
+      int fk = 0, fpart = 0;  // fetch cursor: row index among this wave's rows, part of it
+      int ik[RU], ioff[RU], iend[RU];  // item: row index, first entry (relative to e0), end of the row
       int cc[RU];
       double vv[RU];
-      auto fetch = [&](int u, int k) __attribute__((always_inline)) {
-        if (k < nmine) {  // (row bounds from LDS: a global load here would sit in front of the dependent column load)
-          const int rl = w + k * NW;
-          rs[u] = e0 + s_rp[rl];
-          re[u] = e0 + s_rp[rl + 1];
-        } else {
-          rs[u] = re[u] = e0;
+      auto fetch = [&](int u) __attribute__((always_inline)) {
+        int rs = 0, rend = 0;
+        if (fk < nmine) {
+          const int rl = w + fk * NW;
+          rs = s_rp[rl];
+          rend = s_rp[rl + 1];
         }
-        const int64_t e = min(rs[u] + lane, elast);
+        ik[u] = fk;
+        ioff[u] = rs + fpart * 64;
+        iend[u] = rend;
+        const int64_t e = min(e0 + ioff[u] + lane, elast);
         cc[u] = col[e];
         if (pass == 1) vv[u] = val[e];
+        // next item: the next part of a row longer than a wave, else the next row
+        const bool more_parts = ioff[u] + 64 < rend;
+        fpart = more_parts ? fpart + 1 : 0;
+        fk = more_parts ? fk : fk + 1;
       };
 #pragma unroll
-      for (int u = 0; u < RU; ++u) fetch(u, u);
-      for (int k0 = 0; k0 < nmine; k0 += RU) {
+      for (int u = 0; u < RU; ++u) fetch(u);
+      bool busy = nmine > 0;
+      while (busy) {
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-          const int k = k0 + u;
-          if (k < nmine) {
-            int64_t off = rs[u];
-            const int64_t rend = re[u];
-            int c = cc[u];
-            double v = (pass == 1) ? vv[u] : 0.0;
-            while (off < rend) {
-              const bool act = off + lane < rend;
-              const int g = act ? col_rank(c) : 0;
-              // pass 0 counts per chunk of the column list, pass 1 works in the processing order of the tiles
-              const int tl = (pass == 0) ? (g >> CP_BITS) : s_inv[g >> CP_BITS];
-              uint64_t rem = __ballot(act);
-              while (rem) {
-                const int l0 = __ffsll((unsigned long long)rem) - 1;
-                const int t0 = __builtin_amdgcn_readlane(tl, l0);
-                const uint64_t m = __ballot(act && tl == t0);
-                if (pass == 1) {
-                  const int c0 = __builtin_amdgcn_readlane(curs, t0);
-                  if (act && tl == t0) {
-                    // append order: position = start of the (wave, tile) segment + entries of it seen so far; the
-                    // segment is brought into its final (transposed) order by pt_transpose_kernel
-                    const int64_t pos = e0 + __builtin_amdgcn_readlane(seg_start, t0) + c0 + __popcll(m & lt);
-                    pval[pos] = v;
-                    pidx[pos] = (uint32_t)(g & (CP - 1)) | ((uint32_t)k << CP_BITS);
-                  }
-                }
-                if (lane == t0) curs += __popcll(m);
-                rem &= ~m;
+          const int k = ik[u];
+          const int off = ioff[u], rend = iend[u];
+          const int c = cc[u];
+          const double v = (pass == 1) ? vv[u] : 0.0;
+          fetch(u);
+          const bool act = (k < nmine) && (off + lane < rend);  // (the active lanes are 0 .. n - 1)
+          const int g = act ? col_rank(c) : 0;
+          const int ch = g >> CP_BITS;  // chunk of the column list: non-decreasing along the lanes
+          // pass 0 counts per list chunk, pass 1 works in the processing order of the tiles
+          const int tl = (pass == 0) ? ch : __builtin_amdgcn_ds_bpermute(ch << 2, inv_v);
+          const int chp = __shfl_up(ch, 1, 64);
+          const bool head = act && (lane == 0 || ch != chp);
+          const uint64_t hm = __ballot(head);
+          const int nact = __popcll(__ballot(act));
+          const int hl = 63 - __clzll((unsigned long long)(hm & le));        // head lane of my run
+          const uint64_t above = (lane == 63) ? 0 : (hm >> (lane + 1));
+          const int run_end = above ? lane + __ffsll((unsigned long long)above) : nact;  // one past my run
+          if (pass == 1) {
+            const int c0 = __builtin_amdgcn_ds_bpermute(tl << 2, curs);
+            const int st = __builtin_amdgcn_ds_bpermute(tl << 2, seg_start);
+            const int n = __builtin_amdgcn_ds_bpermute(tl << 2, seg_len);
+            if (act) {
+              // Logical position i of the entry in its segment ((row, column) order: start of the (wave, tile)
+              // segment + entries of it seen so far); stored TRANSPOSED over the 64 lanes of the consumer wave:
+              // lane l owns a contiguous run of the segment and chunk c holds each lane's c-th entry (n = 64 q + r
+              // entries: lanes < r own q + 1 of them, the others q).  One instruction of the consumer then touches
+              // 64 entries that are n/64 apart in (row, column) order -- different rows -- and a lane meets the
+              // entries of a row in consecutive chunks, so it can sum the run in registers.
+              const int i = c0 + (lane - hl);
+              const int q = n >> 6, r = n & 63;
+              auto divu = [](int x, int d, float rcp) __attribute__((always_inline)) {  // x, d < 2^24
+                int qq = (int)((float)x * rcp);
+                qq -= (qq * d > x) ? 1 : 0;
+                qq += ((qq + 1) * d <= x) ? 1 : 0;
+                return qq;
+              };
+              int l, cch;
+              if (i < r * (q + 1)) {
+                l = divu(i, q + 1, 1.0f / (float)(q + 1));
+                cch = i - l * (q + 1);
+              } else {
+                const int jj = i - r * (q + 1);
+                const int lq = divu(jj, max(q, 1), 1.0f / (float)max(q, 1));
+                l = r + lq;
+                cch = jj - lq * q;
               }
-              off += 64;
-              if (off < rend) {  // rows longer than a wave: next 64 entries
-                const int64_t e = min(off + lane, elast);
-                c = col[e];
-                if (pass == 1) v = val[e];
-              }
+              // (Written straight from the walk: a staging pass through LDS that transposes whole segments costs
+              // the same.  The stores are the expensive part of the build -- 0.8 of its 1.5 ms at 1M cells: every
+              // instruction writes a few 8-byte pieces of ~27 x 64 different cache lines.)
+              const int64_t pos = e0 + st + cch * 64 + l;
+              pval[pos] = v;
+              pidx[pos] = (uint32_t)(g & (CP - 1)) | ((uint32_t)k << CP_BITS);
             }
-            fetch(u, k + RU);
           }
+          // every run head adds the length of its run to the cursor of its tile (lane 63 is the dump of the
+          // other lanes: tile indices are <= 62)
+          curs += __builtin_amdgcn_ds_permute((head ? tl : 63) << 2, head ? run_end - lane : 0);
+          if (u == RU - 1) busy = ik[0] < nmine;  // (uniform) items are in order: nothing left once slot 0 is past the end
         }
       }
     }
@@ -772,6 +814,7 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
           for (int jj = 0; jj < SEGW; ++jj) tmp[jj] = (jj < T) ? s_cnt[ow][s_ord[jj]] : 0;
           for (int jj = 0; jj < SEGW; ++jj) {
             s_cnt[ow][jj] = run;
+            s_len[ow][jj] = tmp[jj];
             run += tmp[jj];
           }
         }
@@ -779,58 +822,15 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
         blk_ndist[b] = ndist;
       }
       __syncthreads();
+      inv_v = s_inv[lane];
       if (w < NW) {
         seg_start = s_cnt[w][lane];
+        seg_len = s_len[w][lane];
         seg[((size_t)b * (NW + 1) + w) * SEGW + lane] = seg_start;
       } else if (w == NW) {
         seg[((size_t)b * (NW + 1) + NW) * SEGW + lane] = s_ord[lane];  // row NW: list chunk of every processed tile
       }
     }
-  }
-}
-
-// Second step of the layout: every (wave, tile) segment, written in (row, column) order by pt_build_kernel, is
-// re-ordered IN PLACE through LDS into its final form, TRANSPOSED over the 64 lanes of the consumer wave: lane l
-// owns a contiguous run of the segment's (row, column) order and chunk c of the segment holds each lane's c-th
-// entry (n = 64 q + r entries: lanes < r own q + 1 of them, the others q).  One instruction of the consumer then
-// touches 64 entries that are n/64 apart in (row, column) order -- different rows -- instead of 64 consecutive
-// ones (runs of ~5 lanes per row, which the LDS would serialise on the same accumulator), and a lane meets the
-// entries of a row in consecutive chunks, so it can sum the run in registers.  (Done as its own pass: scattering
-// the entries to their transposed positions directly from the row walk keeps 64 partially written cache lines
-// open per segment for the whole walk -- 2.3 ms of read-modify-write traffic at 1M cells, against 0.2 ms here.)
-// Segments beyond the LDS capacity stay in (row, column) order: the consumer is correct for any order.
-constexpr int TR_THREADS = 256;
-constexpr int TR_CAP = 8192;  // entries staged at once (96 KiB)
-__global__ __launch_bounds__(TR_THREADS) void pt_transpose_kernel(const int64_t* __restrict__ rowptr,
-                                                                  const int32_t* __restrict__ blk_row,
-                                                                  const int32_t* __restrict__ blk_ntile,
-                                                                  const int32_t* __restrict__ seg, double* __restrict__ pval,
-                                                                  uint32_t* __restrict__ pidx) {
-  __shared__ double s_v[TR_CAP];
-  __shared__ uint32_t s_i[TR_CAP];
-  const int b = blockIdx.x / NW, w = blockIdx.x % NW;
-  const int T = blk_ntile[b];
-  if (T <= 0) return;
-  const int64_t e0 = rowptr[blk_row[b]];
-  const int32_t* sg = seg + ((size_t)b * (NW + 1) + w) * SEGW;
-  for (int t = 0; t < T; ++t) {
-    const int s0 = sg[t], n = sg[t + 1] - sg[t];
-    if (n <= 64 || n > TR_CAP) continue;  // (wave-uniform) one chunk: nothing to transpose
-    double* pv = pval + e0 + s0;
-    uint32_t* pi = pidx + e0 + s0;
-    for (int i = threadIdx.x; i < n; i += TR_THREADS) {
-      s_v[i] = pv[i];
-      s_i[i] = pi[i];
-    }
-    __syncthreads();
-    const int q = n >> 6, r = n & 63;
-    for (int pos = threadIdx.x; pos < n; pos += TR_THREADS) {
-      const int c = pos >> 6, l = pos & 63;
-      const int i = (l < r) ? l * (q + 1) + c : r * (q + 1) + (l - r) * q + c;
-      pv[pos] = s_v[i];
-      pi[pos] = s_i[i];
-    }
-    __syncthreads();
   }
 }
 
@@ -889,9 +889,6 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
                      const_cast<int32_t*>(layout->blk_ntile), const_cast<int32_t*>(layout->blk_ndist),
                      const_cast<int32_t*>(layout->seg), const_cast<int32_t*>(layout->list_cols),
                      const_cast<double*>(layout->pval), const_cast<uint32_t*>(layout->pidx), status, (g_pt_ablate >> 8) & 7);
-  if (((g_pt_ablate >> 8) & 7) == 0)
-    hipLaunchKernelGGL(pt::pt_transpose_kernel, dim3(nb * pt::NW), dim3(pt::TR_THREADS), 0, st, rowptr, layout->blk_row,
-                       layout->blk_ntile, layout->seg, const_cast<double*>(layout->pval), const_cast<uint32_t*>(layout->pidx));
   MELD_LAUNCH_CHECK("pt_build_kernel");
   return MELD_OK;
 }

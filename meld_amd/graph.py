@@ -355,6 +355,7 @@ class HipOps:
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
+        used_prune = used_seed = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if search == "wide":
@@ -470,6 +471,7 @@ class HipOps:
                     check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
+            used_prune, used_seed = lb2 is not None, seeds is not None
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
@@ -641,6 +643,8 @@ class HipOps:
         tm.stop("coo_emit")
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
+                    # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), split_tail=bool(self.split_tail),
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
                     wave_tiles_done=int(tiles_done.item()) if tiles_done is not None else None)

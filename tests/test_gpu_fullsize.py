@@ -1,25 +1,29 @@
-"""Parity at BASELINE.json's full size (1M cells x 50 dims) through size-independent properties
-(the CPU oracle needs hours there): exact neighbourhoods of sampled rows against an independent
-fp64 brute force, symmetry, degree consistency, mass conservation, linearity, determinism."""
+"""Parity at BASELINE.json's full sizes -- configs[2] (500k cells x 50 dims) and configs[3]'s problem
+size (1M cells x 50 dims; on one GPU here, the 8-way split is covered by the sharded tests) -- where the
+CPU oracle's kNN needs hours: the graph through size-independent properties (exact neighbourhoods of
+sampled rows against an independent fp64 brute force, symmetry, degree consistency, determinism), the
+filter stage against the CPU oracle itself (pygsp-style scipy recurrence on the device-built CSR,
+SURVEY 8d "CPU baseline beside it"), mass conservation and linearity."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-N_FULL, D_FULL = 1_000_000, 50
+D_FULL = 50
 
 
-@pytest.fixture(scope="module")
-def full():
+@pytest.fixture(scope="module", params=[500_000, 1_000_000], ids=["C3-500k", "C4-1M"])
+def full(request):
     import bench
     import meld_amd
 
+    N_FULL = request.param
     X, labels = bench.synthetic_cells(N_FULL, n_dims=D_FULL, seed=0)
     Xd = torch.from_numpy(X).cuda()
     op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, verbose=0)
     op.fit(Xd)
-    return dict(op=op, X=Xd, labels=labels)
+    return dict(op=op, X=Xd, labels=labels, N=N_FULL)
 
 
 def _rows_csr(G, rows_perm):
@@ -36,7 +40,7 @@ def test_sampled_rows_equal_an_independent_exact_neighbourhood(full):
     """For 256 random cells: bandwidth = exact distance to the (knn+1)-th nearest cell (self included),
     and the directed kernel row = exp(-(d/bw)^decay) >= thresh over ALL 1M cells, computed by fp64 brute
     force in torch -- index sets bit-exact, values to 1e-12."""
-    op, X = full["op"], full["X"]
+    op, X, N_FULL = full["op"], full["X"], full["N"]
     G = op.graph
     knn, decay, thresh = 15, 40.0, 1e-4
     g = torch.Generator().manual_seed(1)
@@ -105,7 +109,7 @@ def test_mass_conservation_and_linearity_at_full_size(full):
     import meld_amd
     from meld_amd import filter as mfilter
 
-    op, labels = full["op"], full["labels"]
+    op, labels, N_FULL = full["op"], full["labels"], full["N"]
     dens = op.transform(labels)
     # L 1 = 0, so the column sums are multiplied by the degree-30 polynomial's value at lambda = 0:
     # p(0) = c_0 / 2 + sum_k c_k T_k(-1) (= h(0) = 1 up to the approximation error, ~1e-7 here)
@@ -123,3 +127,37 @@ def test_mass_conservation_and_linearity_at_full_size(full):
     assert np.abs(a * F[:, 0] + b * F[:, 1] - F[:, 2]).max() <= 1e-12 * scale
     f1 = mfilter.filter(s1, op.graph, "heat", 60, chebyshev_order=30)
     assert np.abs(f1 - F[:, 0]).max() <= 1e-12 * scale
+
+
+def test_filter_stage_matches_the_cpu_oracle_at_full_size(full):
+    """The Chebyshev stage against the CPU oracle at full size: the device-built CSR goes to the host once,
+    the oracle's pygsp-style recurrence (scipy CSR x dense, [UPSTREAM pygsp cheby_op] as called from
+    reference meld/filter.py:59) runs on it with the same lmax, and the device recurrence (the panel-tiled
+    kernel at these sizes) has to agree within the north-star tolerance 1e-5 (measured ~1e-14).  Done in the
+    graph's internal (locality) order, so that no 39 M-entry permutation is needed on the host; the end-to-end
+    transform (original cell order) is checked against the same reference through the permutation."""
+    from scipy import sparse
+
+    from meld_amd import filter as mfilter
+    from oracle import meld_oracle as mo
+
+    op, labels, n = full["op"], full["labels"], full["N"]
+    G = op.graph
+    W = sparse.csr_matrix((G.val.cpu().numpy(), G.col.cpu().numpy(), G.rowptr.cpu().numpy()), shape=(n, n))
+    dw = G.dw_dev.cpu().numpy()
+    np.testing.assert_allclose(np.ravel(W.sum(1)), dw, rtol=1e-12)
+    L = (sparse.diags(dw, 0) - W).tocsr()
+    lmax = G.lmax
+    c = mo.cheby_coeff(mo.filter_kernel_fn("heat", 60, 0, 1, lmax), lmax, 30)
+    samples, ind = mo.sample_indicators(labels)
+    perm = G.perm.cpu().numpy()
+    s_int = np.ascontiguousarray(ind[perm])
+    ref = mo.cheby_op(L, lmax, c, s_int)
+    out = mfilter.chebyshev_apply(G, torch.from_numpy(s_int).cuda(), c, lmax).cpu().numpy()
+    assert G.info["spmm"] == "tiled"
+    for col in range(ref.shape[1]):
+        assert np.abs(out[:, col] - ref[:, col]).max() <= 1e-5 * np.abs(ref[:, col]).max()
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()  # what is actually reached
+    dens = op.transform(labels)
+    assert list(dens.columns) == list(samples)
+    assert np.abs(dens.values[perm] - ref).max() <= 1e-11 * np.abs(ref).max()

@@ -59,6 +59,7 @@ for mode in ("csr", "tiled"):
             G.pt = None
             us = timed(lambda: (setattr(G, "pt", None), G.ops.pt_layout(G)), 3)
             print("  layout build stopped after stage %d: %.2f ms" % (stage, us / 1e3), flush=True)
+        get_lib().meld_pt_debug_ablate(0)
         G.pt = None
         G.ops.pt_layout(G)
     for pp in (p, 1):
