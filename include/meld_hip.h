@@ -333,6 +333,15 @@ int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, 
                          const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
                          const double* state, double* dots, meld_stream_t stream);
 
+/* ---- KMeans step of VertexFrequencyCluster.predict (reference meld/cluster.py:315-345 -> [UPSTREAM
+ *      sklearn.cluster.KMeans], Lloyd iteration; csrc/kmeans.hip) ---------------------------------------
+ * One pass over X[n, d] (fp64, d <= 32): labels[i] = nearest of the k <= 64 centroids (ties: lowest index),
+ * and per workgroup b < n_blocks the partial sums part_sum[b][k][d], counts part_cnt[b][k] (as fp64) and
+ * inertia part_inertia[b]; the caller reduces the partials over b (fixed order) and divides. */
+int meld_kmeans_max_blocks(void);
+int meld_kmeans_assign(const double* X, int64_t n, int d, const double* centroids, int k, int32_t* labels,
+                       double* part_sum, double* part_cnt, double* part_inertia, int n_blocks, meld_stream_t stream);
+
 /* ---- cache-locality ordering helper (no reference counterpart; csrc/reorder.hip) ---------- */
 /* out[i] = index (within its group) of the centroid nearest to X[i]; cents holds n_per_group
  * centroids per group, group[i] selects the group of point i (NULL = one shared set).  order

@@ -88,6 +88,8 @@ SIGNATURES = {
     "meld_pt_cheby_step": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr]),
     "meld_pt_lanczos_steps": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
     "meld_pt_lanczos_spmv": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_kmeans_max_blocks": (_i32, []),
+    "meld_kmeans_assign": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_scale_f64": (_i32, [_ptr, _f64, _ptr, _i64, _ptr]),
     "meld_axpby_f64": (_i32, [_f64, _ptr, _f64, _ptr, _i64, _ptr, _ptr]),
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),

@@ -1,14 +1,44 @@
-"""Vertex-Frequency Clustering (reference ``meld/cluster.py:13-367``) at small N on the device.
+"""Vertex-Frequency Clustering (reference ``meld/cluster.py:13-367``) on the device.
 
-SURVEY.md section 8f row 2 (i): the reference algorithm is dense -- windows are powers of the
-diffusion operator (``cluster.py:158-194``), the spectrogram is a windowed graph Fourier transform
-over ALL eigenvectors of the Laplacian (``:98-156``, ``:235-236``) -- so it is O(N^3) and cannot run
-at the hot path's sizes; this module is the faithful version for N <= ``dense.DENSE_MAX_N`` on dense
-PyTorch-ROCm linear algebra (fp64 rocBLAS GEMMs for the window powers and U^T (W .* s), rocSOLVER
-``eigh`` for the Fourier basis; library calls, not hand-written kernels), followed by PCA
-(``meld_amd.pca``) and a seeded k-means++ / Lloyd KMeans on the device.  The scalable reformulation
-(heat-filter windows + a Chebyshev filter bank instead of the full eigenbasis, section 8f row 2 (ii)) is
-not implemented.  Same constructor, methods, checks and messages as the reference class.
+SURVEY.md section 8f row 2.  The reference algorithm is dense -- windows are powers of the diffusion
+operator (``cluster.py:158-194``), the spectrogram is a windowed graph Fourier transform over ALL
+eigenvectors of the Laplacian (``:98-156``, ``:235-236``) -- so it is O(N^3) and cannot run at the hot
+path's sizes.  Two methods (``method=``):
+
+``"dense"`` (N <= ``dense.DENSE_MAX_N``; default there): the faithful reference algorithm on dense
+    PyTorch-ROCm linear algebra (fp64 rocBLAS GEMMs for the window powers and U^T (W .* s), rocSOLVER
+    ``eigh`` for the Fourier basis; library calls), parity-tested against the oracle's restatement.
+
+``"filterbank"`` (default above that; BASELINE config 5): a NEW algorithm with the same role, built on the
+    hot path's recurrence kernel, not a restatement of the reference.  What the reference's spectrogram
+    computes is, for vertex j, scale t and frequency k, ``|sum_i U[i,k] P^t[j,i] / c_t[i]|`` normalised
+    over k (the sample indicator multiplies column j as a whole and cancels in that normalisation:
+    the reference's spectrogram is a structural signature of the graph, independent of the signal --
+    ``tests/test_gpu_cluster.py`` checks that on the oracle).  With the window a function of the Laplacian,
+    ``h_t(L) = exp(-t L / dbar)`` (a diffusion step is ``P = I - D^-1 L``; dbar = mean kernel degree;
+    precedent: a pygsp Heat filter as window, ``notebooks/meld_txclustering.ipynb`` cells 31-32), the energy
+    of that signature in a band b of the spectrum is a DIAGONAL entry of a function of L,
+
+        E[t, b, j] = sum_{k in b} h_t(lambda_k)^2 U[j,k]^2 = [ (h_t^2 g_b)(L) ]_jj ,
+
+    with g_b a partition of unity over [0, lmax] (n_bands hat functions, log-spaced), and the signature itself
+    restricted to an eigenvector u_k is |u_k[j]| h_t(lambda_k).  The low end of the spectrum -- where the smooth,
+    cluster-scale structure lives and where the long windows put all their weight -- is resolved explicitly:
+    n_probes random +-1 vectors are low-pass filtered through the hot path's recurrence kernel, orthonormalised,
+    and Rayleigh-Ritz gives approximate eigenpairs (theta_i, u_i), i < n_probes; these are the first n_probes
+    COLUMNS of the spectrogram, each treated exactly like a frequency of the reference's,
+    ``sum_t tanh(|u_i[j]| h_t(theta_i) / norm_t[j])``.  The rest of the spectrum enters as n_bands more columns, the
+    band amplitudes ``sum_t tanh sqrt(E_rest[t,b,j]) / norm_t[j]`` of what the Ritz subspace leaves, estimated by
+    Hutchinson probing of the DEFLATED operator (Hutch++; plain probing is useless for the long windows, whose
+    operators have dense rows: relative error sqrt(N / n_probes) for the constant eigenvector alone) through
+    per-vertex Chebyshev moments  m_k[j] = mean_r z_r[j] ((I - QQ^T) T_k(L) z'_r)[j]  accumulated over a second pass
+    of the recurrence: every (t, b) is a coefficient vector applied to them, and norm_t[j]^2 = [h_t^2(L)]_jj is
+    the sum of both parts.  With n_probes = N the Ritz pairs are the eigenpairs and the first N columns ARE the
+    reference-style spectrogram with heat windows (tested).  Cost: 2 chebyshev_order + 1 SpMMs of n_probes
+    columns, independent of n_windows x n_bands.
+
+PCA (``meld_amd.pca``) and a seeded k-means++ / Lloyd KMeans follow (assignment + centroid update in
+``csrc/kmeans.hip``).  Same constructor, methods, checks and messages as the reference class.
 """
 from __future__ import annotations
 
@@ -26,10 +56,38 @@ def _l2_normalize_columns(M):
     return M / torch.where(nrm == 0, torch.ones_like(nrm), nrm)
 
 
+def _lloyd_step(Y, C, lab, scratch):
+    """One Lloyd iteration on the device (``meld_kmeans_assign``): labels of the nearest centroid, new centroids
+    (an empty cluster keeps its centroid), inertia of the assignment -- all as device tensors, no sync."""
+    from ._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    n, d = Y.shape
+    k = C.shape[0]
+    nb = scratch["nb"]
+    check(lib.meld_kmeans_assign(ptr(Y), n, d, ptr(C), k, ptr(lab), ptr(scratch["sum"]), ptr(scratch["cnt"]), ptr(scratch["in"]),
+                                 nb, torch.cuda.current_stream().cuda_stream), "meld_kmeans_assign")
+    sums = scratch["sum"].view(nb, k, d).sum(0)  # fixed-order reduction of the per-workgroup partials
+    cnt = scratch["cnt"].view(nb, k).sum(0)
+    newC = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1.0)[:, None], C)
+    return newC, scratch["in"].sum()
+
+
 def _kmeans(Y, k, n_init=10, max_iter=300, tol=1e-4, seed=None):
     """Seeded k-means++ initialisation + Lloyd iterations on the device; best inertia of ``n_init``
-    runs (sklearn's ``KMeans`` defaults; its relative tolerance is on the centre shift)."""
-    n = Y.shape[0]
+    runs (sklearn's ``KMeans`` defaults; its relative tolerance is on the centre shift).  The Lloyd step is
+    the HIP kernel of ``csrc/kmeans.hip`` (d <= 32, k <= 64: what PCA(n_clusters) hands over)."""
+    from ._lib import get_lib
+
+    Y = Y.contiguous()
+    n, d = Y.shape
+    if d > 32 or k > 64 or not Y.is_cuda:
+        raise NotImplementedError("KMeans on the device is built for d <= 32 features and k <= 64 clusters, got d={}, k={}".format(d, k))
+    nb = int(min(get_lib().meld_kmeans_max_blocks(), max(1, (n + 255) // 256)))
+    scratch = dict(nb=nb, sum=torch.empty(nb * k * d, dtype=torch.float64, device=Y.device),
+                   cnt=torch.empty(nb * k, dtype=torch.float64, device=Y.device),
+                   **{"in": torch.empty(nb, dtype=torch.float64, device=Y.device)})
+    lab = torch.empty(n, dtype=torch.int32, device=Y.device)
     gen = torch.Generator(device=Y.device)
     gen.manual_seed(0 if seed is None else int(seed))
     var_tol = tol * float(Y.var(dim=0, unbiased=False).mean())
@@ -45,23 +103,17 @@ def _kmeans(Y, k, n_init=10, max_iter=300, tol=1e-4, seed=None):
             nxt = int(torch.multinomial(probs, 1, generator=gen))
             C.append(Y[nxt])
             d2 = torch.minimum(d2, ((Y - C[-1]) ** 2).sum(1))
-        C = torch.stack(C)
+        C = torch.stack(C).contiguous()
         for _it in range(max_iter):
-            D = torch.cdist(Y, C) ** 2
-            lab = D.argmin(1)
-            newC = torch.zeros_like(C)
-            cnt = torch.bincount(lab, minlength=k).to(Y.dtype)
-            newC.index_add_(0, lab, Y)
-            newC = torch.where(cnt[:, None] > 0, newC / cnt.clamp(min=1)[:, None], C)
+            newC, _ = _lloyd_step(Y, C, lab, scratch)
             shift = ((newC - C) ** 2).sum()
-            C = newC
+            C = newC.contiguous()
             if (_it & 7) == 7 and float(shift) <= var_tol:  # one host sync per 8 iterations
                 break
-        D = torch.cdist(Y, C) ** 2
-        lab = D.argmin(1)
-        inertia = float(D.gather(1, lab[:, None]).sum())
+        _, inertia = _lloyd_step(Y, C, lab, scratch)
+        inertia = float(inertia)
         if best is None or inertia < best[0]:
-            best = (inertia, lab)
+            best = (inertia, lab.to(torch.int64).clone())
     return best[1]
 
 
@@ -70,7 +122,16 @@ class VertexFrequencyCluster:
     experimental signal (reference ``meld/cluster.py:13-46``; same parameters)."""
 
     def __init__(self, n_clusters=10, likelihood_bias=1, window_count=9, window_sizes=None, sparse=False,
-                 suppress=False, random_state=None, **kwargs):
+                 suppress=False, random_state=None, method="auto", n_bands=16, n_probes=64, chebyshev_order=None,
+                 **kwargs):
+        if method not in ("auto", "dense", "filterbank"):
+            raise ValueError("method value {} not recognized. Choose from ['auto', 'dense', 'filterbank']".format(method))
+        # extensions of the device version (see the module docstring): which algorithm, and the resolution of the
+        # filter-bank one (bands of the spectrum, random probes of the diagonal estimate, polynomial order)
+        self.method = method
+        self.n_bands = int(n_bands)
+        self.n_probes = int(n_probes)
+        self.chebyshev_order = chebyshev_order
         self.suppress = suppress
         self.sparse = sparse  # accepted for API compatibility; the device version is dense either way
         self._basewindow = None
@@ -141,10 +202,13 @@ class VertexFrequencyCluster:
         G = self.graph
         if G.n_rows != G.N:
             raise ValueError("VertexFrequencyCluster needs an unsharded graph")
+        self.method_ = self.method if self.method != "auto" else ("dense" if G.N <= DENSE_MAX_N else "filterbank")
+        if self.method_ == "filterbank":
+            return self._fit_filterbank(G)
         if G.N > DENSE_MAX_N:
             raise NotImplementedError(
-                "VertexFrequencyCluster is the reference's dense O(N^3) algorithm; N={} exceeds the {} cells it is "
-                "offered for (the scalable filter-bank reformulation is not implemented)".format(G.N, DENSE_MAX_N)
+                "method='dense' is the reference's O(N^3) algorithm; N={} exceeds the {} cells it is offered for "
+                "(use method='filterbank')".format(G.N, DENSE_MAX_N)
             )
         dev, n = G.val.device, G.N
         # dense kernel (diagonal included) and Laplacian in the graph's internal cell order
@@ -163,6 +227,150 @@ class VertexFrequencyCluster:
             self.windows = [self._compute_window(self._basewindow, t=t) for t in self.window_sizes]
         L = torch.diag(G.dw_dev[:n]) - W
         _, self.eigenvectors = torch.linalg.eigh(L)  # pygsp compute_fourier_basis
+        self.N = n
+        self.isfit = True
+        return self
+
+    # -- the filter-bank method (module docstring) ---------------------------------------------------------
+    @staticmethod
+    def _band_edges(lmax, n_bands):
+        """Centres of the n_bands hat functions: 0, then log-spaced up to lmax (the low end of the spectrum, where
+        the cluster structure lives, gets the resolution)."""
+        eps = lmax / 64.0
+        om = np.linspace(0.0, 1.0, n_bands)
+        return eps * (np.power(1.0 + lmax / eps, om) - 1.0)
+
+    @staticmethod
+    def _hat(lam, centres, b):
+        """b-th hat function of the partition of unity over the band centres (piecewise linear, sums to 1 on [0, lmax])."""
+        c = centres[b]
+        out = np.zeros_like(lam)
+        if b > 0:
+            lo = centres[b - 1]
+            m = (lam >= lo) & (lam <= c)
+            out[m] = (lam[m] - lo) / (c - lo)
+        else:
+            out[lam <= c] = 1.0
+        if b < len(centres) - 1:
+            hi = centres[b + 1]
+            m = (lam > c) & (lam <= hi)
+            out[m] = (hi - lam[m]) / (hi - c)
+        else:
+            out[lam >= c] = 1.0
+        return out
+
+    def _filterbank_functions(self, lmax, dbar):
+        """[(t, b)] -> callable f(lambda) = h_t(lambda)^2 g_b(lambda), h_t = exp(-t lambda / dbar)."""
+        centres = self._band_edges(lmax, self.n_bands)
+        fns = []
+        for t in self.window_sizes:
+            for b in range(self.n_bands):
+                fns.append(lambda lam, t=float(t), b=b: np.exp(-2.0 * t * lam / dbar) * self._hat(lam, centres, b))
+        return fns
+
+    def _fit_filterbank(self, G):
+        """Band energies E[t, b, j] = [p_tb(L)]_jj for every window t, band b and vertex j through the hot path's
+        recurrence kernel.  Plain Hutchinson probing (diag A ~ mean_r z_r .* A z_r) is hopeless for the long
+        windows: h_t^2 is then a smooth low-rank operator with dense rows -- for the constant eigenvector alone the
+        relative error is sqrt(N / n_probes).  So the low end of the spectrum is DEFLATED first (Hutch++):
+
+          pass 1  Y = phi(L) Z, phi a low-pass of the longest windows' scale, on n_probes random +-1 vectors Z;
+                  Q = orth(Y); Rayleigh-Ritz on Q gives approximate low eigenpairs (theta_i, u_i), whose
+                  contribution  sum_i p_tb(theta_i) u_i[j]^2  is evaluated exactly;
+          pass 2  the rest, (I - QQ^T) p_tb(L) (I - QQ^T) -- localised rows now --, by Hutchinson on the deflated
+                  probes, through per-vertex Chebyshev moments  m_k[j] = mean_r z_r[j] ((I - QQ^T) T_k(L) z'_r)[j]:
+                  every (t, b) is then a coefficient vector applied to the moments.
+
+        Cost: 2 chebyshev_order + 1 SpMMs of n_probes columns, independent of n_windows x n_bands."""
+        from .filter import _ops_of, chebyshev_coefficients
+
+        dev, n = G.val.device, G.N
+        ops = _ops_of(G)
+        lmax = float(G.lmax)
+        kdiag = G.kernel_diagonal()[:n]
+        dbar = float((G.dw_dev[:n] + kdiag).mean())  # mean row sum of the kernel: P = I - D^-1 L
+        self._fb = dict(lmax=lmax, dbar=dbar)
+        t_max = float(np.max(self.window_sizes))
+        M = self.chebyshev_order
+        if M is None:  # exp(-2 t lambda / dbar) on [0, lmax] needs ~ sqrt(2 t lmax / dbar) x 4 terms; at least 64
+            M = int(min(512, max(64, np.ceil(4.0 * np.sqrt(2.0 * t_max * lmax / dbar)))))
+        self._fb["order"] = M
+        kk = np.arange(M + 1)
+        nn = M + 2
+        jackson = ((nn - kk) * np.cos(np.pi * kk / nn) + np.sin(np.pi * kk / nn) / np.tan(np.pi / nn)) / nn
+
+        def coeffs(f):
+            c = chebyshev_coefficients(f, lmax, M)
+            c[0] *= 0.5  # pygsp's convention: the k = 0 term enters with 1/2
+            # Jackson damping: the damped expansion of a non-negative function is non-negative (no Gibbs lobes), so
+            # the band energies are >= 0 by construction; the polynomial filters p_tb ARE the method's bands (they
+            # resolve ~ lmax pi / M) and still sum to the damped window: sum_b p_tb = p_t.
+            return c * jackson
+
+        Cm = np.stack([coeffs(f) for f in self._filterbank_functions(lmax, dbar)])  # [T*B, M+1]
+        self._fb["coeffs"] = Cm
+        t_phi = max(1.0, t_max / 8.0)
+        c_phi = coeffs(lambda lam: np.exp(-2.0 * t_phi * lam / dbar))
+        R = int(min(self.n_probes, n))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0 if self.random_state is None else int(self.random_state))
+        Z = (torch.randint(0, 2, (n, R), device=dev, generator=gen, dtype=torch.int8).to(torch.float64) * 2.0 - 1.0).contiguous()
+        a1 = a2 = lmax / 2.0
+
+        def recurrence(Z0, visit):
+            """visit(k, T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, p = R columns)."""
+            t_old, t_cur = Z0.clone(), torch.empty_like(Z0)
+            visit(0, t_old)
+            ops.cheby_step(G, R, t_old, 0, None, t_cur, None, 1.0 / a1, -a2 / a1, 0.0, 0.0)
+            visit(1, t_cur)
+            for k in range(2, M + 1):
+                ops.cheby_step(G, R, t_cur, 0, t_old, t_old, None, 2.0 / a1, -2.0 * a2 / a1, -1.0, 0.0)
+                visit(k, t_old)
+                t_old, t_cur = t_cur, t_old
+
+        # pass 1: low-pass filtered probes -> basis of the low end of the spectrum -> Ritz pairs
+        Y = torch.zeros_like(Z)
+        recurrence(Z, lambda k, Tk: Y.add_(Tk, alpha=float(c_phi[k])))
+        Q, _ = torch.linalg.qr(Y)
+        Q = Q.contiguous()  # (the solver hands back a column-major tensor; the kernels take row-major [n, R])
+        LQ = torch.empty(n, R, dtype=torch.float64, device=dev)
+        ops.cheby_step(G, R, Q, 0, None, LQ, None, 1.0, 0.0, 0.0, 0.0)  # L Q
+        H = Q.T @ LQ
+        theta, V = torch.linalg.eigh(0.5 * (H + H.T))
+        Ur = Q @ V  # approximate eigenvectors [n, R]
+        theta = theta.clamp(0.0, lmax)
+        Cd = torch.from_numpy(Cm).to(dev)
+        # p_tb(theta_i) by the Clenshaw-free direct sum (R values, M + 1 terms)
+        xt = (2.0 * theta / lmax - 1.0).clamp(-1.0, 1.0)
+        Tm = torch.cos(torch.arange(M + 1, device=dev, dtype=torch.float64)[:, None] * torch.acos(xt)[None, :])  # [M+1, R]
+        Pth = (Cd @ Tm).clamp_(min=0.0)  # [T*B, R]
+        E_low = (Ur * Ur) @ Pth.T  # [n, T*B]
+        # pass 2: Hutchinson on the deflated operator
+        Zd = Z - Q @ (Q.T @ Z)
+        mom = torch.empty(n, M + 1, dtype=torch.float64, device=dev)
+
+        def visit2(k, Tk):
+            W = Tk - Q @ (Q.T @ Tk)
+            mom[:, k] = (Z * W).mean(1)
+
+        recurrence(Zd, visit2)
+        T, B = len(self.window_sizes), self.n_bands
+        E_res = (mom @ Cd.T).view(n, T, B).clamp_(min=0.0)  # band energies outside the Ritz subspace
+        E_lowb = E_low.view(n, T, B)
+        tot = (E_lowb + E_res).sum(2)  # [n, T]: [p_t(L)]_jj, the squared norm of vertex j's window signature
+        tot = torch.where(tot > 0, tot, torch.ones_like(tot))
+        # columns 0 .. R-1: the Ritz vectors, each treated like a frequency of the reference spectrogram --
+        # sum_t tanh(|u_i[j]| h_t(theta_i) / norm_t[j]); columns R ..: what is left per band, as amplitudes
+        pt_theta = Pth.view(T, B, R).sum(1).clamp_(min=0.0)  # [T, R]: p_t(theta_i)
+        ritz_feat = torch.zeros(n, R, dtype=torch.float64, device=dev)
+        absU = Ur.abs()
+        for ti in range(T):
+            ritz_feat += torch.tanh(absU * torch.sqrt(pt_theta[ti])[None, :] / torch.sqrt(tot[:, ti])[:, None])
+        res_feat = torch.tanh(torch.sqrt(E_res / tot[:, :, None])).sum(1)  # [n, B]
+        self._fb_spectrogram = torch.cat([ritz_feat, res_feat], dim=1)  # [n, R + B], internal cell order
+        self._fb["window_norm2"] = tot
+        self._fb["ritz"] = theta
+        self.eigenvectors = None
         self.N = n
         self.isfit = True
         return self
@@ -192,8 +400,25 @@ class VertexFrequencyCluster:
         if center:
             self.sample_indicator = self.sample_indicator - self.sample_indicator.mean()
 
-        dev = self.eigenvectors.device
         perm = getattr(self.graph, "perm", None)  # internal (locality) order -> caller's order
+        if getattr(self, "method_", "dense") == "filterbank":
+            # The reference's spectrogram depends on the indicator only through its zero pattern (the indicator
+            # multiplies a whole column, which is then normalised): rows of zero entries are zero, every other
+            # row is the structural signature; one copy per indicator column, as the reference stacks them.
+            spec = self._fb_spectrogram
+            if perm is not None:
+                out = torch.empty_like(spec)
+                out[perm] = spec
+                spec = out
+            spec = spec.cpu().numpy()
+            ind = self.sample_indicator if self.sample_indicator.ndim > 1 else self.sample_indicator[:, None]
+            if ind.shape[0] != self.N:
+                ind = ind.T
+            self.spectrogram = np.hstack([spec * (ind[:, i] != 0)[:, None] for i in range(ind.shape[1])])
+            if self.likelihood is not None:
+                self.combined_spectrogram = self._combine_spectrogram_likelihood(self.spectrogram, self.likelihood)
+            return self.spectrogram
+        dev = self.eigenvectors.device
 
         def to_internal(v):
             t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
@@ -234,17 +459,20 @@ class VertexFrequencyCluster:
 
         params = dict(self._sklearn_params)
         params.update(kwargs)
-        dev = self.eigenvectors.device
+        dev = self.graph.val.device
         Y = pca_project(torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64)).to(dev), self.n_clusters)
         lab = _kmeans(Y, self.n_clusters, n_init=params.get("n_init", 10), max_iter=params.get("max_iter", 300),
                       tol=params.get("tol", 1e-4), seed=params.get("random_state", self.random_state)).cpu().numpy()
         values = self.likelihood if self.likelihood is not None else self.sample_indicator
         # scprep.utils.sort_clusters_by_values: clusters relabelled by ascending mean of the values
         values = np.asarray(values, dtype=np.float64)
-        uniq = np.unique(lab)
-        means = np.array([np.mean(values[lab == c]) for c in uniq])
-        remap = {c: i for i, c in enumerate(uniq[np.argsort(means)])}
-        self.labels_ = np.array([remap[c] for c in lab])
+        if values.ndim > 1:  # (2-D indicators / likelihoods: the mean over all columns, as np.mean does in scprep)
+            values = values.reshape(values.shape[0], -1).mean(1) if values.shape[0] == lab.shape[0] else values.mean(0)
+        uniq, inv = np.unique(lab, return_inverse=True)
+        means = np.bincount(inv, weights=values, minlength=uniq.shape[0]) / np.bincount(inv, minlength=uniq.shape[0])
+        rank = np.empty(uniq.shape[0], dtype=np.int64)
+        rank[np.argsort(means, kind="stable")] = np.arange(uniq.shape[0])
+        self.labels_ = rank[inv]
         return self.labels_
 
     def fit_predict(self, G, sample_indicator, likelihood=None, **kwargs):
