@@ -298,7 +298,7 @@ int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, do
  *   blk_ndist [nb]      int32   distinct columns of the block
  *   seg       [meld_pt_seg_len(nb)] int32  per (block, wave, tile) entry offsets
  *   list_cols [nnz]     int32   block b's sorted distinct columns start at rowptr[blk_row[b]]
- *   pval      [nnz]     fp64    values in layout order
+ *   pval      [nnz]     fp64    values in layout order   (+ optional pval32 [nnz] fp32, see the struct)
  *   pidx      [nnz]     uint32  tile-local column | row slot << log2(tile_cols)                   */
 typedef struct meld_pt_layout {
   const int32_t* blk_row;
@@ -309,6 +309,8 @@ typedef struct meld_pt_layout {
   const double* pval;
   const uint32_t* pidx;
   int32_t nb;
+  const float* pval32; /* optional [nnz]: pval rounded to fp32, streamed by the Lanczos SpMV of the lmax estimate
+                          (meld_pt_lanczos_*) instead of pval; NULL = not kept */
 } meld_pt_layout_t;
 int meld_pt_geometry(int* consumer_waves, int* rows_max, int* tile_cols, int* tiles_max);
 int meld_pt_num_blocks(int64_t n_rows); /* nb the builder wants for n_rows local rows */

@@ -103,7 +103,7 @@ class PtLayout(C.Structure):
     """``meld_pt_layout_t`` of include/meld_hip.h (device pointers of the panel-tiled copy of W)."""
 
     _fields_ = [("blk_row", _ptr), ("blk_ntile", _ptr), ("blk_ndist", _ptr), ("seg", _ptr), ("list_cols", _ptr),
-                ("pval", _ptr), ("pidx", _ptr), ("nb", C.c_int32)]
+                ("pval", _ptr), ("pidx", _ptr), ("nb", C.c_int32), ("pval32", _ptr)]
 
 
 _lib = None

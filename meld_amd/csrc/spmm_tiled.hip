@@ -61,6 +61,7 @@ struct StepArgs {
   const int32_t* seg;        // [nb][NW][SEGW] offsets relative to the block's first entry
   const int32_t* list_cols;  // [nnz] block b's sorted distinct columns start at rowptr[blk_row[b]]
   const double* pval;        // [nnz] values in (block, wave, tile, row, col) order
+  const float* pval32;       // [nnz] the same rounded to fp32 (F32 instantiation: the lmax estimate's SpMV)
   const uint32_t* pidx;      // [nnz] tile-local column | row slot << 11
   const int64_t* rowptr;     // CSR row pointers (entry base of a block)
   const double* dw;
@@ -119,7 +120,10 @@ static_assert(U == 8, "the consumer stream names its 8 slots (v96..v119) and wai
 __device__ __forceinline__ int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_bump(int* p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <int P>
+// F32: the matrix VALUES are streamed from the fp32 copy (8 instead of 12 bytes per nonzero); vectors, products and
+// sums stay fp64.  Only the Lanczos SpMV of the lmax estimate uses it: rounding W to fp32 moves the largest
+// eigenvalue by < 1e-7 relative, far inside the tolerance that estimate is computed to (and the 1.01 factor on it).
+template <int P, bool F32>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void pt_step_kernel(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* acc = lds;               // [NW][SLOTS][P]
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     const int sgv = a.seg[((size_t)b * (NW + 1) + w) * SEGW + lane];
     auto sg = [&](int t) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(sgv, t); };
     const double* pv = a.pval + ebase;
+    const float* pv32 = a.pval32 + ebase;
     const uint32_t* pi = a.pidx + ebase;
     const int e_begin = sg(0);
     const int e_end = sg(T);
@@ -195,6 +200,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
                :                                                                                            \
                : "v"(off8), "v"(off4), "s"(pv), "s"(pi)                                                     \
                : "memory", "v" #VLO, "v" #VHI, "v" #IX)
+#define PT_SLOT_LOAD32(VLO, VHI, IX)                                                                   \
+  asm volatile("global_load_dword v" #VLO ", %0, %1 nt\n\tglobal_load_dword v" #IX ", %0, %2 nt"        \
+               :                                                                                         \
+               : "v"(off4), "s"(pv32), "s"(pi)                                                           \
+               : "memory", "v" #VLO, "v" #VHI, "v" #IX)
 #define PT_SLOT_TAKE(VLO, VHI, IX)                                                                                     \
   asm volatile("s_waitcnt vmcnt(14)\n\tv_mov_b32 %0, v" #VLO "\n\tv_mov_b32 %1, v" #VHI "\n\tv_mov_b32 %2, v" #IX \
                : "=v"(t_lo), "=v"(t_hi), "=v"(t_ix)                                                                    \
@@ -204,15 +214,28 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       const int n = (tp < T) ? min(64, pend - pe) : 0;
       const int e = min(pe + lane, e_last);
       const unsigned off8 = (unsigned)e * 8u, off4 = (unsigned)e * 4u;
-      switch (u) {  // (u is a constant after unrolling)
-        case 0: PT_SLOT_LOAD(96, 97, 112); break;
-        case 1: PT_SLOT_LOAD(98, 99, 113); break;
-        case 2: PT_SLOT_LOAD(100, 101, 114); break;
-        case 3: PT_SLOT_LOAD(102, 103, 115); break;
-        case 4: PT_SLOT_LOAD(104, 105, 116); break;
-        case 5: PT_SLOT_LOAD(106, 107, 117); break;
-        case 6: PT_SLOT_LOAD(108, 109, 118); break;
-        default: PT_SLOT_LOAD(110, 111, 119); break;
+      if constexpr (F32) {
+        switch (u) {  // (u is a constant after unrolling)
+          case 0: PT_SLOT_LOAD32(96, 97, 112); break;
+          case 1: PT_SLOT_LOAD32(98, 99, 113); break;
+          case 2: PT_SLOT_LOAD32(100, 101, 114); break;
+          case 3: PT_SLOT_LOAD32(102, 103, 115); break;
+          case 4: PT_SLOT_LOAD32(104, 105, 116); break;
+          case 5: PT_SLOT_LOAD32(106, 107, 117); break;
+          case 6: PT_SLOT_LOAD32(108, 109, 118); break;
+          default: PT_SLOT_LOAD32(110, 111, 119); break;
+        }
+      } else {
+        switch (u) {
+          case 0: PT_SLOT_LOAD(96, 97, 112); break;
+          case 1: PT_SLOT_LOAD(98, 99, 113); break;
+          case 2: PT_SLOT_LOAD(100, 101, 114); break;
+          case 3: PT_SLOT_LOAD(102, 103, 115); break;
+          case 4: PT_SLOT_LOAD(104, 105, 116); break;
+          case 5: PT_SLOT_LOAD(106, 107, 117); break;
+          case 6: PT_SLOT_LOAD(108, 109, 118); break;
+          default: PT_SLOT_LOAD(110, 111, 119); break;
+        }
       }
       ct[u] = tp;
       cn[u] = n;
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
         case 6: PT_SLOT_TAKE(108, 109, 118); break;
         default: PT_SLOT_TAKE(110, 111, 119); break;
       }
-      v = __hiloint2double(t_hi, t_lo);
+      v = F32 ? (double)__int_as_float(t_lo) : __hiloint2double(t_hi, t_lo);
       ix = t_ix;
     };
     int cur = -1;  // the tile this wave holds (-1: none yet); tiles are entered in order, every one exactly once
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #undef PT_SLOT_LOAD
+#undef PT_SLOT_LOAD32
 #undef PT_SLOT_TAKE
     if (srow >= 0 && !(ab & 1)) {  // the last run of every lane
       lds_add(myacc + P * srow, s0);
@@ -515,8 +539,8 @@ constexpr int GPT = (GROUPS_MAX + THREADS - 1) / THREADS;  // groups per thread 
 __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ val, int64_t n_cols,
     int nb, const int32_t* __restrict__ blk_row, int32_t* __restrict__ blk_ntile, int32_t* __restrict__ blk_ndist,
-    int32_t* __restrict__ seg, int32_t* __restrict__ list_cols, double* __restrict__ pval, uint32_t* __restrict__ pidx,
-    int32_t* __restrict__ status, int stop /* timing only: leave after stage `stop` (0 = run everything) */) {
+    int32_t* __restrict__ seg, int32_t* __restrict__ list_cols, double* __restrict__ pval, float* __restrict__ pval32,
+    uint32_t* __restrict__ pidx, int32_t* __restrict__ status, int stop /* timing only: leave after stage `stop` (0 = run everything) */) {
   __shared__ int16_t s_pmap[NPAN_MAX];          // panel -> compact index of the touched panels (ascending), -1
   __shared__ uint32_t s_bits[TP_MAX][BP / 32];  // one bit per column of every touched panel
   __shared__ int32_t s_gpre[GROUPS_MAX + 1];    // distinct columns before each group of GW bitmap words
@@ -766,6 +790,7 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
               // instruction writes a few 8-byte pieces of ~27 x 64 different cache lines.)
               const int64_t pos = e0 + st + cch * 64 + l;
               pval[pos] = v;
+              if (pval32 != nullptr) pval32[pos] = (float)v;
               pidx[pos] = (uint32_t)(g & (CP - 1)) | ((uint32_t)k << CP_BITS);
             }
           }
@@ -888,18 +913,19 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
   hipLaunchKernelGGL(pt::pt_build_kernel, dim3(nb), dim3(pt::THREADS), 0, st, rowptr, col, val, n_cols, nb, layout->blk_row,
                      const_cast<int32_t*>(layout->blk_ntile), const_cast<int32_t*>(layout->blk_ndist),
                      const_cast<int32_t*>(layout->seg), const_cast<int32_t*>(layout->list_cols),
-                     const_cast<double*>(layout->pval), const_cast<uint32_t*>(layout->pidx), status, (g_pt_ablate >> 8) & 7);
+                     const_cast<double*>(layout->pval), const_cast<float*>(layout->pval32), const_cast<uint32_t*>(layout->pidx), status,
+                     (g_pt_ablate >> 8) & 7);
   MELD_LAUNCH_CHECK("pt_build_kernel");
   return MELD_OK;
 }
 
 namespace {
-template <int P>
+template <int P, bool F32>
 int pt_launch(const pt::StepArgs& a, hipStream_t st) {
   static bool configured = false;
   constexpr size_t lds = sizeof(double) * (size_t)(pt::RMAX + pt::NB * pt::CP) * P;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt::pt_step_kernel<P>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pt::pt_step_kernel<P, F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       set_err("pt_step_kernel: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -908,23 +934,23 @@ int pt_launch(const pt::StepArgs& a, hipStream_t st) {
     configured = true;
   }
   const unsigned grid = (unsigned)(ceil_div(a.nb, 8) * 8);
-  hipLaunchKernelGGL((pt::pt_step_kernel<P>), dim3(grid), dim3(pt::THREADS), lds, st, a);
+  hipLaunchKernelGGL((pt::pt_step_kernel<P, F32>), dim3(grid), dim3(pt::THREADS), lds, st, a);
   return MELD_OK;
 }
 }  // namespace
 
-static int pt_step_cols(pt::StepArgs a, int p, hipStream_t st) {
+static int pt_step_cols(pt::StepArgs a, int p, hipStream_t st, bool f32) {
   int colofs = 0;
   a.ld = p;
   while (colofs + 2 <= p) {
     a.colofs = colofs;
-    const int rc = pt_launch<2>(a, st);
+    const int rc = pt_launch<2, false>(a, st);
     if (rc != MELD_OK) return rc;
     colofs += 2;
   }
   if (colofs < p) {
     a.colofs = colofs;
-    const int rc = pt_launch<1>(a, st);
+    const int rc = f32 ? pt_launch<1, true>(a, st) : pt_launch<1, false>(a, st);
     if (rc != MELD_OK) return rc;
   }
   return MELD_OK;
@@ -941,7 +967,9 @@ int meld::pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double
   a.z = z; a.y = y; a.r = r; a.dots = dots; a.coef_dev = coef_dev; a.x_row_offset = x_row_offset; a.alpha = alpha;
   a.beta = beta; a.gamma = gamma; a.coef = coef; a.nb = L->nb; a.ld = p; a.colofs = 0;
   a.ablate = g_pt_ablate;
-  return pt_step_cols(a, p, st);
+  a.pval32 = L->pval32;
+  // the fp32 copy of the values serves the lmax estimate only (p = 1 with device-resident Lanczos scalars)
+  return pt_step_cols(a, p, st, coef_dev != nullptr && p == 1 && L->pval32 != nullptr);
 }
 
 extern "C" int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,

@@ -180,14 +180,16 @@ class DeviceGraph:
     def lmax(self, value):
         self._lmax = None if value is None else float(value)
 
-    def estimate_lmax(self, recompute=False, tol=3e-4, max_iter=300, method="lanczos"):
+    def estimate_lmax(self, recompute=False, tol=1e-3, max_iter=300, method="lanczos"):
         """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
         ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
         tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos
         recurrence on the device SpMV is run to a relative Ritz residual ``tol``: measured on the 1M-cell
-        benchmark graph the eigenvalue error is 9e-8 relative at 3e-4 (40 iterations), 4e-9 at 1e-4 (45),
-        1.2e-6 at 1e-3 (35) -- the error goes with the square of the residual.  No-op when a value is already set
-        (same as pygsp), which is how parity tests inject a common lmax."""
+        benchmark graph the eigenvalue error is 1.2e-6 relative at the default 1e-3 (35 iterations), 9e-8 at 3e-4
+        (40), 4e-9 at 1e-4 (45) -- the error goes with the square of the residual; 1.2e-6 is 1/40 of the spread of
+        the reference's own estimate between two runs.  On the panel-tiled layout the SpMV streams an fp32 copy of
+        the weights (vectors and sums fp64): that moves the eigenvalue by < 1e-7 relative.  No-op when a value is
+        already set (same as pygsp), which is how parity tests inject a common lmax."""
         if self._lmax is not None and not recompute:
             return self._lmax
         if method == "arpack":
@@ -720,9 +722,11 @@ class HipOps:
             blk_row=torch.empty(nb + 1, **i32), blk_ntile=torch.empty(nb, **i32), blk_ndist=torch.empty(nb, **i32),
             seg=torch.empty(int(lib.meld_pt_seg_len(nb)), **i32), list_cols=torch.empty(G.nnz, **i32),
             pval=torch.empty(G.nnz, dtype=torch.float64, device=dev), pidx=torch.empty(G.nnz, **i32),
+            pval32=torch.empty(G.nnz, dtype=torch.float32, device=dev),  # fp32 values for the lmax estimate's SpMV
         )
         status = torch.zeros(1, **i32)
-        lay = PtLayout(*(t[k].data_ptr() for k in ("blk_row", "blk_ntile", "blk_ndist", "seg", "list_cols", "pval", "pidx")), nb)
+        lay = PtLayout(*(t[k].data_ptr() for k in ("blk_row", "blk_ntile", "blk_ndist", "seg", "list_cols", "pval", "pidx")), nb,
+                       t["pval32"].data_ptr())
         with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
             check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, C.byref(lay), ptr(status), _stream()),
                   "meld_pt_build")

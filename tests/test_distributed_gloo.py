@@ -64,7 +64,7 @@ def test_sharded_fit_transform_equals_oracle(world, n, n_labels, d, n_pca, tmp_p
     lam = float(sparse.linalg.eigsh(G.L, k=1, tol=1e-12, return_eigenvectors=False)[0])
     for r in ranks:
         assert float(r["lmax"]) == float(ranks[0]["lmax"])
-    assert abs(float(ranks[0]["lmax"]) / 1.01 - lam) / lam < 1e-6
+    assert abs(float(ranks[0]["lmax"]) / 1.01 - lam) / lam < 5e-5  # default Lanczos tolerance 1e-3: eigenvalue error ~ tol^2
     # densities: identical on every rank and equal to the oracle with the same lmax
     samples, ind = mo.sample_indicators(labels)
     ref = mo.meld_filter(ind, G, beta=40, chebyshev_order=25, lmax=float(ranks[0]["lmax"]))

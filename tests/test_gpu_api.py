@@ -484,3 +484,18 @@ def test_mnn_three_samples_and_argument_checks():
         meld_amd.MELD(verbose=0).fit(X, sample_idx=np.zeros(450))
     with pytest.raises(ValueError, match="same length"):
         meld_amd.MELD(verbose=0).fit(X, sample_idx=batch[:-1])
+
+
+def test_verbose_prints_the_stage_lines(capsys):
+    """with verbose the build reports its stages the way graphtools does through tasklogger
+    (reference notebooks/MELD_Quickstart.ipynb:190-198)."""
+    meld = _meld()
+    X = np.random.default_rng(0).normal(size=(3000, 10))
+    meld.MELD(verbose=1, knn=7).fit(X)
+    out = capsys.readouterr().out
+    for piece in ("Building graph on 3000 samples and 10 features.", "Calculating graph and diffusion operator...",
+                  "Calculating KNN search...", "Calculated KNN search in ", "Calculated affinities in ",
+                  "Calculated graph and diffusion operator in "):
+        assert piece in out, out
+    meld.MELD(verbose=0, knn=7).fit(X)
+    assert capsys.readouterr().out == ""

@@ -194,7 +194,7 @@ def test_fit_transform_parity_50k_config_scaled():
     op2 = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30)
     op2.fit_transform(X, labels)
     lam = float(sparse.linalg.eigsh(G.L, k=1, tol=1e-10, return_eigenvectors=False)[0])
-    assert abs(op2.graph.lmax / 1.01 - lam) / lam < 1e-6
+    assert abs(op2.graph.lmax / 1.01 - lam) / lam < 2e-5  # default Lanczos tolerance 1e-3 (eigenvalue error ~ tol^2)
     assert abs(op2.graph.lmax - G.lmax) / G.lmax < 5e-3
 
 

@@ -195,9 +195,9 @@ def test_tiled_kernel_on_a_row_shard():
     y1 = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
     G.ops.lanczos_spmv(G, x1, z1, y1, state, dots)
     ref1 = 0.5 * (np.ravel(Wl.sum(1)) * xf[r0:r1, 0] - Wl @ xf[:n, 0]) - 0.25 * z1.cpu().numpy()
-    assert _rel(y1.cpu().numpy(), ref1) < 1e-13
+    assert _rel(y1.cpu().numpy(), ref1) < 1e-6  # (the lmax estimate's SpMV streams the fp32 copy of the weights)
     s = G.ops.dot_slots()
-    assert abs(dots[:s].sum().item() - float(ref1 @ xf[r0:r1, 0])) < 1e-10
+    assert abs(dots[:s].sum().item() - float(ref1 @ xf[r0:r1, 0])) < 1e-5 * abs(float(ref1 @ xf[r0:r1, 0])) + 1e-9
     # an empty shard: nothing launched, nothing raised
     E = DeviceGraph(torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
                     torch.zeros(0, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev),
@@ -228,7 +228,12 @@ def test_lmax_and_densities_do_not_depend_on_the_recurrence_kernel():
     op2 = meld_amd.MELD(knn=15, chebyshev_order=30).fit(G2)
     out2 = op2.transform(labels)
     assert G2.info["spmm"] == "csr"
-    assert abs(G2.lmax - lm_t) <= 1e-10 * lm_t
-    assert np.abs(out.values - out2.values).max() <= 1e-9 * np.abs(out2.values).max()
+    # the tiled Lanczos streams the fp32 copy of the weights: the two estimates agree to ~1e-7, both are within the
+    # Lanczos tolerance's eigenvalue error of the converged value
+    assert abs(G2.lmax - lm_t) <= 1e-6 * lm_t
     lam = float(sparse.linalg.eigsh(G.L, k=1, tol=1e-10, return_eigenvectors=False)[0])
-    assert abs(lm_t / 1.01 - lam) <= 1e-6 * lam
+    assert abs(lm_t / 1.01 - lam) <= 2e-5 * lam and abs(G2.lmax / 1.01 - lam) <= 2e-5 * lam
+    # ... and with the same lmax the two recurrence kernels give the same densities to rounding
+    G2.lmax = lm_t
+    out2 = op2.transform(labels)
+    assert np.abs(out.values - out2.values).max() <= 1e-12 * np.abs(out2.values).max()
