@@ -320,9 +320,11 @@ int meld_pt_debug_ablate(int mask);
 /* Build the layout of the local rows [0, n_rows) of a CSR matrix with n_cols columns (the arrays of
  * `layout` are written).  status[1] (device) receives 0, or the reason the layout cannot be used:
  * 1 = a block touches too many column panels, 2 = too many distinct columns in a block,
- * 3 = n_cols beyond the builder's index range -- the caller then stays on meld_cheby_step. */
+ * 3 = n_cols beyond the builder's index range, 4 = a (wave, tile) segment beyond 65535 entries -- the caller then stays on
+ * meld_cheby_step. */
 int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, int64_t n_rows, int64_t n_cols,
-                  const meld_pt_layout_t* layout, int32_t* status, meld_stream_t stream);
+                  const meld_pt_layout_t* layout, uint32_t* codes /* scratch, nnz entries */, int32_t* status,
+                  meld_stream_t stream);
 /* meld_cheby_step on the layout (p = 1, 2 or any p as passes of 2 + 1 columns; dots as there). */
 int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
                        const double* x_full, int64_t x_row_offset, const double* z, double* y, double* r,

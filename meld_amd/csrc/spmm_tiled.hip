@@ -539,8 +539,8 @@ constexpr int GPT = (GROUPS_MAX + THREADS - 1) / THREADS;  // groups per thread 
 __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const double* __restrict__ val, int64_t n_cols,
     int nb, const int32_t* __restrict__ blk_row, int32_t* __restrict__ blk_ntile, int32_t* __restrict__ blk_ndist,
-    int32_t* __restrict__ seg, int32_t* __restrict__ list_cols, double* __restrict__ pval, float* __restrict__ pval32,
-    uint32_t* __restrict__ pidx, int32_t* __restrict__ status, int stop /* timing only: leave after stage `stop` (0 = run everything) */) {
+    int32_t* __restrict__ seg, int32_t* __restrict__ list_cols, uint32_t* __restrict__ codes, int32_t* __restrict__ status,
+    int stop /* timing only: leave after stage `stop` (0 = run everything) */) {
   __shared__ int16_t s_pmap[NPAN_MAX];          // panel -> compact index of the touched panels (ascending), -1
   __shared__ uint32_t s_bits[TP_MAX][BP / 32];  // one bit per column of every touched panel
   __shared__ int32_t s_gpre[GROUPS_MAX + 1];    // distinct columns before each group of GW bitmap words
@@ -548,9 +548,8 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
   __shared__ int32_t s_cnt[NW][SEGW];           // entries per (wave, tile), then running cursors
   __shared__ int s_scan[THREADS / 64 + 1];
   __shared__ int32_t s_rp[RMAX + 1];            // row pointers of the block, relative to its first entry
-  __shared__ int s_ord[SEGW], s_inv[SEGW];      // processing order of the tiles <-> chunk of the column list
+  __shared__ int s_ord[SEGW];                    // processing order of the tiles: j -> chunk of the column list
   __shared__ int s_tmp[3][SEGW];
-  __shared__ int s_len[NW][SEGW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -691,170 +690,261 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     }
   }
   if (stop == 2) return;
-  // Passes B2 and C: every owner wave walks ITS rows in order, lanes = the row's entries (one coalesced load per
-  // row, RU rows in flight).  B2 counts the wave's entries per tile, C appends every entry to its (wave, tile)
-  // segment.  A row's entries are sorted by column, so the entries of one tile are a run of consecutive lanes; the
-  // per-tile counters / cursors of a wave live in ONE VGPR (lane t = tile t; T <= 63) that the entry lanes read with
-  // ds_bpermute and the run heads update with ds_permute -- no loop over the tiles of a row, no LDS memory in the
-  // dependent chain of the walk.
-  constexpr int RU = 8;  // rows in flight
+  // The walk: every owner wave goes through ITS rows in order, lanes = the row's entries (one coalesced load per
+  // work item, RU items in flight), and counts its entries per tile.  A row's entries are sorted by column, so the
+  // entries of one tile are a run of consecutive lanes; the per-tile counters of a wave live in ONE VGPR (lane t =
+  // tile t; T <= 63) that the entry lanes read with ds_bpermute and the run heads update with ds_permute -- no loop
+  // over the tiles of a row, no LDS memory in the dependent chain.  Every entry leaves a 32-bit code behind
+  // (list chunk | position within its (wave, tile) segment in (row, column) order | tile-local column), from which
+  // pt_fill_kernel places it without any ordering constraint.
+  constexpr int RU = 8;  // work items in flight
   const int nmine = (w < NW && nrows > w) ? (nrows - w + NW - 1) / NW : 0;
   const int64_t elast = max(e1 - 1, e0);
   const uint64_t le = ((uint64_t)2 << lane) - 1;  // lanes <= mine
-  int seg_start = 0;  // lane j: start of this wave's segment of the j-th processed tile
-  int inv_v = lane;   // lane c: processing position of list chunk c (pass 1)
-  int seg_len = 0;    // lane j: entries of this wave in the j-th processed tile
-  for (int pass = 0; pass < 2; ++pass) {
-    int curs = 0;  // lane t: entries of tile t seen so far
-    if (w < NW && e1 > e0) {
-      // Work items = (row, 64-entry part of it), in order; RU of them are in flight.  The fetch cursor runs ahead of
-      // the walk on its own (row bounds come from LDS), so the walk itself is ONE loop without inner loops or loads
-      // behind branches -- hipcc's wait-count pass puts s_waitcnt vmcnt(0) at every loop header / join it cannot see
-      // through, which made every row wait for the row fetched last (1.5 us per row, 0.47 ms per pass).
-      int fk = 0, fpart = 0;  // fetch cursor: row index among this wave's rows, part of it
-      int ik[RU], ioff[RU], iend[RU];  // item: row index, first entry (relative to e0), end of the row
-      int cc[RU];
-      double vv[RU];
-      auto fetch = [&](int u) __attribute__((always_inline)) {
-        int rs = 0, rend = 0;
-        if (fk < nmine) {
-          const int rl = w + fk * NW;
-          rs = s_rp[rl];
-          rend = s_rp[rl + 1];
+  int curs = 0;  // lane t: entries of list chunk t seen so far
+  if (w < NW && e1 > e0) {
+    // Work items = (row, 64-entry part of it), in order.  The fetch cursor runs ahead of the walk on its own (row
+    // bounds come from LDS), so the walk itself is ONE loop without inner loops or loads behind branches -- hipcc's
+    // wait-count pass puts s_waitcnt vmcnt(0) at every loop header / join it cannot see through, which made every
+    // row wait for the row fetched last (1.5 us per row).
+    int fk = 0, fpart = 0;  // fetch cursor: row index among this wave's rows, part of it
+    int ik[RU], ioff[RU], iend[RU];  // item: row index, first entry (relative to e0), end of the row
+    int cc[RU];
+    auto fetch = [&](int u) __attribute__((always_inline)) {
+      int rs = 0, rend = 0;
+      if (fk < nmine) {
+        const int rl = w + fk * NW;
+        rs = s_rp[rl];
+        rend = s_rp[rl + 1];
+      }
+      ik[u] = fk;
+      ioff[u] = rs + fpart * 64;
+      iend[u] = rend;
+      cc[u] = col[min(e0 + ioff[u] + lane, elast)];
+      // next item: the next part of a row longer than a wave, else the next row
+      const bool more_parts = ioff[u] + 64 < rend;
+      fpart = more_parts ? fpart + 1 : 0;
+      fk = more_parts ? fk : fk + 1;
+    };
+#pragma unroll
+    for (int u = 0; u < RU; ++u) fetch(u);
+    bool busy = nmine > 0;
+    bool too_long = false;
+    while (busy) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int k = ik[u];
+        const int off = ioff[u], rend = iend[u];
+        const int c = cc[u];
+        fetch(u);
+        const bool act = (k < nmine) && (off + lane < rend);  // (the active lanes are 0 .. n - 1)
+        const int g = act ? col_rank(c) : 0;
+        const int ch = g >> CP_BITS;  // chunk of the column list: non-decreasing along the lanes
+        const int chp = __shfl_up(ch, 1, 64);
+        const bool head = act && (lane == 0 || ch != chp);
+        const uint64_t hm = __ballot(head);
+        const int nact = __popcll(__ballot(act));
+        const int hl = 63 - __clzll((unsigned long long)(hm & le));                    // head lane of my run
+        const uint64_t above = (lane == 63) ? 0 : (hm >> (lane + 1));
+        const int run_end = above ? lane + __ffsll((unsigned long long)above) : nact;  // one past my run
+        const int pos = __builtin_amdgcn_ds_bpermute(ch << 2, curs) + (lane - hl);     // position in the segment
+        if (act) {
+          too_long |= pos > 0xFFFF;
+          codes[e0 + off + lane] = ((uint32_t)ch << 26) | ((uint32_t)(pos & 0xFFFF) << CP_BITS) | (uint32_t)(g & (CP - 1));
         }
-        ik[u] = fk;
-        ioff[u] = rs + fpart * 64;
-        iend[u] = rend;
-        const int64_t e = min(e0 + ioff[u] + lane, elast);
-        cc[u] = col[e];
-        if (pass == 1) vv[u] = val[e];
-        // next item: the next part of a row longer than a wave, else the next row
-        const bool more_parts = ioff[u] + 64 < rend;
-        fpart = more_parts ? fpart + 1 : 0;
-        fk = more_parts ? fk : fk + 1;
-      };
-#pragma unroll
-      for (int u = 0; u < RU; ++u) fetch(u);
-      bool busy = nmine > 0;
-      while (busy) {
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-          const int k = ik[u];
-          const int off = ioff[u], rend = iend[u];
-          const int c = cc[u];
-          const double v = (pass == 1) ? vv[u] : 0.0;
-          fetch(u);
-          const bool act = (k < nmine) && (off + lane < rend);  // (the active lanes are 0 .. n - 1)
-          const int g = act ? col_rank(c) : 0;
-          const int ch = g >> CP_BITS;  // chunk of the column list: non-decreasing along the lanes
-          // pass 0 counts per list chunk, pass 1 works in the processing order of the tiles
-          const int tl = (pass == 0) ? ch : __builtin_amdgcn_ds_bpermute(ch << 2, inv_v);
-          const int chp = __shfl_up(ch, 1, 64);
-          const bool head = act && (lane == 0 || ch != chp);
-          const uint64_t hm = __ballot(head);
-          const int nact = __popcll(__ballot(act));
-          const int hl = 63 - __clzll((unsigned long long)(hm & le));        // head lane of my run
-          const uint64_t above = (lane == 63) ? 0 : (hm >> (lane + 1));
-          const int run_end = above ? lane + __ffsll((unsigned long long)above) : nact;  // one past my run
-          if (pass == 1) {
-            const int c0 = __builtin_amdgcn_ds_bpermute(tl << 2, curs);
-            const int st = __builtin_amdgcn_ds_bpermute(tl << 2, seg_start);
-            const int n = __builtin_amdgcn_ds_bpermute(tl << 2, seg_len);
-            if (act) {
-              // Logical position i of the entry in its segment ((row, column) order: start of the (wave, tile)
-              // segment + entries of it seen so far); stored TRANSPOSED over the 64 lanes of the consumer wave:
-              // lane l owns a contiguous run of the segment and chunk c holds each lane's c-th entry (n = 64 q + r
-              // entries: lanes < r own q + 1 of them, the others q).  One instruction of the consumer then touches
-              // 64 entries that are n/64 apart in (row, column) order -- different rows -- and a lane meets the
-              // entries of a row in consecutive chunks, so it can sum the run in registers.
-              const int i = c0 + (lane - hl);
-              const int q = n >> 6, r = n & 63;
-              auto divu = [](int x, int d, float rcp) __attribute__((always_inline)) {  // x, d < 2^24
-                int qq = (int)((float)x * rcp);
-                qq -= (qq * d > x) ? 1 : 0;
-                qq += ((qq + 1) * d <= x) ? 1 : 0;
-                return qq;
-              };
-              int l, cch;
-              if (i < r * (q + 1)) {
-                l = divu(i, q + 1, 1.0f / (float)(q + 1));
-                cch = i - l * (q + 1);
-              } else {
-                const int jj = i - r * (q + 1);
-                const int lq = divu(jj, max(q, 1), 1.0f / (float)max(q, 1));
-                l = r + lq;
-                cch = jj - lq * q;
-              }
-              // (Written straight from the walk: a staging pass through LDS that transposes whole segments costs
-              // the same.  The stores are the expensive part of the build -- 0.8 of its 1.5 ms at 1M cells: every
-              // instruction writes a few 8-byte pieces of ~27 x 64 different cache lines.)
-              const int64_t pos = e0 + st + cch * 64 + l;
-              pval[pos] = v;
-              if (pval32 != nullptr) pval32[pos] = (float)v;
-              pidx[pos] = (uint32_t)(g & (CP - 1)) | ((uint32_t)k << CP_BITS);
-            }
+        // every run head adds the length of its run to the counter of its tile (lane 63 is the dump of the other
+        // lanes: tile indices are <= 62)
+        curs += __builtin_amdgcn_ds_permute((head ? ch : 63) << 2, head ? run_end - lane : 0);
+        if (u == RU - 1) busy = ik[0] < nmine;  // (uniform) items are in order: nothing left once slot 0 is past the end
+      }
+    }
+    if (__any(too_long)) atomicMax(status, 4);
+  }
+  if (stop == 3) return;
+  if (w < NW) s_cnt[w][lane] = (lane < T) ? curs : 0;
+  __syncthreads();
+  if (tid == 0) {
+    // Processing order of the tiles.  A tile of the iterate takes the loaders about as long to stage whether ten
+    // or ten thousand entries use it, so the order alternates heavy and light tiles: one of the heaviest left,
+    // then two of the lightest left -- while the consumers work through a heavy tile the ring (NB = 4 buffers)
+    // fills with the two light ones and the next heavy one.  j-th processed tile = chunk s_ord[j] of the list.
+    int* tot = s_tmp[0];
+    int* srt = s_tmp[1];
+    for (int t = 0; t < T; ++t) {
+      int c = 0;
+      for (int ow = 0; ow < NW; ++ow) c += s_cnt[ow][t];
+      tot[t] = c;
+      int k = t;
+      while (k > 0 && tot[srt[k - 1]] < c) {  // insertion sort, descending
+        srt[k] = srt[k - 1];
+        --k;
+      }
+      srt[k] = t;
+    }
+    int hi = 0, lo = T - 1, j = 0;
+    while (hi <= lo) {
+      s_ord[j++] = srt[hi++];
+      for (int k = 0; k < 2 && hi <= lo; ++k) s_ord[j++] = srt[lo--];
+    }
+    for (int jj = T; jj < SEGW; ++jj) s_ord[jj] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {  // segment offsets, (wave, processing order): a wave's stream is contiguous
+    int run = 0;
+    for (int ow = 0; ow < NW; ++ow) {
+      int* tmp = s_tmp[2];
+      for (int jj = 0; jj < SEGW; ++jj) tmp[jj] = (jj < T) ? s_cnt[ow][s_ord[jj]] : 0;
+      for (int jj = 0; jj < SEGW; ++jj) {
+        s_cnt[ow][jj] = run;
+        run += tmp[jj];
+      }
+    }
+    blk_ntile[b] = T;
+    blk_ndist[b] = ndist;
+  }
+  __syncthreads();
+  if (w < NW) {
+    seg[((size_t)b * (NW + 1) + w) * SEGW + lane] = s_cnt[w][lane];
+  } else if (w == NW) {
+    seg[((size_t)b * (NW + 1) + NW) * SEGW + lane] = s_ord[lane];  // row NW: list chunk of every processed tile
+  }
+}
+
+// Second step of the layout: one workgroup per (block, owner wave) places the wave's entries.  Every entry knows its
+// segment and its position in it (the code written by pt_build_kernel), so this step has no ordering constraint: the
+// entries are read in CSR order (coalesced), dropped at their final place in an LDS image of the wave's stream, and
+// the image is copied out with full-line stores.  (Storing straight from the walk -- a few 8-byte pieces of ~27 x 64
+// different cache lines per instruction -- cost 0.8 ms of the 1.5 ms build at 1M cells.)
+// Final place within a segment of n = 64 q + r entries: TRANSPOSED over the 64 lanes of the consumer wave -- lane l
+// owns a contiguous run of the segment's (row, column) order (q + 1 entries for l < r, else q) and chunk c holds each
+// lane's c-th entry.  One instruction of the consumer then touches 64 entries that are n/64 apart in (row, column)
+// order, i.e. different rows, and a lane meets the entries of a row in consecutive chunks and can sum the run in
+// registers.
+constexpr int FILL_CAP = 12800;  // entries of the LDS image (12 B each)
+__global__ __launch_bounds__(THREADS) void pt_fill_kernel(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                          const uint32_t* __restrict__ codes, const int32_t* __restrict__ blk_row,
+                                                          const int32_t* __restrict__ blk_ntile, const int32_t* __restrict__ seg,
+                                                          double* __restrict__ pval, uint32_t* __restrict__ pidx) {
+  __shared__ double s_val[FILL_CAP];
+  __shared__ uint32_t s_idx[FILL_CAP];
+  __shared__ int s_seg[SEGW + 1], s_inv[SEGW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x / NW, w = blockIdx.x % NW;
+  const int T = blk_ntile[b];
+  if (T <= 0) return;
+  const int row0 = blk_row[b];
+  const int nrows = blk_row[b + 1] - row0;
+  const int64_t e0 = rowptr[row0];
+  if (tid < SEGW) {
+    s_seg[tid] = seg[((size_t)b * (NW + 1) + w) * SEGW + tid];
+    if (tid < T) s_inv[seg[((size_t)b * (NW + 1) + NW) * SEGW + tid]] = tid;  // list chunk -> processing position
+  }
+  __syncthreads();
+  const int nmine = (nrows > w) ? (nrows - w + NW - 1) / NW : 0;  // rows of owner wave w
+  // this workgroup wave's rows: k = wv, wv + 16, ...; their bounds are loaded once, one row per lane
+  const int kmine = (nmine > wv) ? (nmine - wv + 15) / 16 : 0;  // <= 20 (RMAX / NW / 16)
+  int64_t rs_l = 0, re_l = 0;
+  if (lane < kmine) {
+    const int rl = w + (wv + 16 * lane) * NW;
+    rs_l = rowptr[row0 + rl];
+    re_l = rowptr[row0 + rl + 1];
+  }
+  for (int ja = 0; ja < T;) {  // tile ranges [ja, jb) that fit the LDS image
+    int jb = ja + 1;
+    while (jb < T && s_seg[jb + 1] - s_seg[ja] <= FILL_CAP) ++jb;
+    const int base = s_seg[ja], span = s_seg[jb] - s_seg[ja];
+    if (span <= FILL_CAP) {
+      auto place = [&](uint32_t code, double v, int k) __attribute__((always_inline)) {
+        const int j = s_inv[code >> 26];
+        if (j >= ja && j < jb) {
+          const int pos = (code >> CP_BITS) & 0xFFFF;
+          const int n = s_seg[j + 1] - s_seg[j];
+          const int q = n >> 6, r = n & 63;
+          int l, cch;
+          if (pos < r * (q + 1)) {
+            l = pos / (q + 1);
+            cch = pos - l * (q + 1);
+          } else {
+            const int jj = pos - r * (q + 1);
+            const int lq = jj / max(q, 1);
+            l = r + lq;
+            cch = jj - lq * q;
           }
-          // every run head adds the length of its run to the cursor of its tile (lane 63 is the dump of the
-          // other lanes: tile indices are <= 62)
-          curs += __builtin_amdgcn_ds_permute((head ? tl : 63) << 2, head ? run_end - lane : 0);
-          if (u == RU - 1) busy = ik[0] < nmine;  // (uniform) items are in order: nothing left once slot 0 is past the end
+          const int p = s_seg[j] - base + cch * 64 + l;
+          s_val[p] = v;
+          s_idx[p] = (code & (CP - 1)) | ((uint32_t)k << CP_BITS);
+        }
+      };
+      constexpr int FG = 6;  // rows in flight per wave (their first 64 entries; what is longer follows in a plain loop)
+      for (int i0 = 0; i0 < kmine; i0 += FG) {
+        uint32_t code[FG];
+        double v[FG];
+        int64_t rs[FG], rend[FG];
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+          const int i = min(i0 + g, kmine - 1);
+          rs[g] = __shfl(rs_l, i, 64);
+          rend[g] = (i0 + g < kmine) ? __shfl(re_l, i, 64) : rs[g];
+          const int64_t e = min(rs[g] + lane, max(rend[g] - 1, rs[g]));
+          code[g] = codes[e];
+          v[g] = val[e];
+        }
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+          const int k = wv + 16 * (i0 + g);
+          if (rs[g] + lane < rend[g]) place(code[g], v[g], k);
+          for (int64_t e = rs[g] + 64 + lane; e < rend[g]; e += 64) place(codes[e], val[e], k);
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < span; i += THREADS) {
+        pval[e0 + base + i] = s_val[i];
+        pidx[e0 + base + i] = s_idx[i];
+      }
+      __syncthreads();
+    } else {
+      // one segment longer than the image (never on kNN graphs): its entries go out directly
+      for (int i = 0; i < kmine; ++i) {
+        const int k = wv + 16 * i;
+        const int64_t rs = __shfl(rs_l, i, 64), rend = __shfl(re_l, i, 64);
+        for (int64_t e = rs + lane; e < rend; e += 64) {
+          const uint32_t code = codes[e];
+          const int j = s_inv[code >> 26];
+          if (j == ja) {
+            const int pos = (code >> CP_BITS) & 0xFFFF;
+            const int n = s_seg[j + 1] - s_seg[j];
+            const int q = n >> 6, r = n & 63;
+            int l, cch;
+            if (pos < r * (q + 1)) {
+              l = pos / (q + 1);
+              cch = pos - l * (q + 1);
+            } else {
+              const int jj = pos - r * (q + 1);
+              const int lq = jj / max(q, 1);
+              l = r + lq;
+              cch = jj - lq * q;
+            }
+            const int64_t p = e0 + s_seg[j] + cch * 64 + l;
+            pval[p] = val[e];
+            pidx[p] = (code & (CP - 1)) | ((uint32_t)k << CP_BITS);
+          }
         }
       }
     }
-    if (pass == 0) {
-      if (stop == 3) return;
-      if (w < NW) s_cnt[w][lane] = (lane < T) ? curs : 0;
-      __syncthreads();
-      if (tid == 0) {
-        // Processing order of the tiles.  A tile of the iterate takes the loaders about as long to stage whether ten
-        // or ten thousand entries use it, so the order alternates heavy and light tiles: one of the heaviest left,
-        // then two of the lightest left -- while the consumers work through a heavy tile the ring (NB = 4 buffers)
-        // fills with the two light ones and the next heavy one.  j-th processed tile = chunk s_ord[j] of the list.
-        int* tot = s_tmp[0];
-        int* srt = s_tmp[1];
-        for (int t = 0; t < T; ++t) {
-          int c = 0;
-          for (int ow = 0; ow < NW; ++ow) c += s_cnt[ow][t];
-          tot[t] = c;
-          int k = t;
-          while (k > 0 && tot[srt[k - 1]] < c) {  // insertion sort, descending
-            srt[k] = srt[k - 1];
-            --k;
-          }
-          srt[k] = t;
-        }
-        int hi = 0, lo = T - 1, j = 0;
-        while (hi <= lo) {
-          s_ord[j++] = srt[hi++];
-          for (int k = 0; k < 2 && hi <= lo; ++k) s_ord[j++] = srt[lo--];
-        }
-        for (int jj = 0; jj < T; ++jj) s_inv[s_ord[jj]] = jj;
-        for (int jj = T; jj < SEGW; ++jj) s_ord[jj] = 0;
-      }
-      __syncthreads();
-      if (tid == 0) {  // segment offsets, (wave, processing order) : a wave's stream is contiguous
-        int run = 0;
-        for (int ow = 0; ow < NW; ++ow) {
-          int* tmp = s_tmp[2];
-          for (int jj = 0; jj < SEGW; ++jj) tmp[jj] = (jj < T) ? s_cnt[ow][s_ord[jj]] : 0;
-          for (int jj = 0; jj < SEGW; ++jj) {
-            s_cnt[ow][jj] = run;
-            s_len[ow][jj] = tmp[jj];
-            run += tmp[jj];
-          }
-        }
-        blk_ntile[b] = T;
-        blk_ndist[b] = ndist;
-      }
-      __syncthreads();
-      inv_v = s_inv[lane];
-      if (w < NW) {
-        seg_start = s_cnt[w][lane];
-        seg_len = s_len[w][lane];
-        seg[((size_t)b * (NW + 1) + w) * SEGW + lane] = seg_start;
-      } else if (w == NW) {
-        seg[((size_t)b * (NW + 1) + NW) * SEGW + lane] = s_ord[lane];  // row NW: list chunk of every processed tile
-      }
+    ja = jb;
+  }
+}
+
+// pval32[e] = (float)pval[e] for the layout's nnz entries (nnz read from rowptr[n_rows] on the device)
+__global__ __launch_bounds__(256) void pt_round_f32_kernel(const double* __restrict__ pval, float* __restrict__ pval32, int64_t,
+                                                           const int64_t* __restrict__ rowptr, int64_t n_rows) {
+  const int64_t nnz = rowptr[n_rows];
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < nnz; i += (int64_t)gridDim.x * blockDim.x * 2) {
+    if (i + 1 < nnz) {
+      const double2 v = *reinterpret_cast<const double2*>(pval + i);
+      *reinterpret_cast<float2*>(pval32 + i) = make_float2((float)v.x, (float)v.y);
+    } else {
+      pval32[i] = (float)pval[i];
     }
   }
 }
@@ -895,9 +985,9 @@ extern "C" int meld_pt_num_blocks(int64_t n_rows) {
 extern "C" int64_t meld_pt_seg_len(int nb) { return (int64_t)nb * (pt::NW + 1) * pt::SEGW; }
 
 extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, int64_t n_rows, int64_t n_cols,
-                             const meld_pt_layout_t* layout, int32_t* status, meld_stream_t stream) {
+                             const meld_pt_layout_t* layout, uint32_t* codes, int32_t* status, meld_stream_t stream) {
   MELD_CHECK_ARG(rowptr && col && val && layout && layout->blk_row && layout->blk_ntile && layout->blk_ndist && layout->seg &&
-                     layout->list_cols && layout->pval && layout->pidx && status && n_rows > 0 && layout->nb > 0 && n_cols > 0,
+                     layout->list_cols && layout->pval && layout->pidx && codes && status && n_rows > 0 && layout->nb > 0 && n_cols > 0,
                  "meld_pt_build: bad arguments");
   const int nb = layout->nb;
   MELD_CHECK_ARG((int64_t)nb * pt::RMAX >= n_rows, "meld_pt_build: %d blocks of %d rows cannot hold %lld rows", nb, pt::RMAX,
@@ -913,8 +1003,13 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
   hipLaunchKernelGGL(pt::pt_build_kernel, dim3(nb), dim3(pt::THREADS), 0, st, rowptr, col, val, n_cols, nb, layout->blk_row,
                      const_cast<int32_t*>(layout->blk_ntile), const_cast<int32_t*>(layout->blk_ndist),
                      const_cast<int32_t*>(layout->seg), const_cast<int32_t*>(layout->list_cols),
-                     const_cast<double*>(layout->pval), const_cast<float*>(layout->pval32), const_cast<uint32_t*>(layout->pidx), status,
-                     (g_pt_ablate >> 8) & 7);
+                     codes, status, (g_pt_ablate >> 8) & 7);
+  if (((g_pt_ablate >> 8) & 7) == 0)
+    hipLaunchKernelGGL(pt::pt_fill_kernel, dim3(nb * pt::NW), dim3(pt::THREADS), 0, st, rowptr, val, codes, layout->blk_row,
+                       layout->blk_ntile, layout->seg, const_cast<double*>(layout->pval), const_cast<uint32_t*>(layout->pidx));
+  if (layout->pval32 != nullptr)  // (its own streaming pass: a third scattered store in the walk costs 0.5 ms, this 0.08)
+    hipLaunchKernelGGL(pt::pt_round_f32_kernel, dim3(2048), dim3(256), 0, st, layout->pval, const_cast<float*>(layout->pval32),
+                       (int64_t)0, rowptr, n_rows);
   MELD_LAUNCH_CHECK("pt_build_kernel");
   return MELD_OK;
 }

@@ -727,9 +727,11 @@ class HipOps:
         status = torch.zeros(1, **i32)
         lay = PtLayout(*(t[k].data_ptr() for k in ("blk_row", "blk_ntile", "blk_ndist", "seg", "list_cols", "pval", "pidx")), nb,
                        t["pval32"].data_ptr())
+        codes = torch.empty(G.nnz, **i32)  # scratch of the builder
         with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
-            check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, C.byref(lay), ptr(status), _stream()),
-                  "meld_pt_build")
+            check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, C.byref(lay), ptr(codes), ptr(status),
+                                    _stream()), "meld_pt_build")
+        del codes
         st = int(status.item())
         if st != 0:  # cannot be laid out (see include/meld_hip.h): stay on the CSR-stream kernel
             G.info["spmm"] = "csr (tiled layout refused: status {})".format(st)

@@ -7,5 +7,6 @@ for n in 1000000 500000; do
   (cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/trace_$n -o t -- python $OLDPWD/bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input > $OLDPWD/$out/trace_${n}_stdout.log 2>&1)
   db=$(ls $out/trace_$n/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/kernel_stats_$n.md
+  rm -rf $out/trace_$n   # (the rocpd database is ~50 MB; gpurun_out is capped at 64 MiB)
 done
 ls -la $out
