@@ -31,10 +31,10 @@
 namespace meld {
 namespace pt {
 
-constexpr int NW = 14;                    // consumer waves = row owners
-constexpr int NL = 2;                     // loader waves
+constexpr int NW = 12;                    // consumer waves = row owners
+constexpr int NL = 4;                     // loader waves
 constexpr int THREADS = 64 * (NW + NL);   // 1024: one workgroup per CU
-constexpr int SLOTS = 320;                // accumulator rows per consumer wave
+constexpr int SLOTS = 384;                // accumulator rows per consumer wave
 constexpr int RMAX = NW * SLOTS;          // 4480 rows per block at most
 constexpr int CP = 1024;                  // columns per staged tile
 constexpr int CP_BITS = 10;
@@ -75,8 +75,9 @@ struct StepArgs {
   double alpha, beta, gamma, coef;
   int nb;
   int ld, colofs;
-  int ablate;  // timing-only modes (results wrong): 1 no accumulator updates, 2 no LDS gather, 4 no panel loads,
-               // 8 panel gathers from a 16 KB window of x, 16 consumers do not wait for the panels
+  int ablate;  // timing-only modes (results wrong): 4 no panel loads, 8 panel gathers from a 16 KB window of x,
+               // 16 consumers do not wait for the panels  (1 / 2, no accumulator updates / no LDS gather, were removed
+               // from the hot loop once measured: DESIGN section 4.4)
 };
 
 template <int P>
@@ -111,6 +112,8 @@ __device__ __forceinline__ void stg(double* __restrict__ base, int64_t row, int 
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+__device__ __forceinline__ double& pr0_sink(const double& x) { return const_cast<double&>(x); }
 
 constexpr int U = 8;  // entry chunks (64 nonzeros each) in flight per consumer wave
 static_assert(U == 8, "the consumer stream names its 8 slots (v96..v119) and waits with vmcnt(2 (U - 1))");
@@ -286,13 +289,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     // few lanes whose row changed (hardly any bank conflict).
     auto accumulate = [&](bool act, double v, int sl, const V<P>& xv) __attribute__((always_inline)) {
       if (act) {
+        // (the products first: their LDS wait then precedes the flush below instead of also covering it)
+        const double pr0 = v * xv.v[0];
+        double pr1 = 0.0;
+        if constexpr (P == 2) pr1 = v * xv.v[1];
+        asm volatile("" : "+v"(pr0_sink(pr0)), "+v"(pr0_sink(pr1)));
         const bool same = sl == srow;
-        if (!same && srow >= 0 && !(ab & 1)) {
+        if (!same && srow >= 0) {
           lds_add(myacc + P * srow, s0);
           if constexpr (P == 2) lds_add(myacc + 2 * srow + 1, s1);
         }
-        s0 = same ? s0 + v * xv.v[0] : v * xv.v[0];
-        if constexpr (P == 2) s1 = same ? s1 + v * xv.v[1] : v * xv.v[1];
+        s0 = same ? s0 + pr0 : pr0;
+        if constexpr (P == 2) s1 = same ? s1 + pr1 : pr1;
         srow = sl;
       }
     };
@@ -327,20 +335,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
           uint32_t ix;
           take(u, v, ix);  // (in the first round: whatever the slot registers held; n == 0, nothing is used)
           issue(u);  // the slot is free again: chunk k + U
+          // ---- stage 2 of the previous chunk FIRST: its x values were requested a whole step ago, so the LDS wait
+          // in front of the products is free; the gather of this chunk goes out at the END of the step and has the
+          // next step's entry wait to land (requested before the products, the wait for the previous gather also
+          // waited for the one just issued: a full LDS round trip per step)
+          accumulate(h_act, h_v, h_sl, h_x);
           if (cur < t) advance(t);
           const double* pan = pans + (size_t)(t & (NB - 1)) * CP * P;
           const int cl = ix & (CP - 1);
           const bool act = lane < n;
           V<P> xv;
           if constexpr (P == 1) {
-            xv.v[0] = (ab & 2) ? 1.0 : pan[act ? cl : 0];
+            xv.v[0] = pan[act ? cl : 0];
           } else {
-            const double2 t2 = (ab & 2) ? make_double2(1.0, 1.0) : *reinterpret_cast<const double2*>(pan + 2 * (act ? cl : 0));
+            const double2 t2 = *reinterpret_cast<const double2*>(pan + 2 * (act ? cl : 0));
             xv.v[0] = t2.x;
             xv.v[1] = t2.y;
           }
-          // ---- stage 2 of the previous chunk
-          accumulate(h_act, h_v, h_sl, h_x);
           h_act = act;
           h_v = v;
           h_sl = (int)(ix >> CP_BITS);
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
 #undef PT_SLOT_LOAD
 #undef PT_SLOT_LOAD32
 #undef PT_SLOT_TAKE
-    if (srow >= 0 && !(ab & 1)) {  // the last run of every lane
+    if (srow >= 0) {  // the last run of every lane
       lds_add(myacc + P * srow, s0);
       if constexpr (P == 2) lds_add(myacc + 2 * srow + 1, s1);
     }

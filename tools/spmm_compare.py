@@ -75,7 +75,7 @@ for mode in ("csr", "tiled"):
 if os.environ.get("PT_ABLATE", "1") != "0":
     from meld_amd._lib import get_lib
     lib = get_lib()
-    for mask, what in ((1, "no accumulator updates"), (3, "no LDS gather, no updates"), (4, "no panel loads"), (7, "stream + barriers only"), (8, "panel gathers from a 16 KB window"), (16, "consumers ignore panel readiness"), (19, "ignore readiness, no LDS work")):
+    for mask, what in ((4, "no panel loads"), (8, "panel gathers from a 16 KB window"), (16, "consumers ignore panel readiness")):
         lib.meld_pt_debug_ablate(mask)
         for pp in (p, 1):
             x = torch.rand(n, pp, dtype=torch.float64, device="cuda")
