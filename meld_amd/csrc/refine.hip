@@ -283,11 +283,19 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
   }
 }
 
-// bw is the (knn+1)-th smallest distance iff at most knn references are strictly closer
-__global__ void radius_check_kernel(int* __restrict__ lt_then_cursor, int n_flag, int knn, int* __restrict__ err_flag) {
+// bw is the (knn+1)-th smallest distance iff at most knn references are strictly closer.  A row whose bandwidth
+// was clipped to eps (more than knn exact duplicates of the cell: the true bandwidth is 0, graphtools uses eps and
+// the duplicates get K = 1) is fine by definition.  A row that fails gets fb_cnt = -1 (and err_flag): its
+// candidate list missed one of its knn nearest cells, the caller recomputes its bandwidth exactly and sweeps again.
+__global__ void radius_check_kernel(int* __restrict__ lt_then_cursor, int n_flag, int knn, int* __restrict__ err_flag,
+                                    const int* __restrict__ flag_rows, const double* __restrict__ bw_all,
+                                    int* __restrict__ fb_cnt) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_flag) return;
-  if (lt_then_cursor[f] > knn) atomicOr(err_flag, 1);
+  if (lt_then_cursor[f] > knn && bw_all[flag_rows[f]] > DBL_EPSILON) {
+    atomicOr(err_flag, 1);
+    fb_cnt[f] = -1;
+  }
   lt_then_cursor[f] = 0;
 }
 
@@ -345,7 +353,7 @@ extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t 
                      ref_chunk, pow(-log(thresh), 1.0 / decay));
   if (mode == 0)
     hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, st, fb_cursor, n_flag, knn,
-                       err_flag);
+                       err_flag, flag_rows, bw, fb_cnt);
   MELD_LAUNCH_CHECK("radius_exact_kernel");
   return MELD_OK;
 }

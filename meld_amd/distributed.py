@@ -156,7 +156,7 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     if not isinstance(X, torch.Tensor):
         X = torch.from_numpy(np.ascontiguousarray(np.asarray(getattr(X, "values", X)), dtype=np.float64))
     X = X.to(device=ops.device, dtype=torch.float64).contiguous()
-    if op.thresh == 0 or op.n_landmark is not None or op.decay is None:
+    if op.thresh == 0 or op.decay is None:  # (n_landmark: accepted, the filter never uses the landmark operator)
         raise NotImplementedError("the sharded builder supports the sparse alpha-decay kNN graph only")
     unsupported = sorted(k for k in op.kwargs if k not in ("ksel",))
     if unsupported:  # e.g. sample_idx (MNN graph): single-GPU only

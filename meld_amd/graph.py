@@ -121,6 +121,7 @@ class DeviceGraph:
         # caller's original order
         self.perm = None
         self.bandwidth = None
+        self.n_landmark = None
 
     @classmethod
     def from_scipy(cls, W, device="cuda"):
@@ -281,6 +282,13 @@ class DeviceGraph:
         if getattr(self, "_kdiag", None) is not None:  # dense graph: the diagonal was computed explicitly
             return (self.W + sparse.diags(self._vec_host(self._kdiag), 0)).tocsr()
         return (self.W + sparse.diags(self._vec_host(self.kernel_diagonal()), 0)).tocsr()
+
+    @property
+    def landmark_op(self):
+        """graphtools' LandmarkGraph operator (reference ``meld/meld.py:105`` forwards ``n_landmark``): lazily built
+        there, never used by MELD's filter; not implemented here."""
+        raise NotImplementedError("the landmark operator (graphtools LandmarkGraph.landmark_op) is not implemented; "
+                                  "MELD's density estimate does not use it")
 
     def kernel_diagonal(self):
         """Diagonal of the kernel matrix K in the device order: K_ii = 1 / (ksum_i^2)^anisotropy for a
@@ -599,6 +607,7 @@ class HipOps:
             return out
 
         # exact sweep for rows the candidate list could not certify
+        n_rebandwidth = 0
         fb_total = 0
         fb_off = fb_col = fb_val = None
         if n_flag_h > 0:
@@ -613,13 +622,30 @@ class HipOps:
                 ),
                 "meld_knn_radius_exact(count)",
             )
+            if int(err.item()) != 0:
+                # rows whose candidate list missed one of their knn nearest cells (marked fb_cnt = -1: more than knn
+                # references are strictly closer than the bandwidth the list implied): their bandwidth is recomputed
+                # exactly over all references -- a rare library path (fp64 screen + direct differences) -- and the
+                # sweep is counted again (graphtools re-searches such rows with more neighbours)
+                bad = torch.nonzero(fb_cnt < 0).reshape(-1)
+                rows_bad = flag_rows[bad].to(torch.int64)
+                bw[rows_bad] = _exact_bandwidth(X, q_begin + rows_bad, knn)
+                fb_cnt.zero_()
+                cursor.zero_()
+                err.zero_()
+                check(
+                    lib.meld_knn_radius_exact(
+                        ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
+                        ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
+                    ),
+                    "meld_knn_radius_exact(recount)",
+                )
+                if int(err.item()) != 0:
+                    raise NotImplementedError(
+                        "degenerate neighbourhoods: the exact sweep could not settle the bandwidth of {} rows".format(int((fb_cnt < 0).sum())))
+                n_rebandwidth = int(bad.shape[0])
             fb_off = _scan_i32(lib, fb_cnt, st)
             fb_total = int(fb_off[n_flag_h].item())
-            if int(err.item()) != 0:
-                raise NotImplementedError(
-                    "degenerate neighbourhoods (more than {} references tie below the bandwidth of a row); "
-                    "this data needs the dense exact graph".format(ksel)
-                )
             fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
             fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
             check(  # (the count pass left the cursors at zero)
@@ -647,6 +673,7 @@ class HipOps:
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
                     prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), split_tail=bool(self.split_tail),
+                    n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
                     wave_tiles_done=int(tiles_done.item()) if tiles_done is not None else None)
@@ -805,6 +832,23 @@ class HipOps:
 
     def axpby(self, a, x, b, y, nrm2=None):
         check(self.lib.meld_axpby_f64(float(a), ptr(x), float(b), ptr(y), y.numel(), ptr(nrm2), _stream()), "meld_axpby_f64")
+
+
+def _exact_bandwidth(X, rows, knn):
+    """Distance to the (knn+1)-th nearest cell (self included) of the given rows over ALL references, exactly:
+    an fp64 GEMM-form screen keeps the 4 (knn + 1) nearest, their distances are recomputed by direct differences.
+    Library path for the handful of rows the exact sweep finds with an incomplete candidate list."""
+    n2 = (X * X).sum(1)
+    out = torch.empty(rows.shape[0], dtype=torch.float64, device=X.device)
+    kk = min(int(X.shape[0]), 4 * (knn + 1))
+    for lo in range(0, rows.shape[0], 256):
+        r = rows[lo : lo + 256]
+        Xq = X[r]
+        d2 = n2[r][:, None] + n2[None, :] - 2.0 * (Xq @ X.T)
+        cand = torch.topk(d2, kk, dim=1, largest=False).indices
+        dist = torch.linalg.vector_norm(X[cand] - Xq[:, None, :], dim=2)
+        out[lo : lo + 256] = torch.sort(dist, dim=1).values[:, min(knn, kk - 1)]
+    return out.clamp_(min=float(np.finfo(np.float64).eps))
 
 
 def resolve_graph_params(N, knn, thresh, ksel):

@@ -38,7 +38,7 @@ class MELD(GraphEstimator):
     lap_type : {'combinatorial', 'normalized'}, default 'combinatorial' (validated and stored;
         like the reference it is never forwarded, the Laplacian is always combinatorial)
     sample_normalize : bool, default True -- indicator columns are scaled to sum to 1
-    anisotropy : default 1;  n_landmark : default None (landmarking is not implemented)
+    anisotropy : default 1;  n_landmark : default None (accepted; the filter never uses graphtools' landmark operator)
     **kwargs : graph parameters -- knn=5, decay=40, n_pca=100, thresh=1e-4,
         distance='euclidean', n_jobs, random_state, verbose; ``ksel`` (candidate list length of the
         GPU search) and ``lmax`` are extensions: a number injects the Laplacian's spectral bound,
@@ -121,8 +121,6 @@ class MELD(GraphEstimator):
             raise NotImplementedError(
                 "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
             )
-        if self.n_landmark is not None:
-            raise NotImplementedError("n_landmark is not implemented by the MI355X graph builder")
         if self.decay is None and self.thresh == 0:
             raise NotImplementedError("decay=None with thresh=0 (dense unweighted graph) is not implemented")
         if not torch.cuda.is_available():
@@ -156,11 +154,18 @@ class MELD(GraphEstimator):
             from .dense import build_dense_graph
 
             return build_dense_graph(X, knn=self.knn, decay=self.decay, anisotropy=self.anisotropy)
-        return build_knn_graph(
+        G = build_knn_graph(
             X, knn=self.knn, decay=float("inf") if self.decay is None else self.decay,  # None: unweighted kNN graph
             thresh=self.thresh, anisotropy=self.anisotropy,
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)),
         )
+        # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the
+        # same kernel, weights and Laplacian as the plain kNN graph -- the landmark operator is a lazily built extra
+        # (`landmark_op`, `transitions`, `interpolate`) that MELD's filter never touches -- so the densities do not
+        # depend on it.  The parameter is accepted and recorded; asking the graph for the landmark operator itself is
+        # what is not implemented.
+        G.n_landmark = self.n_landmark
+        return G
 
     # -- indicators (reference meld/meld.py:143-191) ------------------------------------------------
     @staticmethod

@@ -204,8 +204,13 @@ def test_unsupported_options_fail_loudly():
     labels = np.random.choice(["a", "b"], size=100)
     out = meld.MELD(verbose=0).fit_transform(data, labels, sample_idx=labels)  # MNN graph (reference test_mnn): supported
     assert out.shape == (100, 2) and np.isfinite(out.values).all()
+    # n_landmark (reference meld/meld.py:105): a LandmarkGraph's kernel / Laplacian are those of the plain graph, so the
+    # densities are the same; only the landmark operator itself is not offered
+    a = meld.MELD(n_landmark=50, verbose=0).fit_transform(data, labels)
+    b = meld.MELD(verbose=0).fit_transform(data, labels)
+    assert np.array_equal(a.values, b.values)
     with pytest.raises(NotImplementedError):
-        meld.MELD(n_landmark=50).fit(data)
+        meld.MELD(n_landmark=50, verbose=0).fit(data).graph.landmark_op
     with pytest.raises(NotImplementedError):
         meld.MELD(verbose=0).fit(data, bandwidth=1.0)  # graph kwargs the builder does not know
     with pytest.raises(NotImplementedError):

@@ -181,3 +181,14 @@ def test_many_uncertified_rows_trigger_one_search_with_the_longest_list():
     G = mo.build_graph(X, knn=10)
     W = op.graph.W
     assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+
+
+def test_more_exact_duplicates_than_the_candidate_list_holds():
+    """A cell with more exact copies than ksel (32 at knn = 5): its true bandwidth is 0, graphtools clips it to eps and
+    the copies get K = 1 among themselves (reference path: re-search, then radius search).  The exact sweep used to
+    refuse such rows ('degenerate neighbourhoods'); now they come out as the oracle builds them."""
+    rng = np.random.default_rng(3)
+    base = rng.normal(size=(400, 5))
+    X = np.concatenate([base, np.repeat(base[:1], 45, axis=0), np.repeat(base[1:2], 70, axis=0)])
+    DG, G = _check_graph(X, knn=5)
+    assert np.isfinite(DG.dw).all() and DG.info["n_flagged_rows"] >= 115
