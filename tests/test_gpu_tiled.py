@@ -237,3 +237,28 @@ def test_lmax_and_densities_do_not_depend_on_the_recurrence_kernel():
     G2.lmax = lm_t
     out2 = op2.transform(labels)
     assert np.abs(out.values - out2.values).max() <= 1e-12 * np.abs(out2.values).max()
+
+
+def test_graphs_the_layout_refuses_stay_on_the_csr_kernel():
+    """A block of a random (non-kNN) graph can touch more distinct columns than 63 tiles hold: the builder reports it
+    (status 2), the graph stays on the CSR-stream kernel, results unchanged."""
+    from meld_amd.graph import HipOps
+    import meld_amd
+
+    n = 200_000
+    rng = np.random.default_rng(0)
+    rows = np.repeat(np.arange(n), 64)
+    cols = rng.integers(0, n, size=rows.shape[0])
+    A = sparse.csr_matrix((rng.random(rows.shape[0]) + 0.1, (rows, cols)), shape=(n, n))
+    W = ((A + A.T) * 0.5).tocsr()
+    W.setdiag(0)
+    W.eliminate_zeros()
+    W.sort_indices()
+    G = meld_amd.DeviceGraph.from_scipy(W)
+    G.ops = HipOps(spmm="tiled")
+    x = rng.normal(size=(n, 2))
+    y = torch.empty(n, 2, dtype=torch.float64, device="cuda")
+    G.ops.cheby_step(G, 2, torch.from_numpy(x).cuda(), 0, None, y, None, 1.0, 0.0, 0.0, 0.0)
+    assert G.info["spmm"].startswith("csr (tiled layout refused")
+    ref = np.ravel(W.sum(1))[:, None] * x - W @ x
+    assert _rel(y.cpu().numpy(), ref) < 1e-13
