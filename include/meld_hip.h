@@ -105,12 +105,17 @@ int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, in
  * (meld_assign_nearest ordering).  lb2 = NULL disables pruning.  q_begin (a multiple of TS) = global
  * index of query 0 (the scan of every workgroup starts at its own position among the references and
  * wraps around).
+ * thr_seed (optional, q_count floats, scaled units) = the thr_init the search of the same queries will be
+ * started with (meld_knn16_seed_thresholds*), nprod = that search's products: thresholds only fall, so a tile
+ * that no query of the wave can reach from its OWN start threshold (|p - c_t| - rho_t > sqrt(seed_p + E) for
+ * all 64 cells p) is marked +inf in the table.  The table is then valid only for a search started from
+ * exactly these thresholds (or lower ones).
  * No reference counterpart: graphtools delegates the search to sklearn's trees. */
 size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                      const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count, void* temp,
-                      void* lb2, meld_stream_t stream);
+                      const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
+                      const float* thr_seed, int nprod, void* temp, void* lb2, meld_stream_t stream);
 /* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are

@@ -335,6 +335,8 @@ class HipOps:
         self.radius_cut = os.environ.get("MELD_KNN_RADIUS_CUT", "1") != "0"
         # thresholds of the first pass seeded from every row's own block (meld_knn16_seed_thresholds)
         self.seed = os.environ.get("MELD_KNN_SEED", "1") != "0"
+        # per-query test of the pruning table against those seeds (meld_knn16_bounds, thr_seed)
+        self.seeded_bounds = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
         # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
         # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
         # waves and the sliced launch costs more than the idle tail, so it is off
@@ -365,7 +367,7 @@ class HipOps:
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
-        used_prune = used_seed = False
+        used_prune = used_seed = used_seeded_bounds = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if search == "wide":
@@ -440,18 +442,13 @@ class HipOps:
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
             lb2 = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
-            if self.prune and q_begin % TS == 0 and N >= 16384:
-                tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
-                tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
-                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
-                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
-                tm.stop("bounds")
+            will_prune = self.prune and q_begin % TS == 0 and N >= 16384
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
             # of the chip idle is searched separately with the references cut into slices, so that its
             # few query blocks x slices fill the chip again.
             n_blocks = q_pad // BQ
             q_main, tail_slices = q_count, 1
-            if lb2 is None and self.split_tail:
+            if not will_prune and self.split_tail:
                 resident = lib.meld_knn16_resident_blocks(d, nprod)
                 if resident < 0:
                     check(resident, "meld_knn16_resident_blocks")
@@ -469,6 +466,15 @@ class HipOps:
                 else:
                     check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
+            if will_prune:
+                # (after the seeds: with them the table also drops the tiles no query of a wave can reach from
+                # its own start threshold, see meld_knn16_bounds)
+                tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
+                tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
+                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
+                seeded_bounds = seeds is not None and self.seeded_bounds
+                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
                 if q_main < q_count:
@@ -482,6 +488,7 @@ class HipOps:
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             used_prune, used_seed = lb2 is not None, seeds is not None
+            used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
@@ -672,7 +679,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), split_tail=bool(self.split_tail),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), split_tail=bool(self.split_tail),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)

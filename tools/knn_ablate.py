@@ -25,7 +25,10 @@ norm2 = torch.empty(N, dtype=torch.float32, device="cuda"); nmax = torch.zeros(1
 check(lib.meld_knn16_prepare(ptr(Xd), N, d, ptr(mean), 0, N, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
 tmpb = torch.empty(lib.meld_knn16_bounds_temp_bytes(N, d, N), dtype=torch.uint8, device="cuda")
 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, N), dtype=torch.uint8, device="cuda")
-check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(tmpb), ptr(lb2), st))
+mseed = torch.empty(q_pad, dtype=torch.float32, device="cuda")   # the product's seeds (neighbourhood of the own block, on the matrix pipe)
+check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), ptr(nmax), N, d, 0, N, 15, (-math.log(1e-4)) ** (1 / 40), 1, ptr(mseed), st))
+seeded_table = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
+check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(mseed) if seeded_table else None, 1, ptr(tmpb), ptr(lb2), st))
 ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
 cthr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device="cuda"); done = torch.zeros(1, dtype=torch.int64, device="cuda")
 rf = (-math.log(1e-4)) ** (1 / 40)
@@ -41,17 +44,12 @@ def run(seed, label):
 
 abl = os.environ.get("MELD_KNN16_ABLATION")
 if abl is None:
-    run(None, "product"); run(None, "product")
-    seed = (cthr * float(sinfo[0]) ** 2 * 1.0001).contiguous()
+    run(mseed, "product (seeds of the own neighbourhood)"); run(mseed, "product (seeds of the own neighbourhood)")
+    seed = torch.minimum(cthr * float(sinfo[0]) ** 2 * 1.0001, mseed).contiguous()
     torch.save(seed.cpu(), "/tmp/knn_seed.pt")
     run(seed, "product, thresholds seeded with the final ones")
-    for f in (1.2, 1.5, 2.0, 3.0):
-        run((seed * f).contiguous(), "product, seeds = %.1f x the final thresholds" % f)
-    own = torch.empty(q_pad, dtype=torch.float32, device="cuda")
-    check(lib.meld_knn16_seed_thresholds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), 0, N, knn, rf, 1, ptr(own), st))
-    run(own, "product, seeds from the own block (the default)")
-    print("own-block seed / final threshold: median %.2f, p90 %.2f" % (float((own[:N] / seed[:N]).median()), float(torch.quantile((own[:N] / seed[:N])[:200000], 0.9))))
-    for a, name in (("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("9", "MFMAs only, no tile loads")):
+    print("seed / final threshold: median %.2f, p90 %.2f" % (float((mseed[:N] / seed[:N]).median()), float(torch.quantile((mseed[:N] / seed[:N])[:200000], 0.9))))
+    for a, name in (("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
         subprocess.run([sys.executable, __file__, str(n)], env=env)
 else:

@@ -1,0 +1,83 @@
+"""How tight could the tile pruning of the kNN search be?  For sampled waves (64 consecutive cells in the
+locality order) count the reference tiles a rule keeps, against the tiles that really hold a candidate.
+python tools/sim_prune_rules.py [N] [n_waves]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import meld_amd
+from bench import synthetic_cells
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+NW = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+knn, ksel = 15, 64
+rf2 = float(np.log(1e4) ** (2.0 / 40.0))
+X, _ = synthetic_cells(N, 50, seed=0)
+Xd = torch.from_numpy(X).cuda()
+op = meld_amd.MELD(knn=knn, verbose=0).fit(Xd)
+G = op.graph
+Xo = Xd[G.perm]
+T = (N + 63) // 64
+pad = T * 64 - N
+Xp = torch.cat([Xo, Xo[-1:].expand(pad, -1)]) if pad else Xo
+tiles = Xp.view(T, 64, -1)
+C = tiles.mean(1)
+rho = torch.linalg.vector_norm(tiles - C[:, None, :], dim=2).max(1).values
+# two half-tile spheres (32 + 32 cells in index order)
+C2 = tiles.view(T, 2, 32, -1).mean(2)
+rho2 = torch.linalg.vector_norm(tiles.view(T, 2, 32, -1) - C2[:, :, None, :], dim=3).max(2).values
+g = torch.Generator().manual_seed(0)
+waves = torch.randint(0, T - 1, (NW,), generator=g).tolist()
+acc = {}
+def add(k, v):
+    acc.setdefault(k, []).append(float(v))
+n2 = (Xo * Xo).sum(1)
+for w in waves:
+    P = Xo[64 * w: 64 * w + 64]
+    d2 = ((P * P).sum(1)[:, None] + n2[None, :] - 2.0 * P @ Xo.T).clamp_min(0)
+    srt = torch.topk(d2, ksel, dim=1, largest=False).values
+    thr = torch.minimum(srt[:, ksel - 1], rf2 * srt[:, knn])          # final thresholds (error allowance ignored)
+    lo, hi = max(0, 64 * (w - 4)), min(N, 64 * (w + 8))
+    seed = rf2 * torch.topk(d2[:, lo:hi], knn + 1, dim=1, largest=False).values[:, knn]
+    # which tiles hold a candidate
+    hit = (d2 < thr[:, None])
+    hit_p = torch.cat([hit, hit.new_zeros(64, pad)], 1) if pad else hit
+    need = hit_p.view(64, T, 64).any(2).any(0)
+    Dc = torch.cdist(P, C)                     # 64 x T
+    lb = (Dc - rho[None, :]).clamp_min(0)
+    lbmin2 = lb.min(0).values ** 2
+    add("ideal (tile holds a candidate)", need.float().mean())
+    add("A: min_p LB <= max_p thr (final thresholds)", (lbmin2 <= thr.max()).float().mean())
+    add("A: ... with the seeds", (lbmin2 <= seed.max()).float().mean())
+    add("B: any_p LB_p <= thr_p (final)", (lb <= thr.sqrt()[:, None]).any(0).float().mean())
+    add("B: ... with the seeds", (lb <= seed.sqrt()[:, None]).any(0).float().mean())
+    Dc2 = torch.cdist(P, C2.reshape(2 * T, -1)).view(64, T, 2)
+    lbh = (Dc2 - rho2[None]).clamp_min(0)
+    add("C: half-tile spheres, max thr", ((lbh.min(0).values.min(1).values) ** 2 <= thr.max()).float().mean())
+    add("D: half-tile spheres, per query", (lbh.min(2).values <= thr.sqrt()[:, None]).any(0).float().mean())
+    phis = ((lb / seed.sqrt()[:, None]).min(0).values)            # smallest relative radius at which the tile is live
+    phi = (thr.sqrt() / seed.sqrt()).max()
+    add("E: phi rule  min_p LB_p/s_p <= max_p r_p/s_p (final)", (phis <= phi).float().mean())
+    add("F: A(final) and B(seeds)", ((lbmin2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    add("G: A(final) and E", ((lbmin2 <= thr.max()) & (phis <= phi)).float().mean())
+    add("G at the start: A(seeds) and B(seeds)", ((lbmin2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    lo2, hi2 = max(0, 64 * (w - 16)), min(N, 64 * (w + 20))
+    seed2 = rf2 * torch.topk(d2[:, lo2:hi2], knn + 1, dim=1, largest=False).values[:, knn]
+    add("B with seeds from +-16 tiles", (lb <= seed2.sqrt()[:, None]).any(0).float().mean())
+    add("phi (final max r/s)", phi)
+    for K in (12, 24, 48, 96):
+        near = torch.topk(torch.cdist(C[w:w + 1], C)[0], K, largest=False).indices      # nearest tiles by centroid distance
+        cols = (near[:, None] * 64 + torch.arange(64, device=near.device)[None, :]).reshape(-1)
+        cols = cols[cols < N]
+        seedK = rf2 * torch.topk(d2[:, cols], knn + 1, dim=1, largest=False).values[:, knn]
+        add("F with seeds from the %d nearest tiles (centroid distance)" % K, ((lbmin2 <= thr.max()) & (lb <= seedK.sqrt()[:, None]).any(0)).float().mean())
+        add("   seed/thr median ratio, %d nearest" % K, (seedK / thr).median())
+    add("   seed/thr median ratio, +-4 index tiles", (seed / thr).median())
+    for q in (0.9, 0.75):
+        tq = torch.quantile(thr, q)
+        add("A with the %.2f quantile of thr instead of the max (not exact)" % q, (lbmin2 <= tq).float().mean())
+    add("thr max / median", thr.max() / thr.median())
+    add("seed max / thr max", seed.max() / thr.max())
+    add("rho / sqrt(median thr)", rho[w] / thr.median().sqrt())
+print("N = %d, %d sampled waves; product computes %.3f of the blocks" % (N, NW, G.info.get("blocks_computed_frac", float("nan"))))
+for k, v in acc.items():
+    print("  %-70s %.4f" % (k, np.mean(v)))
