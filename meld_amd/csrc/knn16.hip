@@ -114,7 +114,10 @@ __device__ __forceinline__ float from_ordered_bits(unsigned k) {
 // the search-error allowance of the row, the exact bandwidth^2 is <= A + E, so every reference inside the
 // kernel radius has approximate d2 <= R = rf2 (A + E) + E: entries above R are dropped and *r_out = R
 // (+inf when the row has fewer than knn1 entries) lets the caller lower the row's threshold to it.
-__device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, int knn1, float rf2, float err,
+// The rows hold RAW accumulator values during the scan, v = |r|^2 - 2 q.r = d2 - |q|^2 (nq_row = |q|^2 of the row is
+// added when the row is ranked for output): the order within a row is the same, the append path needs no |q|^2, and
+// the thresholds in registers are raw too.  Return value and *r_out are raw.
+__device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, int knn1, float rf2, float err, float nq_row,
                                    float* __restrict__ d2row, int* __restrict__ idxrow, int lane, int* n0_out,
                                    int* n1_out, float* r_out) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's append stores have reached L2
@@ -158,7 +161,7 @@ __device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, int knn1,
       for (int e = 0; e < K16_SLOTS; ++e) c += __popcll(__ballot(key[e] < trial));
       if (c < knn1) A = trial;
     }
-    R = (rf2 * (from_ordered_bits(A) + err) + err) * 1.00001f + 1e-30f;
+    R = (rf2 * ((from_ordered_bits(A) + nq_row) + err) + err) * 1.00001f + 1e-30f - nq_row;
   }
   *r_out = R;
   // survivors: key <= min(T, R) (ties at T all stay; if that leaves no room the caller re-ranks);
@@ -191,7 +194,9 @@ __device__ float knn16_squeeze_row(int n0, int n1, int half, int ksel, int knn1,
 // Ordering of a row: rank by (d2, idx), keep the ksel smallest sorted, scale by out_scale.
 // split_m0 < 0: final form, entry of rank r at slot r.  split_m0 >= 0 (mid-scan, after pathological
 // ties): rank r goes to the half-row position knn16_split_pos(r, split_m0, half).
-__device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_scale, int split_m0,
+// Values are written as (v + add) * out_scale: add = |q|^2 of the row in the final form (the rows hold raw values,
+// see knn16_squeeze_row), 0 mid-scan.
+__device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_scale, float add, int split_m0,
                                float* __restrict__ d2row, int* __restrict__ idxrow, float* sd, int* si, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int n = n0 + n1;
@@ -227,7 +232,7 @@ __device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_sca
   for (int q = 0; q < K16_SLOTS; ++q) {
     if (valid[q] && rk[q] < ksel) {
       const int dst = split_m0 < 0 ? rk[q] : knn16_split_pos(rk[q], split_m0, half);
-      d2row[dst] = d[q] * out_scale;
+      d2row[dst] = (d[q] + add) * out_scale;
       idxrow[dst] = ix[q];
     }
   }
@@ -314,6 +319,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const int tile_lo = (int)((long long)n_tiles * blockIdx.y / gridDim.y);
   const int n_scan = (int)((long long)n_tiles * (blockIdx.y + 1) / gridDim.y) - tile_lo;
   const int row_base = (int)(blockIdx.y * (gridDim.x * K16_BQ)) + q_base;  // first candidate row of this wave
+  float* const wave_d2 = cand_d2 + (size_t)row_base * cap;                // (wave-uniform: SGPR pairs)
+  int* const wave_idx = cand_idx + (size_t)row_base * cap;
 
   // B fragments of both query groups: [g][kb] hi / lo, 8 halves each
   f16x8 bhi[2][KB], blo[2][KB];
@@ -508,25 +515,26 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto squeeze = [&](int g, int j) __attribute__((always_inline)) {
     const int cg = g ? cnt[1] : cnt[0];
     const int n0 = __shfl(cg, j, 64), n1 = __shfl(cg, j + 32, 64);
-    const size_t ro = (size_t)(row_base + g * 32 + j) * cap;
+    const size_t ro = (size_t)(g * 32 + j) * cap;  // (within the wave's rows)
     int m0, m1;
     float rcut = INFINITY, err = 0.0f;
     const int knn1 = K16_COLD(knn1);
+    const float nq_row = __shfl(g ? nq[1] : nq[0], j, 64);
     if (knn1 > 0) {  // search-error allowance of this row, scaled units (refine.hip's E, rounded up)
       const float* sinfo = K16_COLD(scale_info);
       const float nmax_s = K16_COLD(norm2_max)[0] * sinfo[0] * sinfo[0];
-      err = (K16_COLD(err_c) * nmax_s + K16_COLD(err_l) * sqrtf(__shfl(g ? nq[1] : nq[0], j, 64) * nmax_s)) * 1.001f;
+      err = (K16_COLD(err_c) * nmax_s + K16_COLD(err_l) * sqrtf(nq_row * nmax_s)) * 1.001f;
     }
-    float nt = knn16_squeeze_row(n0, n1, half, ksel, knn1, K16_COLD(rf2), err, cand_d2 + ro, cand_idx + ro, lane, &m0, &m1, &rcut);
+    float nt = knn16_squeeze_row(n0, n1, half, ksel, knn1, K16_COLD(rf2), err, nq_row, wave_d2 + ro, wave_idx + ro, lane, &m0, &m1, &rcut);
     if (m0 > half - 32) {
       // pathological ties at the threshold: rank the row down to exactly ksel entries
-      knn16_rank_row(m0, m1, half, ksel, 1.0f, (min(m0 + m1, ksel) + 1) >> 1, cand_d2 + ro, cand_idx + ro, lds_sd[wave],
+      knn16_rank_row(m0, m1, half, ksel, 1.0f, 0.0f, (min(m0 + m1, ksel) + 1) >> 1, wave_d2 + ro, wave_idx + ro, lds_sd[wave],
                      lds_si[wave], lane);
       const int tot = min(m0 + m1, ksel);
       m0 = (tot + 1) >> 1;
       m1 = tot - m0;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      nt = ld_sc1_f(cand_d2 + ro + knn16_split_pos(tot - 1, m0, half));
+      nt = ld_sc1_f(wave_d2 + ro + knn16_split_pos(tot - 1, m0, half));
     }
     if (jq == j) {
       const int mine = h ? m1 : m0;
@@ -535,7 +543,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       // lower: the row holds every reference seen so far whose d2 is below it
       // (a row shorter than ksel keeps its threshold -- the start value -- unless the radius cut lowers it)
       const float t_list = (n0 + n1 >= ksel) ? nt : INFINITY;
-      thrp[g] = fminf(thrp[g], fminf(t_list, rcut) - nq[g]);
+      thrp[g] = fminf(thrp[g], fminf(t_list, rcut));  // (raw, like the row's entries)
     }
     // every load of this cold region has landed when it ends: a result still pending at the join with
     // the hot loop would make the compiler put s_waitcnt vmcnt(0) in front of the next pipeline segment
@@ -559,14 +567,20 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     for (int g = 0; g < 2; ++g) {
       const f32x16 acc = g ? c1 : c0;
       if (!__any((g ? m1 : m0) < thrp[g])) continue;
-      const size_t rowoff = (size_t)(row_base + g * 32 + jq) * cap + (size_t)(h * half);
+      // byte offset of the lane's half-row within the wave's 64 rows: 32 bits, so that a store is one address
+      // instruction (wave base in SGPRs + 32-bit lane offset) instead of a 64-bit multiply-add per append
+      const unsigned rowoff4 = (unsigned)((g * 32 + jq) * cap + h * half) * 4u;
       auto append = [&](int r) __attribute__((always_inline)) {
         const float v = acc[r];
         if (v < thrp[g]) {
-          const int pos = g ? cnt[1]++ : cnt[0]++;
+          const unsigned off4 = rowoff4 + 4u * (unsigned)(g ? cnt[1]++ : cnt[0]++);
           if (ABL == 2) ++st_app;
-          cand_d2[rowoff + pos] = v + nq[g];
-          cand_idx[rowoff + pos] = ref_base + (r & 3) + 8 * (r >> 2);
+          if (ABL == 5) {  // (timing-only ablation: the append without its stores)
+            asm volatile("" ::"v"(off4));
+          } else {
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(wave_d2) + off4) = v;  // raw: |q|^2 is added when the row is ranked
+            *reinterpret_cast<int*>(reinterpret_cast<char*>(wave_idx) + off4) = ref_base + (r & 3) + 8 * (r >> 2);
+          }
         }
       };
 #pragma unroll
@@ -792,18 +806,103 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     cand_thr[row_base + jq] = (thrp[0] + nq[0]) * out_scale;
     cand_thr[row_base + 32 + jq] = (thrp[1] + nq[1]) * out_scale;
   }
-  for (int j = 0; j < 64; ++j) {
-    const int cg = (j >> 5) ? cnt[1] : cnt[0];
-    const int n0 = __shfl(cg, j & 31, 64), n1 = __shfl(cg, (j & 31) + 32, 64);
-    const int qr = row_base + j;
-    const size_t ro = (size_t)qr * cap;
-    knn16_rank_row(n0, n1, half, ksel, out_scale, -1, cand_d2 + ro, cand_idx + ro, lds_sd[wave], lds_si[wave], lane);
-    if (lane == 0) cand_cnt[qr] = min(n0 + n1, ksel);
+  // The rows leave the kernel as they are (raw values, two half-rows each); knn16_finish_rows_kernel, launched right
+  // behind, sorts them.  Ranking them here -- 64 rows per wave one after the other, at three waves per SIMD and
+  // with every workgroup reaching its epilogue at about the same time -- took 4.8 of the search's 51 ms at 1M cells.
+  // cand_cnt carries the two half-row lengths to it.
+  {
+    const int o0 = __shfl_xor(cnt[0], 32, 64), o1 = __shfl_xor(cnt[1], 32, 64);
+    if (h == 0) {
+      cand_cnt[row_base + jq] = cnt[0] | (o0 << 16);
+      cand_cnt[row_base + 32 + jq] = cnt[1] | (o1 << 16);
+    }
   }
 #undef K16_LOAD
 #undef K16_DMA
 #undef K16_STAGED
 #undef K16_ROUND_OK
+}
+
+// Final form of the candidate rows: one wave per row sorts its entries by (value, index) with a bitonic network on
+// 64-bit keys (ordered value bits : index; element i = 64 e + lane, so exchanges at distance >= 64 stay inside a
+// lane and the others are one __shfl_xor), keeps the ksel smallest, converts them to input units
+// ((v + |q|^2) / s^2) and writes the row's length.  cnt: in = half-row lengths n0 | n1 << 16, out = min(n, ksel).
+// 1M rows of <= 128 entries: 0.8 ms (the in-kernel ranking it replaces: 4.8 ms).
+template <int SL>
+__device__ __forceinline__ void k16_bitonic_sort(unsigned long long (&key)[SL], int lane) {
+  constexpr int NE = 64 * SL;
+#pragma unroll
+  for (int k = 2; k <= NE; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int je = j >> 6;
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+          if ((e & je) == 0) {
+            const int i = 64 * e + lane;
+            const bool asc = (i & k) == 0;
+            const unsigned long long a = key[e], b = key[e | je];
+            const bool sw = asc ? (b < a) : (a < b);
+            key[e] = sw ? b : a;
+            key[e | je] = sw ? a : b;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+          const int i = 64 * e + lane;
+          const unsigned long long o = __shfl_xor(key[e], j, 64);
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          key[e] = keep_min ? (o < key[e] ? o : key[e]) : (o < key[e] ? key[e] : o);
+        }
+      }
+    }
+  }
+}
+// (the network is as small as the row allows: most rows hold fewer than 128 entries, many fewer than 64)
+template <int SL>
+__device__ __forceinline__ void k16_finish_row(float* __restrict__ drow, int* __restrict__ irow, int n0, int half, int n_all, int n,
+                                               float add, float out_scale, int lane) {
+  unsigned long long key[SL];
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    const int i = lane + 64 * e;                        // i-th entry of the packed row: first half-row, then second
+    const int p = i < n0 ? i : half + (i - n0);
+    key[e] = ~0ull;
+    if (i < n_all) key[e] = ((unsigned long long)ordered_bits(drow[p] + 0.0f) << 32) | (unsigned)irow[p];  // (+0: -0 and +0 tie)
+  }
+  k16_bitonic_sort<SL>(key, lane);
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    const int i = 64 * e + lane;
+    if (i < n) {
+      drow[i] = (from_ordered_bits((unsigned)(key[e] >> 32)) + add) * out_scale;
+      irow[i] = (int)(unsigned)key[e];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void knn16_finish_rows_kernel(float* __restrict__ d2, int* __restrict__ idx,
+                                                                int* __restrict__ cnt, const float* __restrict__ Qn,
+                                                                const float* __restrict__ scale_info, int64_t n_rows,
+                                                                int64_t q_pad, int cap, int ksel) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int packed = cnt[row];
+  const int n0 = packed & 0xffff, n1 = (packed >> 16) & 0xffff, half = cap >> 1;
+  float* drow = d2 + (size_t)row * cap;
+  int* irow = idx + (size_t)row * cap;
+  const int n_all = n0 + n1, n = min(n_all, ksel);
+  const float add = Qn[row % q_pad], out_scale = scale_info[1];
+  // (every load of the row happens before its first store: all lanes of the wave pass the sort's shuffles in between)
+  if (n_all <= 64)
+    k16_finish_row<1>(drow, irow, n0, half, n_all, n, add, out_scale, lane);
+  else if (n_all <= 128)
+    k16_finish_row<2>(drow, irow, n0, half, n_all, n, add, out_scale, lane);
+  else
+    k16_finish_row<K16_SLOTS>(drow, irow, n0, half, n_all, n, add, out_scale, lane);
+  if (lane == 0) cnt[row] = n;
 }
 
 // Merge the per-slice candidate rows of one query (n_slices * q_pad rows of stride cap) into its
@@ -1728,6 +1827,10 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
       K16_LAUNCH(KBV, 3);              \
     else if (abl == 4 && KBV == 4)     \
       K16_LAUNCH(4, 4);                \
+    else if (abl == 5 && KBV == 4)     \
+      K16_LAUNCH(4, 5);                \
+    else if (abl == 7 && KBV == 4)     \
+      K16_LAUNCH(4, 7);                \
     else if (abl == 8 && KBV == 4)     \
       K16_LAUNCH(4, 8);                \
     else if (abl == 9 && KBV == 4)     \
@@ -1757,6 +1860,13 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
 #undef K16_LAUNCH
 #undef K16_LAUNCH2
   MELD_LAUNCH_CHECK("knn16_topk_kernel");
+  if (abl == 0 || abl == 2 || abl == 5 || abl == 6) {  // (the timing-only ablations leave no rows to sort)
+    const int64_t n_rows = (int64_t)grid.x * K16_BQ * grid.y;
+    const dim3 fgrid((unsigned)ceil_div(n_rows, 4));
+    hipLaunchKernelGGL(knn16_finish_rows_kernel, fgrid, dim3(256), 0, S(stream), cand_d2, cand_idx, cand_cnt, Qn, scale_info, n_rows,
+                       (int64_t)grid.x * K16_BQ, cap, ksel);
+    MELD_LAUNCH_CHECK("knn16_finish_rows_kernel");
+  }
   if (stats) {
     unsigned long long st[5] = {0, 0, 0, 0, 0};
     MELD_HIP_CALL(hipStreamSynchronize(S(stream)));

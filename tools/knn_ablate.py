@@ -49,7 +49,7 @@ if abl is None:
     torch.save(seed.cpu(), "/tmp/knn_seed.pt")
     run(seed, "product, thresholds seeded with the final ones")
     print("seed / final threshold: median %.2f, p90 %.2f" % (float((mseed[:N] / seed[:N]).median()), float(torch.quantile((mseed[:N] / seed[:N])[:200000], 0.9))))
-    for a, name in (("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
+    for a, name in (("5", "appends without their stores"), ("7", "no final ranking"), ("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
         subprocess.run([sys.executable, __file__, str(n)], env=env)
 else:
