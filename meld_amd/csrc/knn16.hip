@@ -297,12 +297,17 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   constexpr int TILE_H = KB * 2 * 2 * K16_TS * 8;  // halves per reference tile
   constexpr int TILE_V4 = TILE_H / 8;              // 16-byte vectors per tile = KB * 256
   constexpr int LDS_TILE_H = (NPROD == 3) ? TILE_H : TILE_H / 2;  // (the hi-only search keeps just the hi planes in LDS)
-  // two separate arrays (and a scan loop unrolled by two, each copy reading one and filling the other): the
-  // LDS DMA of the next tile must be provably disjoint from the A-fragment reads of the current one, or the
-  // compiler's wait-count pass guards every ds_read with s_waitcnt vmcnt(0) -- i.e. waits for the tile it has
-  // just requested before touching the one it has
-  __shared__ __attribute__((aligned(16))) _Float16 lds_tile0[LDS_TILE_H];
-  __shared__ __attribute__((aligned(16))) _Float16 lds_tile1[LDS_TILE_H];
+  // A ring of three tile buffers: the tile of the step after next is in flight across the tile barrier.  A tile
+  // requested at the top of an iteration and needed at its end has one iteration (~1.6 us at 1M cells) to arrive
+  // from the Infinity Cache; requested one iteration earlier it has two, and the wave only waits for the OLDER of
+  // its two requests (counted s_waitcnt vmcnt(n) + a raw s_barrier: __syncthreads() would drain the counter).
+  // The copies (global -> LDS DMA) are issued from inline asm: the compiler's wait-count pass knows that the
+  // builtin form writes LDS and guards every ds_read that may alias a pending copy with s_waitcnt vmcnt(0) -- with
+  // a ring addressed by a rotating offset that is every A-fragment read.  (The earlier build kept two separate
+  // arrays and the loop unrolled by two so that the pass could prove them disjoint; three arrays unrolled by three
+  // spill and no longer fit the instruction cache.)  The waits are explicit instead: K16_STAGED / _BUT_LAST.
+  __shared__ __attribute__((aligned(16))) _Float16 lds_ring[3 * LDS_TILE_H];
+  constexpr int TILE_LDS_BYTES = LDS_TILE_H * 2;
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
   __shared__ unsigned long long lds_wlive[3][K16_NWAVE];  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch
@@ -333,9 +338,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       if (NPROD == 3) blo[g][kb] = qrow[(kb * 2 + h) * 2 + 1];
     }
   }
-  float nq[2];
-  nq[0] = Qn[q_base + jq];
-  nq[1] = Qn[q_base + 32 + jq];
+  // |q|^2 is needed in cold code only (the thresholds in registers are raw, thrp = thr - |q|^2): it is re-read from
+  // memory there instead of occupying two registers across the scan (the kernel sits at its register budget)
+  const float* const wave_qn = Qn + q_base;
 
   int cnt[2] = {0, 0};  // entries this lane has appended to its half of the rows of its two queries
   const int half = cap >> 1;
@@ -345,7 +350,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // there instead of at +inf, so that only a handful of candidates per query ever take the slow path
   // (only thrp = thr - |q|^2 lives in registers: the kernel is compiled for a fixed register budget)
   auto thr_start = [&](int g) __attribute__((always_inline)) { return a.thr_init ? a.thr_init[q_base + g * 32 + jq] : INFINITY; };
-  float thrp[2] = {thr_start(0) - nq[0], thr_start(1) - nq[1]};
+  float thrp[2] = {thr_start(0) - wave_qn[jq], thr_start(1) - wave_qn[32 + jq]};
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
   if (a.thr_init) {  // seeded thresholds also seed the pruning bound (and let the timing ablations prune realistically)
     float w = fmaxf(thr_start(0), thr_start(1));
@@ -434,27 +439,36 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // round offset an SGPR.
   const int stage_voff = stage_off * 16;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-#define K16_DMA(U, DST) \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)((DST) + wave * 64 + (U) * K16_THREADS), 16, stage_voff, (U) * STAGE_STRIDE * 16, 0, 0)
-#define K16_LOAD(TILE, DST)                                                                                        \
+  typedef int k16_i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned ring_addr = (unsigned)(size_t)(lds_ptr_t)lds_ring + (unsigned)wave * 1024u;  // LDS byte address of this wave's slots
+  // (M0 = LDS base of the copy; the compiler treats M0 as scratch and sets it before each of its own uses)
+#define K16_DMA(U, DSTB)                                                                                              \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(    \
+                   (int)(ring_addr + (DSTB) + (unsigned)((U) * K16_THREADS * 16)))),                                   \
+               "v"(stage_voff), "s"(rsrc), "s"((U) * STAGE_STRIDE * 16)                                                \
+               : "memory")
+#define K16_LOAD(TILE, DSTB)                                                                                       \
   do {                                                                                                             \
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(                                         \
-        const_cast<float4*>(R4 + (size_t)(TILE) * TILE_V4), 0, TILE_V4 * 16, 0x00020000);                          \
-    if constexpr (NS > 0) if (K16_ROUND_OK(0)) K16_DMA(0, DST);                                                    \
-    if constexpr (NS > 1) if (K16_ROUND_OK(1)) K16_DMA(1, DST);                                                    \
-    if constexpr (NS > 2) if (K16_ROUND_OK(2)) K16_DMA(2, DST);                                                    \
-    if constexpr (NS > 3) if (K16_ROUND_OK(3)) K16_DMA(3, DST);                                                    \
-    if constexpr (NS > 4) if (K16_ROUND_OK(4)) K16_DMA(4, DST);                                                    \
-    if constexpr (NS > 5) if (K16_ROUND_OK(5)) K16_DMA(5, DST);                                                    \
-    if constexpr (NS > 6) if (K16_ROUND_OK(6)) K16_DMA(6, DST);                                                    \
-    if constexpr (NS > 7) if (K16_ROUND_OK(7)) K16_DMA(7, DST);                                                    \
-    if constexpr (NS > 8) if (K16_ROUND_OK(8)) K16_DMA(8, DST);                                                    \
+    const size_t src_ = reinterpret_cast<size_t>(R4 + (size_t)(TILE) * TILE_V4);                                   \
+    const k16_i32x4 rsrc = {(int)(unsigned)src_, (int)((src_ >> 32) & 0xffffu), TILE_V4 * 16, 0x00020000};         \
+    if constexpr (NS > 0) if (K16_ROUND_OK(0)) K16_DMA(0, DSTB);                                                   \
+    if constexpr (NS > 1) if (K16_ROUND_OK(1)) K16_DMA(1, DSTB);                                                   \
+    if constexpr (NS > 2) if (K16_ROUND_OK(2)) K16_DMA(2, DSTB);                                                   \
+    if constexpr (NS > 3) if (K16_ROUND_OK(3)) K16_DMA(3, DSTB);                                                   \
+    if constexpr (NS > 4) if (K16_ROUND_OK(4)) K16_DMA(4, DSTB);                                                   \
+    if constexpr (NS > 5) if (K16_ROUND_OK(5)) K16_DMA(5, DSTB);                                                   \
+    if constexpr (NS > 6) if (K16_ROUND_OK(6)) K16_DMA(6, DSTB);                                                   \
+    if constexpr (NS > 7) if (K16_ROUND_OK(7)) K16_DMA(7, DSTB);                                                   \
+    if constexpr (NS > 8) if (K16_ROUND_OK(8)) K16_DMA(8, DSTB);                                                   \
   } while (0)
   // the copies of this wave have landed in LDS (then the tile barrier makes them visible to the others)
 #define K16_STAGED() __builtin_amdgcn_s_waitcnt(0x0F70)
-  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)), reinterpret_cast<float4*>(lds_tile0));
-  K16_STAGED();
-  __syncthreads();
+  // ... all but the copies of the request issued last (every wave issues at least NS - 1 copies per tile)
+  constexpr int N_INFLIGHT = NS - (STAGE_TAIL ? 1 : 0);
+#define K16_STAGED_BUT_LAST() __builtin_amdgcn_s_waitcnt(0x0F70 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14))
+  // tile barrier that leaves the vector-memory counter alone (LDS traffic of this wave done, then s_barrier)
+#define K16_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)), 0u);
 
   // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
   // their loads past the first barrier and then has to guard their first use inside the loop with
@@ -467,7 +481,6 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       asm volatile("" : "+v"(bhi[g][kb]));
       if (NPROD == 3) asm volatile("" : "+v"(blo[g][kb]));
     }
-    asm volatile("" : "+v"(nq[g]));
     asm volatile("" : "+v"(thrp[g]));  // (its start value may come from thr_init)
   }
 
@@ -519,7 +532,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     int m0, m1;
     float rcut = INFINITY, err = 0.0f;
     const int knn1 = K16_COLD(knn1);
-    const float nq_row = __shfl(g ? nq[1] : nq[0], j, 64);
+    const float nq_row = wave_qn[g * 32 + j];
     if (knn1 > 0) {  // search-error allowance of this row, scaled units (refine.hip's E, rounded up)
       const float* sinfo = K16_COLD(scale_info);
       const float nmax_s = K16_COLD(norm2_max)[0] * sinfo[0] * sinfo[0];
@@ -551,7 +564,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
   auto refresh_wmax = [&]() __attribute__((always_inline)) {
     if (my_lb == nullptr) return;  // only the pruning test reads it
-    float w = fmaxf(thrp[0] + nq[0], thrp[1] + nq[1]);
+    float w = fmaxf(thrp[0] + wave_qn[jq], thrp[1] + wave_qn[32 + jq]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
     wmax = w;
@@ -704,11 +717,19 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   bool live_next = true;
   int s_next = next_step(0, 0, &live_next);
   int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
-  auto scan_step = [&](const _Float16* tile_r, _Float16* tile_w) __attribute__((always_inline)) {
+  // tiles of steps 0 and s_next requested; the first one has to be there
+  if (s_next < n_scan && ABL != 9) {
+    K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), (unsigned)TILE_LDS_BYTES);
+    K16_STAGED_BUT_LAST();
+  } else {
+    K16_STAGED();
+  }
+  K16_TILE_BARRIER();
+  // ring positions (byte offsets, wave-uniform): the tile being read, the next one (requested), the one to request
+  unsigned rd_b = 0u, nx_b = (unsigned)TILE_LDS_BYTES, wr_b = 2u * (unsigned)TILE_LDS_BYTES;
+  auto scan_step = [&]() __attribute__((always_inline)) {
     const int t = t_cur;
-    if (s_next < n_scan && ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
-      K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), reinterpret_cast<float4*>(tile_w));
-    }
+    const _Float16* tile_r = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(lds_ring) + rd_b);
     if (live_cur) {
       // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
       segment(tile_r, 0, accA0, accA1, accB0, accB1, refB, true);
@@ -758,12 +779,21 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const int s_nn = s_next < n_scan ? next_step(s_next, par, &live_nn) : n_scan;
     const int t_nn = s_nn < n_scan ? tile_of(s_nn) : t_next;
 
-    if (s_next < n_scan && ABL != 9) K16_STAGED();
+    // request the tile of the step after next (into the buffer the previous iteration read: every wave has passed
+    // the barrier behind it), then wait for the tile of the next step, requested one iteration ago
+    if (ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
+      if (s_nn < n_scan) {
+        K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_nn & 63) : t_nn), wr_b);
+        K16_STAGED_BUT_LAST();
+      } else {
+        K16_STAGED();
+      }
+    }
     if (my_lb) {
       my_live = __ballot(win_lb <= wmax + prune_margin);
       if (lane == 0) lds_wlive[par ^ 1][wave] = my_live;
     }
-    if (ABL != 4 || (s_cur & 1)) __syncthreads();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
+    if (ABL != 4 || (s_cur & 1)) K16_TILE_BARRIER();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
     s_cur = s_next;
     t_cur = t_next;
     live_cur = live_next;
@@ -772,12 +802,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     live_next = live_nn;
     par ^= 1;
     ++it;
+    const unsigned free_b = rd_b;
+    rd_b = nx_b;
+    nx_b = wr_b;
+    wr_b = free_b;
   };
-  while (s_cur < n_scan) {
-    scan_step(lds_tile0, lds_tile1);
-    if (s_cur >= n_scan) break;
-    scan_step(lds_tile1, lds_tile0);
-  }
+  while (s_cur < n_scan) scan_step();
   if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
   {
     unsigned long long* tiles_done = K16_COLD(tiles_done);
@@ -803,8 +833,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   float* cand_thr = K16_COLD(cand_thr);
   int* cand_cnt = K16_COLD(cand_cnt);
   if (cand_thr && h == 0) {
-    cand_thr[row_base + jq] = (thrp[0] + nq[0]) * out_scale;
-    cand_thr[row_base + 32 + jq] = (thrp[1] + nq[1]) * out_scale;
+    cand_thr[row_base + jq] = (thrp[0] + wave_qn[jq]) * out_scale;
+    cand_thr[row_base + 32 + jq] = (thrp[1] + wave_qn[32 + jq]) * out_scale;
   }
   // The rows leave the kernel as they are (raw values, two half-rows each); knn16_finish_rows_kernel, launched right
   // behind, sorts them.  Ranking them here -- 64 rows per wave one after the other, at three waves per SIMD and
@@ -820,6 +850,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 #undef K16_LOAD
 #undef K16_DMA
 #undef K16_STAGED
+#undef K16_STAGED_BUT_LAST
+#undef K16_TILE_BARRIER
 #undef K16_ROUND_OK
 }
 
