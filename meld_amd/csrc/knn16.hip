@@ -48,6 +48,9 @@ constexpr int K16_BQ = 64 * K16_WG_WAVES;        // queries per workgroup
 constexpr int K16_THREADS = 64 * K16_WG_WAVES;   // waves of 64 queries each; 2-3 workgroups resident per CU
 constexpr int K16_NWAVE = K16_THREADS / 64;
 constexpr int K16_SLACK = 128;     // CAP = ksel + slack
+#ifndef K16_A_AHEAD
+#define K16_A_AHEAD 4  // A fragments of a pipeline segment requested ahead of its first MFMA (hi-only search; measured 2 -> 4: -2 %)
+#endif
 constexpr int K16_CAPMAX = 256;
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
 constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
@@ -637,9 +640,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
         __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
       }
     } else {
-      // two A fragments in flight (the register budget of three waves per SIMD has no room for more):
-      // the fragment of K block kb + 2 is requested right after the MFMAs of block kb have issued
-      __builtin_amdgcn_sched_group_barrier(0x100, KB < 2 ? KB : 2, 0);
+      // A_AHEAD A fragments in flight: the fragment of K block kb + A_AHEAD is requested right after the MFMAs of
+      // block kb have issued (with |q|^2 out of the registers the budget of three waves per SIMD has room for four)
+      constexpr int A_AHEAD = K16_A_AHEAD;  // A fragments in flight
+      __builtin_amdgcn_sched_group_barrier(0x100, KB < A_AHEAD ? KB : A_AHEAD, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -647,7 +651,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
         __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
-        if (kb + 2 < KB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (kb + A_AHEAD < KB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
   };
