@@ -274,7 +274,8 @@ struct K16Args {
 // cannot reach.  The first pass at d <= 61 fits three waves (168 registers): measured 135 ms vs 151 ms
 // with two at 1M cells -- the waves mostly wait (barrier per tile, selection slow path), so occupancy pays.
 __host__ __device__ constexpr int k16_waves(int KB, int ABL, int NPROD) {
-  return (NPROD == 1 && KB <= 4 && ABL != 6) ? 3 : ((KB <= 6 || (NPROD == 1 && KB <= 8)) ? 2 : 1);
+  // (the full split at KB = 6 would fit two by registers, but its three 24 KB tile buffers leave room for one workgroup per CU)
+  return (NPROD == 1 && KB <= 4 && ABL != 6) ? 3 : ((KB <= 5 || (NPROD == 1 && KB <= 8)) ? 2 : 1);
 }
 
 template <int KB, int ABL, int NPROD>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
