@@ -233,6 +233,23 @@ int meld_coo_merge(const uint64_t* keys_sorted, const double* vals_sorted, int64
 int meld_csr_from_keys(const uint64_t* ukeys, int64_t nnz, int64_t row_begin, int64_t n_rows,
                        int64_t* rowptr, int32_t* col, meld_stream_t stream);
 
+/* The same assembly without a global sort (the default; replaces graphtools' (K + K^T)/2 on scipy.sparse, SURVEY.md
+ * section 8a A4, like the calls above).  meld_coo_scatter_rows sends every entry to the bucket of its row -- slots
+ * [r * B, (r + 1) * B) of tcol / tval, B = meld_csr_bucket_slots(), n_rows * B entries each; cursor[n_rows] (zeroed
+ * inside) ends as the number of entries sent to each row, whether they fitted or not.  meld_csr_rows_sort_merge sorts
+ * every bucket by column inside one wave and sums pairs of equal columns in place (ucnt[r] = distinct columns of row r;
+ * flags[0] bit 0: a row with more than B entries, bit 1: a column that occurs more than twice -- in either case the
+ * caller must use the sort-based calls above, whose summation order is defined), and after an exclusive scan of ucnt
+ * (rowptr) meld_csr_compact_rows copies the merged buckets to their final place.  Entries whose row lies outside
+ * [row_begin, row_begin + n_rows) are ignored. */
+int meld_csr_bucket_slots(void);
+int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
+                          int32_t* cursor, int32_t* tcol, double* tval, meld_stream_t stream);
+int meld_csr_rows_sort_merge(const int32_t* cursor, int64_t n_rows, int32_t* tcol, double* tval, int32_t* ucnt,
+                             int32_t* flags, meld_stream_t stream);
+int meld_csr_compact_rows(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval,
+                          int32_t* col, double* val, meld_stream_t stream);
+
 /* ksum[i] = diag + sum_j val[i,j]   (row sums of the symmetrised kernel; diag = K_ii = 1) */
 int meld_csr_row_sums(const int64_t* rowptr, const double* val, int64_t n_rows, double diag,
                       double* out, meld_stream_t stream);

@@ -68,6 +68,10 @@ SIGNATURES = {
     "meld_merge_temp_bytes": (_sz, [_i64]),
     "meld_coo_merge": (_i32, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "meld_csr_from_keys": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
+    "meld_csr_bucket_slots": (_i32, []),
+    "meld_coo_scatter_rows": (_i32, [_ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "meld_csr_rows_sort_merge": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_csr_compact_rows": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),
     "meld_csr_anisotropy": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr]),
     "meld_spmm_dot_slots": (_i32, []),

@@ -251,6 +251,240 @@ extern "C" int meld_csr_from_keys(const uint64_t* ukeys, int64_t nnz, int64_t ro
   return MELD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bucket assembly: unsorted COO -> CSR without a global sort.  The keys of one row are few (tens), so the
+// entries are sent to fixed-size row buckets first (one pass, a per-row cursor advanced by atomics -- the order
+// inside a bucket is whatever the atomics made it) and then every row is sorted by column and its duplicates
+// summed inside ONE wave
+// (bitonic network on (column : slot) keys, the values fetched by slot).  The result does not depend on the
+// bucket order as long as no (row, column) occurs more than twice: a + b is commutative.  A third duplicate
+// (never produced by (K + K^T)/2, where (i, j) occurs once per direction) or a row of more than 256 entries
+// raises a flag and the caller takes the sort-based path, whose summation order is defined by the stable sort.
+// 1M cells, 53 M entries in, 39 M out: 2.5 ms instead of 4.0 (6 radix passes over 16-byte pairs + reduce-by-key).
+// ---------------------------------------------------------------------------------------------
+// (Entries of one row often sit next to each other in the stream -- the rows' own entries are emitted row by row --
+// and their atomics would serialise on one address: the lanes of a wave that hold a run of equal rows send ONE atomic.)
+__device__ __forceinline__ void coo_row_run(int64_t r, int lane, bool* leader, int* rank, int* run_len) {
+  const int64_t prev = __shfl_up(r, 1, 64);
+  const bool head = lane == 0 || prev != r;
+  const unsigned long long hb = __ballot(head);
+  const unsigned long long below = hb & ((2ull << lane) - 1ull);  // heads at or below this lane (never empty: lane 0 is one)
+  const int lead = 63 - __clzll((long long)below);
+  const unsigned long long above = lane == 63 ? 0ull : (hb >> (lane + 1));
+  const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+  *leader = head;
+  *rank = lane - lead;
+  *run_len = next - lane;  // (meaningful on the leader)
+}
+
+// row r's bucket = slots [r * CSR_BUCKET, (r + 1) * CSR_BUCKET) of tcol / tval; cursor[r] counts what was sent to it
+constexpr int CSR_BUCKET = 256;
+
+__global__ __launch_bounds__(256) void coo_scatter_rows_kernel(const unsigned long long* __restrict__ keys,
+                                                               const double* __restrict__ vals, int64_t n, int64_t row_begin,
+                                                               int64_t n_rows, int* __restrict__ cursor, int* __restrict__ tcol,
+                                                               double* __restrict__ tval) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int64_t r = -1 - lane;  // (lanes past the end / rows outside the slice: runs of one, nothing sent)
+  unsigned long long k = 0;
+  if (e < n) {
+    k = keys[e];
+    const int64_t rr = (int64_t)(k >> 32) - row_begin;
+    if (rr >= 0 && rr < n_rows) r = rr;
+  }
+  bool leader;
+  int rank, run_len;
+  coo_row_run(r, lane, &leader, &rank, &run_len);
+  int first = 0;
+  if (leader && r >= 0) first = atomicAdd(cursor + r, run_len);
+  const int slot = __shfl(first, lane - rank, 64) + rank;
+  if (r >= 0 && slot < CSR_BUCKET) {  // (an overfull bucket shows in cursor[r]: the caller takes the sort-based path)
+    tcol[r * CSR_BUCKET + slot] = (int)(unsigned)k;
+    tval[r * CSR_BUCKET + slot] = vals[e];
+  }
+}
+
+template <int SL>
+__device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], int lane) {
+  constexpr int NE = 64 * SL;
+#pragma unroll
+  for (int k = 2; k <= NE; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int je = j >> 6;
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+          if ((e & je) == 0) {
+            const bool asc = ((64 * e + lane) & k) == 0;
+            const unsigned long long a = key[e], b = key[e | je];
+            const bool sw = asc ? (b < a) : (a < b);
+            key[e] = sw ? b : a;
+            key[e | je] = sw ? a : b;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+          const int i = 64 * e + lane;
+          const unsigned long long o = __shfl_xor(key[e], j, 64);
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          key[e] = keep_min ? (o < key[e] ? o : key[e]) : (o < key[e] ? key[e] : o);
+        }
+      }
+    }
+  }
+}
+
+// sorts the bucket [base, base + n) by column in place, sums pairs of equal columns, returns the number of
+// distinct columns; *bad is set when a column occurs more than twice
+template <int SL>
+__device__ __forceinline__ int csr_row_merge(int* __restrict__ tcol, double* __restrict__ tval, int64_t base, int n, int lane,
+                                             bool* bad) {
+  unsigned long long key[SL];
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    const int i = lane + 64 * e;
+    key[e] = i < n ? (((unsigned long long)(unsigned)tcol[base + i] << 32) | (unsigned)i) : ~0ull;
+  }
+  csr_bitonic_sort<SL>(key, lane);
+  double v[SL];
+  unsigned c[SL];
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    const int i = lane + 64 * e;
+    c[e] = (unsigned)(key[e] >> 32);
+    v[e] = i < n ? tval[base + (unsigned)key[e]] : 0.0;
+  }
+  // neighbours in sorted order: position i - 1, i + 1, i + 2 (across the lane / slot boundary)
+  int total = 0;
+  bool any_bad = false;
+  unsigned head_col[SL];
+  double head_val[SL];
+  int head_pos[SL];
+  bool is_head[SL];
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    const int i = lane + 64 * e;
+    unsigned prev = __shfl_up(c[e], 1, 64);
+    if (lane == 0) prev = 0xffffffffu;
+    if (e > 0) {
+      const unsigned pl = __shfl(c[e - 1], 63, 64);
+      if (lane == 0) prev = pl;
+    }
+    unsigned n1 = __shfl_down(c[e], 1, 64), n2 = __shfl_down(c[e], 2, 64);
+    double v1 = __shfl_down(v[e], 1, 64);
+    if (e + 1 < SL) {
+      const unsigned f0 = __shfl(c[e + 1], 0, 64), f1 = __shfl(c[e + 1], 1, 64);
+      const double w0 = __shfl(v[e + 1], 0, 64);
+      if (lane == 63) { n1 = f0; n2 = f1; v1 = w0; }
+      if (lane == 62) n2 = f0;
+    } else {
+      if (lane == 63) { n1 = 0xffffffffu; n2 = 0xffffffffu; }
+      if (lane == 62) n2 = 0xffffffffu;
+    }
+    const bool valid = i < n;
+    const bool head = valid && (i == 0 || prev != c[e]);
+    const bool pair = valid && (i + 1 < n) && n1 == c[e];
+    const bool triple = valid && (i + 2 < n) && n2 == c[e];
+    any_bad |= triple;
+    is_head[e] = head;
+    head_col[e] = c[e];
+    head_val[e] = pair ? v[e] + v1 : v[e];
+    const unsigned long long hb = __ballot(head);
+    head_pos[e] = total + __popcll(hb & ((1ull << lane) - 1ull));
+    total += __popcll(hb);
+  }
+  // (every load of the bucket precedes its first store: the sums depend on all of them)
+#pragma unroll
+  for (int e = 0; e < SL; ++e) {
+    if (is_head[e]) {
+      tcol[base + head_pos[e]] = (int)head_col[e];
+      tval[base + head_pos[e]] = head_val[e];
+    }
+  }
+  if (__any(any_bad)) *bad = true;
+  return total;
+}
+
+__global__ __launch_bounds__(256) void csr_rows_sort_merge_kernel(const int* __restrict__ cursor, int64_t n_rows,
+                                                                  int* __restrict__ tcol, double* __restrict__ tval,
+                                                                  int* __restrict__ ucnt, int* __restrict__ flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int64_t base = r * CSR_BUCKET;
+  const int n = cursor[r];
+  if (n > CSR_BUCKET) {  // more entries than the bucket (and the in-register network) holds
+    if (lane == 0) {
+      atomicOr(flags, 1);
+      ucnt[r] = 0;
+    }
+    return;
+  }
+  bool bad = false;
+  int total;
+  if (n <= 64)
+    total = csr_row_merge<1>(tcol, tval, base, n, lane, &bad);
+  else if (n <= 128)
+    total = csr_row_merge<2>(tcol, tval, base, n, lane, &bad);
+  else
+    total = csr_row_merge<4>(tcol, tval, base, n, lane, &bad);
+  if (lane == 0) {
+    ucnt[r] = total;
+    if (bad) atomicOr(flags, 2);
+  }
+}
+
+// 16 lanes per row: the merged head of the bucket -> [rowptr[r], rowptr[r + 1])
+__global__ __launch_bounds__(256) void csr_compact_rows_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                                               const int* __restrict__ tcol, const double* __restrict__ tval,
+                                                               int* __restrict__ col, double* __restrict__ val) {
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int g = threadIdx.x & 15;
+  if (r >= n_rows) return;
+  const int64_t src = r * CSR_BUCKET, dst = rowptr[r];
+  const int len = (int)(rowptr[r + 1] - dst);
+  for (int k = g; k < len; k += 16) {
+    col[dst + k] = tcol[src + k];
+    val[dst + k] = tval[src + k];
+  }
+}
+
+extern "C" int meld_csr_bucket_slots(void) { return CSR_BUCKET; }
+
+extern "C" int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
+                                     int32_t* cursor, int32_t* tcol, double* tval, meld_stream_t stream) {
+  MELD_CHECK_ARG(cursor && n_rows > 0 && n >= 0 && (n == 0 || (keys && vals && tcol && tval)),
+                 "meld_coo_scatter_rows: bad arguments");
+  MELD_HIP_CALL(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_rows, S(stream)));
+  if (n == 0) return MELD_OK;
+  hipLaunchKernelGGL(coo_scatter_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const unsigned long long*>(keys), vals, n, row_begin, n_rows, cursor, tcol, tval);
+  MELD_LAUNCH_CHECK("coo_scatter_rows_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_csr_rows_sort_merge(const int32_t* cursor, int64_t n_rows, int32_t* tcol, double* tval, int32_t* ucnt,
+                                        int32_t* flags, meld_stream_t stream) {
+  MELD_CHECK_ARG(cursor && tcol && tval && ucnt && flags && n_rows > 0, "meld_csr_rows_sort_merge: bad arguments");
+  MELD_HIP_CALL(hipMemsetAsync(flags, 0, sizeof(int32_t), S(stream)));
+  hipLaunchKernelGGL(csr_rows_sort_merge_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, S(stream), cursor, n_rows,
+                     tcol, tval, ucnt, flags);
+  MELD_LAUNCH_CHECK("csr_rows_sort_merge_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_csr_compact_rows(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval,
+                                     int32_t* col, double* val, meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && n_rows > 0 && tcol && tval && col && val, "meld_csr_compact_rows: bad arguments");
+  hipLaunchKernelGGL(csr_compact_rows_kernel, dim3((unsigned)ceil_div(n_rows * 16, 256)), dim3(256), 0, S(stream), rowptr,
+                     n_rows, tcol, tval, col, val);
+  MELD_LAUNCH_CHECK("csr_compact_rows_kernel");
+  return MELD_OK;
+}
+
 extern "C" int meld_csr_row_sums(const int64_t* rowptr, const double* val, int64_t n_rows, double diag, double* out,
                                  meld_stream_t stream) {
   MELD_CHECK_ARG(rowptr && out && n_rows > 0, "meld_csr_row_sums: bad arguments");

@@ -701,9 +701,30 @@ class HipOps:
         return keys2, vals2
 
     def assemble_rows(self, keys, vals, row_begin, n_rows, N):
-        """Sort by key, sum duplicate keys, build CSR of the local rows."""
+        """Sum duplicate keys, build the CSR (sorted rows) of the local rows: by row buckets sorted inside one wave
+        each (include/meld_hip.h, meld_coo_row_counts ...), or -- for the inputs that path refuses, and with
+        ``MELD_ASSEMBLE=sort`` -- by a global radix sort + reduce-by-key."""
         lib, st, dev = self.lib, _stream(), keys.device
         n = int(keys.shape[0])
+        if n > 0 and n_rows > 0 and os.environ.get("MELD_ASSEMBLE", "bucket") != "sort":
+            i32 = dict(dtype=torch.int32, device=dev)
+            B = int(lib.meld_csr_bucket_slots())
+            cursor = torch.empty(n_rows, **i32)
+            tcol = torch.empty(n_rows * B, **i32)
+            tval = torch.empty(n_rows * B, dtype=torch.float64, device=dev)
+            check(lib.meld_coo_scatter_rows(ptr(keys), ptr(vals), n, row_begin, n_rows, ptr(cursor), ptr(tcol), ptr(tval), st), "meld_coo_scatter_rows")
+            ucnt = torch.empty(n_rows, **i32)
+            flags = torch.empty(1, **i32)
+            check(lib.meld_csr_rows_sort_merge(ptr(cursor), n_rows, ptr(tcol), ptr(tval), ptr(ucnt), ptr(flags), st), "meld_csr_rows_sort_merge")
+            rowptr = _scan_i32(lib, ucnt, st)
+            nnz, flag = (int(v) for v in torch.stack([rowptr[n_rows], flags[0].to(torch.int64)]).tolist())  # (one read-back)
+            if flag == 0:
+                col = torch.empty(nnz, **i32)
+                val = torch.empty(nnz, dtype=torch.float64, device=dev)
+                if nnz > 0:
+                    check(lib.meld_csr_compact_rows(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), st), "meld_csr_compact_rows")
+                return rowptr, col, val
+            del cursor, ucnt, tcol, tval, rowptr
         keys2, vals2 = self.sort_pairs(keys, vals, N)
         tb = lib.meld_merge_temp_bytes(max(n, 1))
         tmp = torch.empty(tb, dtype=torch.uint8, device=dev)

@@ -1,0 +1,88 @@
+"""(K + K^T)/2 assembly: the row-bucket path (one wave sorts and merges a row; include/meld_hip.h,
+meld_coo_row_counts ... meld_csr_compact_rows) against the global sort + reduce-by-key path and against scipy's
+coo -> csr (duplicates summed), which is what graphtools' symmetrize_kernel does on scipy.sparse
+([UPSTREAM graphtools BaseGraph.symmetrize_kernel], called under reference meld/meld.py:117-118)."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _assemble(keys, vals, row_begin, n_rows, N, mode, monkeypatch):
+    from meld_amd.graph import HipOps
+
+    monkeypatch.setenv("MELD_ASSEMBLE", mode)
+    ops = HipOps()
+    rp, col, val = ops.assemble_rows(torch.from_numpy(keys).cuda(), torch.from_numpy(vals).cuda(), row_begin, n_rows, N)
+    torch.cuda.synchronize()
+    return rp.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+
+
+def _sym_coo(rng, N, deg, hub=0):
+    """directed entries (i, j, v), i != j, unique per (i, j); emitted in both directions at v / 2 like meld_coo_emit"""
+    i = np.repeat(np.arange(N), deg)
+    j = rng.integers(0, N, size=i.shape[0])
+    if hub:
+        j[: hub] = 0  # many rows point at cell 0: a long transposed row
+    keep = i != j
+    i, j = i[keep], j[keep]
+    _, first = np.unique(i.astype(np.int64) << 32 | j, return_index=True)
+    i, j = i[first], j[first]
+    v = rng.random(i.shape[0])
+    keys = np.concatenate([(i.astype(np.int64) << 32) | j, (j.astype(np.int64) << 32) | i])
+    vals = np.concatenate([0.5 * v, 0.5 * v])
+    p = rng.permutation(keys.shape[0])
+    return keys[p], vals[p]
+
+
+@pytest.mark.parametrize("N,deg", [(1000, 7), (20000, 20), (5000, 70)])
+def test_bucket_assembly_equals_sort_assembly_and_scipy(N, deg, monkeypatch):
+    rng = np.random.default_rng(N)
+    keys, vals = _sym_coo(rng, N, deg)
+    rb, cb, vb = _assemble(keys, vals, 0, N, N, "bucket", monkeypatch)
+    rs, cs, vs = _assemble(keys, vals, 0, N, N, "sort", monkeypatch)
+    assert np.array_equal(rb, rs) and np.array_equal(cb, cs)
+    assert np.array_equal(vb, vs)  # bit for bit: at most two addends per entry
+    W = sparse.coo_matrix((vals, (keys >> 32, keys & 0xFFFFFFFF)), shape=(N, N)).tocsr()
+    W.sum_duplicates()
+    W.sort_indices()
+    assert np.array_equal(rb, W.indptr) and np.array_equal(cb, W.indices)
+    np.testing.assert_allclose(vb, W.data, rtol=1e-15)
+
+
+def test_bucket_assembly_of_a_row_slice(monkeypatch):
+    """the sharded driver assembles rows [row_begin, row_begin + n_rows) only; other keys are ignored"""
+    rng = np.random.default_rng(3)
+    N = 6000
+    keys, vals = _sym_coo(rng, N, 12)
+    for mode in ("bucket", "sort"):
+        sel = (keys >> 32 >= 1500) & (keys >> 32 < 4000)
+        r, c, v = _assemble(keys[sel], vals[sel], 1500, 2500, N, mode, monkeypatch)
+        W = sparse.coo_matrix((vals, (keys >> 32, keys & 0xFFFFFFFF)), shape=(N, N)).tocsr()[1500:4000]
+        W.sum_duplicates()
+        W.sort_indices()
+        assert np.array_equal(r, W.indptr) and np.array_equal(c, W.indices)
+        np.testing.assert_allclose(v, W.data, rtol=1e-15)
+    # keys outside the slice are skipped by the bucket path
+    r2, c2, v2 = _assemble(keys, vals, 1500, 2500, N, "bucket", monkeypatch)
+    assert np.array_equal(r2, r) and np.array_equal(c2, c) and np.array_equal(v2, v)
+
+
+def test_long_rows_and_repeated_keys_take_the_sort_path(monkeypatch):
+    """a hub row of more than 256 entries, and a key that occurs three times: the bucket path must hand over to the
+    sort-based one (same result as asking for it)"""
+    rng = np.random.default_rng(5)
+    N = 4000
+    keys, vals = _sym_coo(rng, N, 6, hub=3000)
+    assert np.bincount((keys >> 32).astype(np.int64)).max() > 256
+    rb, cb, vb = _assemble(keys, vals, 0, N, N, "bucket", monkeypatch)
+    rs, cs, vs = _assemble(keys, vals, 0, N, N, "sort", monkeypatch)
+    assert np.array_equal(rb, rs) and np.array_equal(cb, cs) and np.array_equal(vb, vs)
+    keys3, vals3 = _sym_coo(rng, N, 6)
+    keys3 = np.concatenate([keys3, keys3[:50]])
+    vals3 = np.concatenate([vals3, rng.random(50)])
+    rb, cb, vb = _assemble(keys3, vals3, 0, N, N, "bucket", monkeypatch)
+    rs, cs, vs = _assemble(keys3, vals3, 0, N, N, "sort", monkeypatch)
+    assert np.array_equal(rb, rs) and np.array_equal(cb, cs) and np.array_equal(vb, vs)
