@@ -264,6 +264,7 @@ struct K16Args {
   int* cand_cnt;
   float* cand_thr;
   unsigned long long* tiles_done;
+  const int* block_order;
 };
 #define K16_COLD(FIELD) \
   (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
@@ -321,7 +322,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform by construction; the compiler cannot tell)
   const int jq = lane & 31;
   const int h = lane >> 5;
-  const int q_base = blockIdx.x * K16_BQ + wave * 64;  // first query of this wave
+  // Query block of this workgroup.  Workgroups are dispatched in index order as slots free up, and with pruning their
+  // work differs by up to 12x: block_order (optional) lists the query blocks by decreasing work, so that the longest
+  // start first and the chip does not wait for a heavy block that was dispatched last (meld_knn16_block_work).
+  const int bx = a.block_order ? __builtin_amdgcn_readfirstlane(a.block_order[blockIdx.x]) : (int)blockIdx.x;
+  const int q_base = bx * K16_BQ + wave * 64;  // first query of this wave
   // reference slices (gridDim.y > 1): slice y scans tiles [tile_lo, tile_lo + n_scan) and writes its
   // own candidate rows; meld_knn16_merge_slices combines them.  Used to spread a small query set
   // (the second-stage re-search) over the whole chip.
@@ -371,8 +376,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // threshold of the workgroup cannot contribute a candidate and is skipped without being loaded.
   // search-error allowance in the scaled space: a skipped tile must fail `d2_approx < thr` for sure
   const float prune_margin = lb2 ? a.err_coef * a.norm2_max[0] * a.scale_info[0] * a.scale_info[0] : 0.0f;
-  const int t0 = (int)(((long long)a.tile_origin + (long long)blockIdx.x * (K16_BQ / K16_TS)) % n_scan);
-  const __half* my_lb = lb2 ? lb2 + (size_t)(blockIdx.x * K16_NWAVE + wave) * n_tiles : nullptr;
+  const int t0 = (int)(((long long)a.tile_origin + (long long)bx * (K16_BQ / K16_TS)) % n_scan);
+  const __half* my_lb = lb2 ? lb2 + (size_t)(bx * K16_NWAVE + wave) * n_tiles : nullptr;
   // (A "convoy" order -- all resident workgroups sweeping the same tiles at the same time so that all but
   // the first find them in L2 -- was tried: the base loop gained 7 %, but the thresholds converge later and
   // the net was +3 %; its progress counter was also a returning atomic in the loop, whose pending result made
@@ -661,7 +666,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto segment = [&](const _Float16* tile, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
                      __attribute__((always_inline)) {
     if (issue) mfma_block(tile, sub, n0, n1);
-    if (ABL == 3 || ABL == 4 || ABL == 8 || ABL == 9) {  // profiling ablation: MFMAs only, accumulators kept live
+    if (ABL == 3 || ABL == 4 || ABL == 8 || ABL == 9 || ABL == 10) {  // profiling ablation: MFMAs only, accumulators kept live
       asm volatile("" ::"v"(c0[0]), "v"(c0[15]), "v"(c1[0]), "v"(c1[15]));
       return;
     }
@@ -798,7 +803,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       my_live = __ballot(win_lb <= wmax + prune_margin);
       if (lane == 0) lds_wlive[par ^ 1][wave] = my_live;
     }
-    if (ABL != 4 || (s_cur & 1)) K16_TILE_BARRIER();  // (4 = timing-only ablation: MFMAs only, a barrier every other tile)
+    if (ABL != 10 && (ABL != 4 || (s_cur & 1))) K16_TILE_BARRIER();  // (4 / 10 = timing-only ablations: MFMAs only, a barrier every other tile / none)
     s_cur = s_next;
     t_cur = t_next;
     live_cur = live_next;
@@ -1659,6 +1664,47 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   return MELD_OK;
 }
 
+// Tiles a search workgroup will stage at most: those some wave of it cannot rule out at its start thresholds (the
+// table entry <= the wave's largest seed + the search-error allowance).  One workgroup per query block.
+__global__ __launch_bounds__(256) void knn16_block_work_kernel(const __half* __restrict__ lb2, const float* __restrict__ thr_seed,
+                                                               int n_tiles, float err_coef, const float* __restrict__ norm2_max,
+                                                               const float* __restrict__ scale_info, int* __restrict__ work) {
+  __shared__ float wm[K16_NWAVE];
+  __shared__ int part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = thr_seed ? thr_seed[(size_t)blockIdx.x * K16_BQ + tid] : INFINITY;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = fmaxf(s, __shfl_xor(s, off, 64));
+  if (lane == 0) wm[wave] = s + err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+  __syncthreads();
+  const float w0 = wm[0], w1 = wm[1], w2 = wm[2], w3 = wm[3];
+  const __half* row = lb2 + (size_t)blockIdx.x * K16_NWAVE * n_tiles;
+  int c = 0;
+  for (int t = tid; t < n_tiles; t += 256) {
+    const bool live = __half2float(row[t]) <= w0 || __half2float(row[(size_t)n_tiles + t]) <= w1 ||
+                      __half2float(row[(size_t)2 * n_tiles + t]) <= w2 || __half2float(row[(size_t)3 * n_tiles + t]) <= w3;
+    c += live ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if (lane == 0) part[wave] = c;
+  __syncthreads();
+  if (tid == 0) work[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int meld_knn16_block_work(const void* lb2, const float* thr_seed, int64_t n_ref, int d, int64_t q_count, int nprod,
+                                     const float* norm2_max, const float* scale_info, int32_t* work, meld_stream_t stream) {
+  MELD_CHECK_ARG(lb2 && norm2_max && scale_info && work && n_ref > 0 && q_count > 0 && (nprod == 1 || nprod == 3),
+                 "meld_knn16_block_work: bad arguments");
+  static_assert(K16_NWAVE == 4 && K16_BQ == 256, "knn16_block_work_kernel is written for 4 waves of 64 queries");
+  const int n_tiles = (int)ceil_div(n_ref, K16_TS);
+  hipLaunchKernelGGL(knn16_block_work_kernel, dim3((unsigned)ceil_div(q_count, K16_BQ)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const __half*>(lb2), thr_seed, n_tiles, (float)meld_knn16_error_coef(nprod, d), norm2_max,
+                     scale_info, work);
+  MELD_LAUNCH_CHECK("knn16_block_work_kernel");
+  return MELD_OK;
+}
+
 // Start values for the thresholds of meld_knn16_topk's first pass (thr_init, scaled units, roundup(q_count, BQ)
 // floats) from every query's own block of BQ cells; q_begin must be a multiple of BQ.  knn, radius_factor as for the
 // radius cut.  Rows whose block holds fewer than knn + 1 cells (or knn + 1 > 64) get +inf.
@@ -1772,8 +1818,9 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
                                int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
                                const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
                                double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                               float* cand_thr, uint64_t* tiles_done, meld_stream_t stream) {
+                               float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
+  MELD_CHECK_ARG(block_order == nullptr || n_slices == 1, "meld_knn16_topk: block_order excludes reference slices");
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
                  "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
                  K16_MERGE_MAX);
@@ -1847,6 +1894,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   ka.cand_cnt = cand_cnt;
   ka.cand_thr = cand_thr;
   ka.tiles_done = reinterpret_cast<unsigned long long*>(tiles_done);
+  ka.block_order = block_order;
 #define K16_LAUNCH2(KBV, ABLV, NP) \
   hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka)
 #define K16_LAUNCH(KBV, ABLV)        \
@@ -1868,6 +1916,8 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
       K16_LAUNCH(4, 5);                \
     else if (abl == 7 && KBV == 4)     \
       K16_LAUNCH(4, 7);                \
+    else if (abl == 10 && KBV == 4)    \
+      K16_LAUNCH(4, 10);               \
     else if (abl == 8 && KBV == 4)     \
       K16_LAUNCH(4, 8);                \
     else if (abl == 9 && KBV == 4)     \

@@ -337,6 +337,8 @@ class HipOps:
         self.seed = os.environ.get("MELD_KNN_SEED", "1") != "0"
         # per-query test of the pruning table against those seeds (meld_knn16_bounds, thr_seed)
         self.seeded_bounds = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
+        # pruned search: query blocks dispatched by decreasing work (meld_knn16_block_work)
+        self.block_order = os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0"
         # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
         # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
         # waves and the sliced launch costs more than the idle tail, so it is off
@@ -367,7 +369,7 @@ class HipOps:
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
-        used_prune = used_seed = used_seeded_bounds = False
+        used_prune = used_seed = used_seeded_bounds = used_block_order = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if search == "wide":
@@ -440,7 +442,7 @@ class HipOps:
                 # publishes each row's final threshold for refine's completeness test
                 cand_thr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
-            lb2 = None
+            lb2 = block_order = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
@@ -474,9 +476,14 @@ class HipOps:
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 seeded_bounds = seeds is not None and self.seeded_bounds
                 check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                if self.block_order and q_main == q_count and n_blocks > 1:
+                    # longest query blocks first (the dispatch follows the block index): see meld_knn16_block_work
+                    work = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+                    check(lib.meld_knn16_block_work(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), ptr(work), st), "meld_knn16_block_work")
+                    block_order = torch.argsort(work, descending=True, stable=True).to(torch.int32)
                 tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main
@@ -484,11 +491,12 @@ class HipOps:
                     t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
                     t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
                     t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), None, st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             used_prune, used_seed = lb2 is not None, seeds is not None
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
+            used_block_order = block_order is not None
             del lb2
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
@@ -578,7 +586,7 @@ class HipOps:
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, None, st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, None, None, st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
@@ -679,7 +687,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), split_tail=bool(self.split_tail),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), split_tail=bool(self.split_tail),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)

@@ -299,7 +299,7 @@ def test_knn16_candidates_contain_true_neighbours(n, d, nprod):
     ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda")
     cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda")
     cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, st))
+    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, nprod, 1, None, None, 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, None, st))
     torch.cuda.synchronize()
     Xc = X - X.mean(0)
     n2 = (Xc**2).sum(1)
@@ -475,11 +475,17 @@ def test_tile_pruning_is_exact():
             outs = []
             # pruning and the radius cut (rows cut at the kernel radius their knn-th neighbour implies) are
             # independent switches of the search; the graph must not depend on either
-            for prune, cut, seed in ((False, False, False), (True, False, False), (False, True, False), (True, True, False),
-                                     (True, True, True), (False, True, True)):
+            # (the last two: the seeded search without the per-query test of the table against the seeds, and without
+            # the longest-first dispatch order of the query blocks)
+            for prune, cut, seed, sb, bo in ((False, False, False, True, True), (True, False, False, True, True),
+                                             (False, True, False, True, True), (True, True, False, True, True),
+                                             (True, True, True, True, True), (False, True, True, True, True),
+                                             (True, True, True, False, True), (True, True, True, True, False)):
                 ops = HipOps(prune=prune)
                 ops.radius_cut = cut
                 ops.seed = seed  # thresholds started from every row's own block (meld_knn16_seed_thresholds)
+                ops.seeded_bounds = sb
+                ops.block_order = bo
                 keys, vals, bw, info = ops.directed_kernel_coo(Xs, 0, 30000, knn, 40, 1e-4, 64)
                 outs.append(ops.assemble_rows(keys, vals, 0, 30000, 30000) + (bw,))
             for other in outs[1:]:
@@ -644,7 +650,7 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         ci = torch.zeros(S * q_pad * cap, dtype=torch.int32, device="cuda")
         cd = torch.zeros(S * q_pad * cap, dtype=torch.float32, device="cuda")
         cc = torch.zeros(S * q_pad, dtype=torch.int32, device="cuda")
-        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, st))
+        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, nq, ksel, 3, S, None, ptr(nmax), 0, None, 0, 1.0, ptr(ci), ptr(cd), ptr(cc), None, None, None, st))
         if S > 1:
             mi = torch.zeros(q_pad * cap, dtype=torch.int32, device="cuda")
             md = torch.zeros(q_pad * cap, dtype=torch.float32, device="cuda")

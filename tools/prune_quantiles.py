@@ -30,7 +30,7 @@ check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr
 ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
 cthr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device="cuda"); done = torch.zeros(1, dtype=torch.int64, device="cuda")
 rf = (-math.log(1e-4)) ** (1 / 40)
-check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, None, knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), st))
+check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, None, knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), None, st))
 torch.cuda.synchronize()
 s2 = float(sinfo[0]) ** 2
 n_w = q_pad // 64
