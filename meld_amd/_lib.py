@@ -51,7 +51,7 @@ SIGNATURES = {
     "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_block_work": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_seed_thresholds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),
-    "meld_knn16_seed_thresholds_mfma": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),
+    "meld_knn16_seed_thresholds_mfma": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i64, _i32, _f64, _i32, _i32, _ptr, _ptr]),
     "meld_knn16_max_slices": (_i32, [_i32]),
     "meld_knn16_merge_slices": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_radius_exact": (

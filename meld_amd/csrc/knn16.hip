@@ -1398,13 +1398,16 @@ __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restric
 // merge their lists.  The approximate distance may fall short of the exact one by the row's search-error allowance, so
 //     thr_init = rf^2 (A~ + 1.01 E_row + 2^-20 n_max) + 1.01 E_row.
 // More cells than the fp32 kernel above looks at (768 vs 256: a tighter bound) for a tenth of its time.
-constexpr int SEED_SIDE = 4;  // tiles on either side of the workgroup's own K16_BQ / K16_TS tiles
+// `side` = tiles on either side of the workgroup's own K16_BQ / K16_TS tiles.  Tighter seeds pay twice since the pruning
+// table tests every query against its own seed (meld_knn16_bounds): at 1M x 50, side 4 / 16 / 32 / 64 cost 0.6 / 1.2 /
+// 1.9 / 3.3 ms and leave the search at 45.9 / 41.9 / 40.9 / 38.9 ms.  The cost grows with N, the gain with N^2: the
+// automatic choice is N / 31250 tiles, between 4 and 64.
 template <int KB, int SEED_K>
 __global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
                                                               const _Float16* __restrict__ Rt16,
                                                               const float* __restrict__ scale_info,
                                                               const float* __restrict__ norm2_max, int n_tiles,
-                                                              int first_tile, int knn1, float rf2, float err_c, float err_l,
+                                                              int first_tile, int side, int knn1, float rf2, float err_c, float err_l,
                                                               float* __restrict__ thr_init) {
   constexpr int HV = KB * 2 * K16_TS;  // hi vectors per tile
   constexpr int NS = (HV + 255) / 256;
@@ -1432,7 +1435,7 @@ __global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __
   };
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   const int t_own = first_tile + blockIdx.x * (K16_BQ / K16_TS);
-  for (int tt = -SEED_SIDE; tt < K16_BQ / K16_TS + SEED_SIDE; ++tt) {
+  for (int tt = -side; tt < K16_BQ / K16_TS + side; ++tt) {
     const int t = t_own + tt;
     if (t < 0 || t >= n_tiles) continue;  // (uniform)
     __syncthreads();
@@ -1763,8 +1766,9 @@ extern "C" int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, con
 // on either side (see knn16_seed_mfma_kernel).  Q16 / Qn / Rt16 / scale_info / norm2_max as for meld_knn16_topk.
 extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                                                const float* norm2_max, int64_t n_ref, int d, int64_t q_begin,
-                                               int64_t q_count, int knn, double radius_factor, int nprod, float* thr_init,
-                                               meld_stream_t stream) {
+                                               int64_t q_count, int knn, double radius_factor, int nprod, int side_tiles,
+                                               float* thr_init, meld_stream_t stream) {
+  const int side = side_tiles > 0 ? side_tiles : (int)std::min<int64_t>(64, std::max<int64_t>(4, n_ref / 31250));
   MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && norm2_max && thr_init && n_ref > 0 && q_count > 0 && q_begin >= 0,
                  "meld_knn16_seed_thresholds_mfma: bad arguments");
   MELD_CHECK_ARG(q_begin % K16_BQ == 0, "meld_knn16_seed_thresholds_mfma: q_begin must be a multiple of the query block (%d)", K16_BQ);
@@ -1785,7 +1789,7 @@ extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn,
 #define K16_SEEDM_LAUNCH(KBV, KV)                                                                                       \
   hipLaunchKernelGGL((knn16_seed_mfma_kernel<KBV, KV>), dim3(n_b), dim3(256), 0, st,                                     \
                      reinterpret_cast<const _Float16*>(Q16), Qn, reinterpret_cast<const _Float16*>(Rt16), scale_info,    \
-                     norm2_max, n_tiles, (int)(q_begin / K16_TS), knn + 1, rf2, ec, el, thr_init)
+                     norm2_max, n_tiles, (int)(q_begin / K16_TS), side, knn + 1, rf2, ec, el, thr_init)
 #define K16_SEEDM_CASE(KBV)          \
   case KBV:                          \
     if (knn + 1 <= 16)               \

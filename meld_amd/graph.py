@@ -466,7 +466,7 @@ class HipOps:
                 if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
                     check(lib.meld_knn16_seed_thresholds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
                 else:
-                    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
+                    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
             if will_prune:
                 # (after the seeds: with them the table also drops the tiles no query of a wave can reach from

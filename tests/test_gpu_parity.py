@@ -581,11 +581,16 @@ def test_threshold_seeds_bound_the_kernel_radius():
     assert bool(torch.isinf(seeds[N:]).all())  # padding rows of the last block
     # the matrix-pipe version over the own tiles and four on either side (the default of the graph builder)
     seeds2 = torch.empty(q_pad, dtype=torch.float32, device="cuda")
-    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), ptr(nmax), N, d, 0, N, knn, rf, 1, ptr(seeds2), st))
-    torch.cuda.synchronize()
-    got2 = seeds2[:N]
-    assert bool((got2 >= radius2).all())
-    assert float((got2 / radius2).median()) < 3.0
+    prev = None
+    for side in (0, 4, 16):  # (0 = automatic; a wider neighbourhood can only lower a seed)
+        check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), ptr(nmax), N, d, 0, N, knn, rf, 1, side, ptr(seeds2), st))
+        torch.cuda.synchronize()
+        got2 = seeds2[:N].clone()
+        assert bool((got2 >= radius2).all())
+        assert float((got2 / radius2).median()) < 3.0
+        if side == 16:
+            assert bool((got2 <= prev).all())
+        prev = got2
 
 
 def test_pruned_search_on_shard_ranges():
