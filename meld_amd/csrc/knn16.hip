@@ -52,6 +52,10 @@ constexpr int K16_SLACK = 128;     // CAP = ksel + slack
 #define K16_A_AHEAD 4  // A fragments of a pipeline segment requested ahead of its first MFMA (hi-only search; measured 2 -> 4: -2 %)
 #endif
 constexpr int K16_CAPMAX = 256;
+// Centroids per workgroup of the pruning-table kernel (64 per wave).  Every workgroup streams all cells of its query
+// slice past its centroids, so the tile traffic is N x d x 2 B x (tiles / centroids per workgroup): 7.9 GB at 1M cells
+// with 256 centroids (the kernel was bound by it, not by its MFMAs or the per-distance VALU work), 2 GB with 1024.
+constexpr int K16_BOUNDS_THREADS = 1024;
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
 constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
@@ -1077,7 +1081,7 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
 // accumulators the first test needs anyway).  Such a tile gets +inf in the table -- the search kernel needs
 // no change -- and at 1M x 50 the blocks computed fall from 35 % to 25 % (tools/sim_prune_rules.py).
 template <int KB, bool SEEDED>
-__global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
+__global__ __launch_bounds__(K16_BOUNDS_THREADS) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
                                                                 const float* __restrict__ Cr,
                                                                 const _Float16* __restrict__ Rt16, int n_tiles,
                                                                 int first_tile, int n_blocks, float err_coef,
@@ -1087,11 +1091,12 @@ __global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* 
                                                                 float seed_err_coef, __half* __restrict__ lb2) {
   constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
-  constexpr int NS = (HV + 255) / 256;
+  constexpr int BT = K16_BOUNDS_THREADS;
+  constexpr int NS = (HV + BT - 1) / BT;
   __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
   __shared__ __attribute__((aligned(16))) float lds_sa[2][K16_TS], lds_sb[2][K16_TS];  // s_p^2, 2 s_p of the tile's cells
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
-  const int c_base = blockIdx.x * 256 + wave * 64;
+  const int c_base = blockIdx.x * BT + wave * 64;
   f16x8 bhi[2][KB];
   float cn[2], cr[2];
 #pragma unroll
@@ -1114,7 +1119,7 @@ __global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* 
     const int t = first_tile + (b_lo * TPB + step);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int j = tid + 256 * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
+      const int j = tid + BT * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
       if (j < HV) p[u] = t < n_tiles ? R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (SEEDED && tid < K16_TS) {  // (seeds are numbered from the first query: table row b = queries 64 b .. 64 b + 63)
@@ -1125,7 +1130,7 @@ __global__ __launch_bounds__(256) void knn16_tile_bounds_kernel(const _Float16* 
   auto store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int j = tid + 256 * u;
+      const int j = tid + BT * u;
       if (j < HV) lds_a[buf][j] = p[u];
     }
     if (SEEDED && tid < K16_TS) {
@@ -1611,7 +1616,7 @@ extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_c
   (void)q_count;
   const int kb = meld_knn16_kblocks(d);
   if (kb < 0) return 0;
-  const size_t n_c = (size_t)ceil_div(ceil_div(n_ref, K16_TS), 256) * 256;  // centroid rows, padded to whole workgroups
+  const size_t n_c = (size_t)ceil_div(ceil_div(n_ref, K16_TS), K16_BOUNDS_THREADS) * K16_BOUNDS_THREADS;  // centroid rows, padded to whole workgroups
   return n_c * ((size_t)kb * 64 + 2 * sizeof(float)) + 256;
 }
 
@@ -1626,25 +1631,25 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
   const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(q_count, K16_BQ) * K16_NWAVE;  // table rows = waves
-  const size_t n_c = (size_t)ceil_div(n_t, 256) * 256;
+  const size_t n_c = (size_t)ceil_div(n_t, K16_BOUNDS_THREADS) * K16_BOUNDS_THREADS;
   hipStream_t st = S(stream);
   _Float16* c16 = reinterpret_cast<_Float16*>(temp);
   float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
   float* cr = cn + n_c;
   MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
   hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr);
-  const int gx = (int)(n_c / 256);
+  const int gx = (int)(n_c / K16_BOUNDS_THREADS);
   const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
   const float ec = (float)meld_knn16_error_coef(1, d);
   const float es = (float)meld_knn16_error_coef(nprod, d);  // the search's allowance: a tile is skipped only if d2_approx < thr fails for sure
 #define K16_BOUNDS_CASE(KBV)                                                                                              \
   case KBV:                                                                                                               \
     if (thr_seed)                                                                                                         \
-      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true>), dim3(gx, gy), dim3(256), 0, st, c16, cn, cr,              \
+      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true>), dim3(gx, gy), dim3(K16_BOUNDS_THREADS), 0, st, c16, cn, cr,              \
                          reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,       \
                          scale_info, thr_seed, q_count, es, reinterpret_cast<__half*>(lb2));                              \
     else                                                                                                                  \
-      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, false>), dim3(gx, gy), dim3(256), 0, st, c16, cn, cr,             \
+      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, false>), dim3(gx, gy), dim3(K16_BOUNDS_THREADS), 0, st, c16, cn, cr,             \
                          reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,       \
                          scale_info, thr_seed, q_count, es, reinterpret_cast<__half*>(lb2));                              \
     break;

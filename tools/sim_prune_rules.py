@@ -72,6 +72,11 @@ for w in waves:
         add("F with seeds from the %d nearest tiles (centroid distance)" % K, ((lbmin2 <= thr.max()) & (lb <= seedK.sqrt()[:, None]).any(0)).float().mean())
         add("   seed/thr median ratio, %d nearest" % K, (seedK / thr).median())
     add("   seed/thr median ratio, +-4 index tiles", (seed / thr).median())
+    for side in (16, 32, 64):
+        lo3, hi3 = max(0, 64 * (w - side)), min(N, 64 * (w + side + 4))
+        seed3 = rf2 * torch.topk(d2[:, lo3:hi3], knn + 1, dim=1, largest=False).values[:, knn]
+        add("F with seeds from +-%d index tiles" % side, ((lbmin2 <= thr.max()) & (lb <= seed3.sqrt()[:, None]).any(0)).float().mean())
+        add("   seed/thr median ratio, +-%d index tiles" % side, (seed3 / thr).median())
     for q in (0.9, 0.75):
         tq = torch.quantile(thr, q)
         add("A with the %.2f quantile of thr instead of the max (not exact)" % q, (lbmin2 <= tq).float().mean())
