@@ -1407,26 +1407,31 @@ __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restric
 // table tests every query against its own seed (meld_knn16_bounds): at 1M x 50, side 4 / 16 / 32 / 64 cost 0.6 / 1.2 /
 // 1.9 / 3.3 ms and leave the search at 45.9 / 41.9 / 40.9 / 38.9 ms.  The cost grows with N, the gain with N^2: the
 // automatic choice is N / 31250 tiles, between 4 and 64.
+// (SEED_WAVES waves = 64 SEED_WAVES queries per workgroup share every staged tile: the kernel is bound by its tile loads and
+// barriers, and a workgroup of 8 waves stages 8 + 2 side tiles where two of 4 waves staged 2 (4 + 2 side))
+constexpr int SEED_WAVES = 8;
 template <int KB, int SEED_K>
-__global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
+__global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
                                                               const _Float16* __restrict__ Rt16,
                                                               const float* __restrict__ scale_info,
                                                               const float* __restrict__ norm2_max, int n_tiles,
-                                                              int first_tile, int side, int knn1, float rf2, float err_c, float err_l,
+                                                              int first_tile, int side, int n_qwaves, int knn1, float rf2, float err_c, float err_l,
                                                               float* __restrict__ thr_init) {
   constexpr int HV = KB * 2 * K16_TS;  // hi vectors per tile
-  constexpr int NS = (HV + 255) / 256;
+  constexpr int ST = 64 * SEED_WAVES;
+  constexpr int NS = (HV + ST - 1) / ST;
   __shared__ __attribute__((aligned(16))) float4 lds_a[HV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
-  const int q_base = blockIdx.x * K16_BQ + wave * 64;
+  const int q_base = (blockIdx.x * SEED_WAVES + wave) * 64;
+  const bool has_q = blockIdx.x * SEED_WAVES + wave < n_qwaves;  // (the last workgroup may reach past the padded query rows)
   f16x8 bhi[2][KB];
   float nq[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const f16x8* qrow = reinterpret_cast<const f16x8*>(Q16 + (size_t)(q_base + g * 32 + jq) * (KB * 32));
+    const f16x8* qrow = reinterpret_cast<const f16x8*>(Q16 + (size_t)((has_q ? q_base : 0) + g * 32 + jq) * (KB * 32));
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
-    nq[g] = Qn[q_base + g * 32 + jq];
+    nq[g] = Qn[(has_q ? q_base : 0) + g * 32 + jq];
   }
   float best0[SEED_K], best1[SEED_K];
 #pragma unroll
@@ -1439,14 +1444,14 @@ __global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __
     }
   };
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
-  const int t_own = first_tile + blockIdx.x * (K16_BQ / K16_TS);
-  for (int tt = -side; tt < K16_BQ / K16_TS + side; ++tt) {
+  const int t_own = first_tile + blockIdx.x * SEED_WAVES;
+  for (int tt = -side; tt < SEED_WAVES + side; ++tt) {
     const int t = t_own + tt;
     if (t < 0 || t >= n_tiles) continue;  // (uniform)
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int j = tid + 256 * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
+      const int j = tid + ST * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
       if (j < HV) lds_a[j] = R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)];
     }
     __syncthreads();
@@ -1487,7 +1492,7 @@ __global__ __launch_bounds__(256) void knn16_seed_mfma_kernel(const _Float16* __
       a1 = best1[e];
     }
   }
-  if (h == 0) {
+  if (h == 0 && has_q) {
     const float s = scale_info[0];
     const float nmax_s = norm2_max[0] * s * s;
 #pragma unroll
@@ -1792,9 +1797,10 @@ extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn,
   const float ec = (float)meld_knn16_error_coef_const(1, d), el = (float)meld_knn16_error_coef_lin(1);
   (void)nprod;
 #define K16_SEEDM_LAUNCH(KBV, KV)                                                                                       \
-  hipLaunchKernelGGL((knn16_seed_mfma_kernel<KBV, KV>), dim3(n_b), dim3(256), 0, st,                                     \
-                     reinterpret_cast<const _Float16*>(Q16), Qn, reinterpret_cast<const _Float16*>(Rt16), scale_info,    \
-                     norm2_max, n_tiles, (int)(q_begin / K16_TS), side, knn + 1, rf2, ec, el, thr_init)
+  hipLaunchKernelGGL((knn16_seed_mfma_kernel<KBV, KV>), dim3((unsigned)ceil_div(n_b * K16_NWAVE, SEED_WAVES)),            \
+                     dim3(64 * SEED_WAVES), 0, st, reinterpret_cast<const _Float16*>(Q16), Qn,                            \
+                     reinterpret_cast<const _Float16*>(Rt16), scale_info, norm2_max, n_tiles, (int)(q_begin / K16_TS),   \
+                     side, n_b * K16_NWAVE, knn + 1, rf2, ec, el, thr_init)
 #define K16_SEEDM_CASE(KBV)          \
   case KBV:                          \
     if (knn + 1 <= 16)               \
