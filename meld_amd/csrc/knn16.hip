@@ -55,7 +55,7 @@ constexpr int K16_CAPMAX = 256;
 // Centroids per workgroup of the pruning-table kernel (64 per wave).  Every workgroup streams all cells of its query
 // slice past its centroids, so the tile traffic is N x d x 2 B x (tiles / centroids per workgroup): 7.9 GB at 1M cells
 // with 256 centroids (the kernel was bound by it, not by its MFMAs or the per-distance VALU work), 2 GB with 1024.
-constexpr int K16_BOUNDS_THREADS = 1024;
+constexpr int K16_BOUNDS_THREADS = 1024;  // (512 from 5 K blocks on: the centroid fragments of a wave no longer fit 128 registers)
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
 constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
@@ -1080,8 +1080,8 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
 // min_p [ acc_pt - s_p^2 - 2 s_p rho_t ] + |c_t|^2 - rho_t^2 > err (two VALU operations per distance on the
 // accumulators the first test needs anyway).  Such a tile gets +inf in the table -- the search kernel needs
 // no change -- and at 1M x 50 the blocks computed fall from 35 % to 25 % (tools/sim_prune_rules.py).
-template <int KB, bool SEEDED>
-__global__ __launch_bounds__(K16_BOUNDS_THREADS) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
+template <int KB, bool SEEDED, int BT>  // BT threads = BT centroids per workgroup
+__global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
                                                                 const float* __restrict__ Cr,
                                                                 const _Float16* __restrict__ Rt16, int n_tiles,
                                                                 int first_tile, int n_blocks, float err_coef,
@@ -1091,7 +1091,6 @@ __global__ __launch_bounds__(K16_BOUNDS_THREADS) void knn16_tile_bounds_kernel(c
                                                                 float seed_err_coef, __half* __restrict__ lb2) {
   constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
-  constexpr int BT = K16_BOUNDS_THREADS;
   constexpr int NS = (HV + BT - 1) / BT;
   __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
   __shared__ __attribute__((aligned(16))) float lds_sa[2][K16_TS], lds_sb[2][K16_TS];  // s_p^2, 2 s_p of the tile's cells
@@ -1643,20 +1642,21 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   float* cr = cn + n_c;
   MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
   hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr);
-  const int gx = (int)(n_c / K16_BOUNDS_THREADS);
+  const int bt = KB <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2;
+  const int gx = (int)(n_c / bt);
   const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
   const float ec = (float)meld_knn16_error_coef(1, d);
   const float es = (float)meld_knn16_error_coef(nprod, d);  // the search's allowance: a tile is skipped only if d2_approx < thr fails for sure
+#define K16_BOUNDS_LAUNCH(KBV, SD, BTV)                                                                                   \
+  hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, SD, BTV>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr,               \
+                     reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,           \
+                     scale_info, thr_seed, q_count, es, reinterpret_cast<__half*>(lb2))
 #define K16_BOUNDS_CASE(KBV)                                                                                              \
   case KBV:                                                                                                               \
     if (thr_seed)                                                                                                         \
-      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true>), dim3(gx, gy), dim3(K16_BOUNDS_THREADS), 0, st, c16, cn, cr,              \
-                         reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,       \
-                         scale_info, thr_seed, q_count, es, reinterpret_cast<__half*>(lb2));                              \
+      K16_BOUNDS_LAUNCH(KBV, true, (KBV <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2));                             \
     else                                                                                                                  \
-      hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, false>), dim3(gx, gy), dim3(K16_BOUNDS_THREADS), 0, st, c16, cn, cr,             \
-                         reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,       \
-                         scale_info, thr_seed, q_count, es, reinterpret_cast<__half*>(lb2));                              \
+      K16_BOUNDS_LAUNCH(KBV, false, (KBV <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2));                            \
     break;
   switch (KB) {
     K16_BOUNDS_CASE(1)
@@ -1673,6 +1673,7 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
       return MELD_ERR_UNSUPPORTED;
   }
 #undef K16_BOUNDS_CASE
+#undef K16_BOUNDS_LAUNCH
   MELD_LAUNCH_CHECK("meld_knn16_bounds");
   return MELD_OK;
 }

@@ -45,6 +45,7 @@ for mode in ("csr", "tiled"):
         G.ops.pt_layout(G)
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
+        print("  layout:", G.info.get("spmm"), flush=True)
         nt = G.pt["tensors"]["blk_ntile"].cpu().numpy()
         nd = G.pt["tensors"]["blk_ndist"].cpu().numpy()
         br = G.pt["tensors"]["blk_row"].cpu().numpy()
