@@ -332,9 +332,7 @@ int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, do
  *   seg       [meld_pt_seg_len(nb)] int32  per (block, wave, tile) entry offsets
  *   list_cols [nnz]     int32   block b's sorted distinct columns start at rowptr[blk_row[b]]
  *   pval      [nnz]     fp64    values in layout order   (+ optional pval32 [nnz] fp32, see the struct)
- *   pidx      [3 nnz + 8] bytes  packed 20-bit words, tile-local column | row slot << log2(tile_cols): word s of a
- *                               consumer wave's stream at bit 20 s from byte 3 * (position of the wave's first entry)
- *                               -- 2.5 index bytes per nonzero (the recurrence is bound by its HBM bytes)            */
+ *   pidx      [nnz]     uint32  tile-local column | row slot << log2(tile_cols)                   */
 typedef struct meld_pt_layout {
   const int32_t* blk_row;
   const int32_t* blk_ntile;
@@ -342,7 +340,7 @@ typedef struct meld_pt_layout {
   const int32_t* seg;
   const int32_t* list_cols;
   const double* pval;
-  const uint8_t* pidx;
+  const uint32_t* pidx;
   int32_t nb;
   const float* pval32; /* optional [nnz]: pval rounded to fp32, streamed by the Lanczos SpMV of the lmax estimate
                           (meld_pt_lanczos_*) instead of pval; NULL = not kept */
@@ -355,8 +353,8 @@ int meld_pt_debug_ablate(int mask);
 /* Build the layout of the local rows [0, n_rows) of a CSR matrix with n_cols columns (the arrays of
  * `layout` are written).  status[1] (device) receives 0, or the reason the layout cannot be used:
  * 1 = a block touches too many column panels, 2 = too many distinct columns in a block,
- * 3 = n_cols beyond the builder's index range, 4 = a (wave, tile) segment beyond 65535 entries, 5 = a segment beyond the
- * builder's staging buffer -- the caller then stays on meld_cheby_step. */
+ * 3 = n_cols beyond the builder's index range, 4 = a (wave, tile) segment beyond 65535 entries -- the caller then stays on
+ * meld_cheby_step. */
 int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, int64_t n_rows, int64_t n_cols,
                   const meld_pt_layout_t* layout, uint32_t* codes /* scratch, nnz entries */, int32_t* status,
                   meld_stream_t stream);

@@ -62,7 +62,7 @@ struct StepArgs {
   const int32_t* list_cols;  // [nnz] block b's sorted distinct columns start at rowptr[blk_row[b]]
   const double* pval;        // [nnz] values in (block, wave, tile, row, col) order
   const float* pval32;       // [nnz] the same rounded to fp32 (F32 instantiation: the lmax estimate's SpMV)
-  const uint8_t* pidx;       // packed 20-bit index words (tile-local column | row slot << 10), see pt_fill_kernel
+  const uint32_t* pidx;      // [nnz] tile-local column | row slot << 11
   const int64_t* rowptr;     // CSR row pointers (entry base of a block)
   const double* dw;
   const double* x_full;
@@ -175,9 +175,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     auto sg = [&](int t) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(sgv, t); };
     const double* pv = a.pval + ebase;
     const float* pv32 = a.pval32 + ebase;
+    const uint32_t* pi = a.pidx + ebase;
     const int e_begin = sg(0);
-    // index stream of this wave: 20-bit words (two in five bytes), starting at byte 3 * (first entry of the wave)
-    const uint8_t* pi = a.pidx + 3 * (ebase + (int64_t)e_begin);
     const int e_end = sg(T);
     // prefetch cursor over the flattened (tile, chunk) sequence; everything here is wave-uniform
     int tp = 0;
@@ -197,17 +196,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     // must never be copied, and the register allocator copies freely (loop phis, tied operands), so the slots are
     // PHYSICAL registers the compiler does not own: the kernel is limited to v0..v95 (amdgpu_num_vgpr) and the
     // asm names v96..v119 itself (values v[96 + 2u : 97 + 2u], packed indices v[112 + u]).
-    int ct[U], cn[U], cpar[U];  // (cpar: parity of the chunk's first entry within the wave's stream)
+    int ct[U], cn[U];
     const int e_last = max(e_end - 1, e_begin);
 #define PT_SLOT_LOAD(VLO, VHI, IX)                                                                          \
   asm volatile("global_load_dwordx2 v[" #VLO ":" #VHI "], %0, %2 nt\n\tglobal_load_dword v" #IX ", %1, %3 nt" \
                :                                                                                            \
-               : "v"(off8), "v"(offp), "s"(pv), "s"(pi)                                                     \
+               : "v"(off8), "v"(off4), "s"(pv), "s"(pi)                                                     \
                : "memory", "v" #VLO, "v" #VHI, "v" #IX)
 #define PT_SLOT_LOAD32(VLO, VHI, IX)                                                                   \
-  asm volatile("global_load_dword v" #VLO ", %0, %2 nt\n\tglobal_load_dword v" #IX ", %1, %3 nt"        \
+  asm volatile("global_load_dword v" #VLO ", %0, %1 nt\n\tglobal_load_dword v" #IX ", %0, %2 nt"        \
                :                                                                                         \
-               : "v"(off4), "v"(offp), "s"(pv32), "s"(pi)                                                \
+               : "v"(off4), "s"(pv32), "s"(pi)                                                           \
                : "memory", "v" #VLO, "v" #VHI, "v" #IX)
 #define PT_SLOT_TAKE(VLO, VHI, IX)                                                                                     \
   asm volatile("s_waitcnt vmcnt(14)\n\tv_mov_b32 %0, v" #VLO "\n\tv_mov_b32 %1, v" #VHI "\n\tv_mov_b32 %2, v" #IX \
@@ -218,12 +217,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       const int n = (tp < T) ? min(64, pend - pe) : 0;
       const int e = min(pe + lane, e_last);
       const unsigned off8 = (unsigned)e * 8u, off4 = (unsigned)e * 4u;
-      // 20-bit index words: entry s of the stream sits at bit 20 s, i.e. in the (unaligned) dword at byte
-      // 5 (s >> 1) + 2 (s & 1), shifted by 4 (s & 1)
-      const unsigned es = (unsigned)(e - e_begin);
-      const unsigned offp = (es >> 1) * 5u + (es & 1u) * 2u;
-      (void)off8;
-      (void)off4;
       if constexpr (F32) {
         switch (u) {  // (u is a constant after unrolling)
           case 0: PT_SLOT_LOAD32(96, 97, 112); break;
@@ -249,7 +242,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       }
       ct[u] = tp;
       cn[u] = n;
-      cpar[u] = (pe - e_begin) & 1;
       pe += n;
       while (tp < T && pe >= pend) {
         ++tp;
@@ -320,7 +312,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       for (int u = 0; u < U; ++u) {
         ct[u] = -1;
         cn[u] = 0;
-        cpar[u] = 0;
       }
       // two-stage pipeline over the chunks: stage 1 of chunk k + 1 (wait for its entries, re-issue its slot, enter
       // its tile if it is a new one, request its x values from LDS) runs before stage 2 of chunk k (products, run
@@ -342,9 +333,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
           const int n = cn[u], t = ct[u];
           double v;
           uint32_t ix;
-          const int par = cpar[u];
           take(u, v, ix);  // (in the first round: whatever the slot registers held; n == 0, nothing is used)
-          ix = (ix >> ((((unsigned)par ^ (unsigned)lane) & 1u) << 2)) & 0xFFFFFu;
           issue(u);  // the slot is free again: chunk k + U
           // ---- stage 2 of the previous chunk FIRST: its x values were requested a whole step ago, so the LDS wait
           // in front of the products is free; the gather of this chunk goes out at the END of the step and has the
@@ -846,13 +835,10 @@ constexpr int FILL_CAP = 12800;  // entries of the LDS image (12 B each)
 __global__ __launch_bounds__(THREADS) void pt_fill_kernel(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
                                                           const uint32_t* __restrict__ codes, const int32_t* __restrict__ blk_row,
                                                           const int32_t* __restrict__ blk_ntile, const int32_t* __restrict__ seg,
-                                                          double* __restrict__ pval, uint8_t* __restrict__ pidx,
-                                                          int32_t* __restrict__ status) {
+                                                          double* __restrict__ pval, uint32_t* __restrict__ pidx) {
   __shared__ double s_val[FILL_CAP];
   __shared__ uint32_t s_idx[FILL_CAP];
   __shared__ int s_seg[SEGW + 1], s_inv[SEGW];
-  __shared__ uint32_t s_carry[2];  // index word of a pair's first half that ended a tile range (see the copy-out)
-  int n_range = 0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.x / NW, w = blockIdx.x % NW;
   const int T = blk_ntile[b];
@@ -922,43 +908,39 @@ __global__ __launch_bounds__(THREADS) void pt_fill_kernel(const int64_t* __restr
         }
       }
       __syncthreads();
-      for (int i = tid; i < span; i += THREADS) pval[e0 + base + i] = s_val[i];
-      // The index words go out packed, 20 bits each (10: tile-local column, 9: row slot): entry s of the wave's stream
-      // at bit 20 s of the stream, which starts at byte 3 * (global position of the wave's first entry) -- 2.5 instead
-      // of 4 index bytes per nonzero of a kernel that is bound by its HBM bytes.  One thread per pair of entries (five
-      // bytes); a pair cut by the end of the tile range waits in s_carry for the next range.
-      {
-        const int s0 = base - s_seg[0];                     // stream position of the range's first entry
-        const bool last_range = jb >= T;
-        struct __attribute__((packed)) Five {
-          uint32_t lo;
-          uint8_t hi;
-        };
-        Five* out = reinterpret_cast<Five*>(pidx + 3 * (e0 + (int64_t)s_seg[0]));
-        const int m_lo = s0 >> 1, m_hi = (s0 + span + 1) >> 1;  // pairs [m_lo, m_hi) have an entry in the range
-        for (int m = m_lo + tid; m < m_hi; m += THREADS) {
-          const int ia = 2 * m - s0, ib = ia + 1;
-          const uint32_t wa = ia < 0 ? s_carry[n_range & 1] : s_idx[ia];
-          uint32_t wb = 0;
-          if (ib < span) {
-            wb = s_idx[ib];
-          } else if (!last_range) {
-            s_carry[(n_range + 1) & 1] = wa;  // (the pair is written with the next range)
-            continue;
-          }
-          Five f;
-          f.lo = wa | (wb << 20);
-          f.hi = (uint8_t)(wb >> 12);
-          out[m] = f;
-        }
+      for (int i = tid; i < span; i += THREADS) {
+        pval[e0 + base + i] = s_val[i];
+        pidx[e0 + base + i] = s_idx[i];
       }
-      ++n_range;
       __syncthreads();
     } else {
-      // one segment longer than the image (never on kNN graphs): the packed index stream is written from the image --
-      // the layout is refused and the caller stays on the CSR-stream kernel
-      if (tid == 0) atomicMax(status, 5);
-      ++n_range;
+      // one segment longer than the image (never on kNN graphs): its entries go out directly
+      for (int i = 0; i < kmine; ++i) {
+        const int k = wv + 16 * i;
+        const int64_t rs = __shfl(rs_l, i, 64), rend = __shfl(re_l, i, 64);
+        for (int64_t e = rs + lane; e < rend; e += 64) {
+          const uint32_t code = codes[e];
+          const int j = s_inv[code >> 26];
+          if (j == ja) {
+            const int pos = (code >> CP_BITS) & 0xFFFF;
+            const int n = s_seg[j + 1] - s_seg[j];
+            const int q = n >> 6, r = n & 63;
+            int l, cch;
+            if (pos < r * (q + 1)) {
+              l = pos / (q + 1);
+              cch = pos - l * (q + 1);
+            } else {
+              const int jj = pos - r * (q + 1);
+              const int lq = jj / max(q, 1);
+              l = r + lq;
+              cch = jj - lq * q;
+            }
+            const int64_t p = e0 + s_seg[j] + cch * 64 + l;
+            pval[p] = val[e];
+            pidx[p] = (code & (CP - 1)) | ((uint32_t)k << CP_BITS);
+          }
+        }
+      }
     }
     ja = jb;
   }
@@ -1035,7 +1017,7 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
                      codes, status, (g_pt_ablate >> 8) & 7);
   if (((g_pt_ablate >> 8) & 7) == 0)
     hipLaunchKernelGGL(pt::pt_fill_kernel, dim3(nb * pt::NW), dim3(pt::THREADS), 0, st, rowptr, val, codes, layout->blk_row,
-                       layout->blk_ntile, layout->seg, const_cast<double*>(layout->pval), const_cast<uint8_t*>(layout->pidx), status);
+                       layout->blk_ntile, layout->seg, const_cast<double*>(layout->pval), const_cast<uint32_t*>(layout->pidx));
   if (layout->pval32 != nullptr)  // (its own streaming pass: a third scattered store in the walk costs 0.5 ms, this 0.08)
     hipLaunchKernelGGL(pt::pt_round_f32_kernel, dim3(2048), dim3(256), 0, st, layout->pval, const_cast<float*>(layout->pval32),
                        (int64_t)0, rowptr, n_rows);

@@ -784,7 +784,7 @@ class HipOps:
         t = dict(
             blk_row=torch.empty(nb + 1, **i32), blk_ntile=torch.empty(nb, **i32), blk_ndist=torch.empty(nb, **i32),
             seg=torch.empty(int(lib.meld_pt_seg_len(nb)), **i32), list_cols=torch.empty(G.nnz, **i32),
-            pval=torch.empty(G.nnz, dtype=torch.float64, device=dev), pidx=torch.empty(3 * G.nnz + 8, dtype=torch.uint8, device=dev),
+            pval=torch.empty(G.nnz, dtype=torch.float64, device=dev), pidx=torch.empty(G.nnz, **i32),
             pval32=torch.empty(G.nnz, dtype=torch.float32, device=dev),  # fp32 values for the lmax estimate's SpMV
         )
         status = torch.zeros(1, **i32)

@@ -134,7 +134,6 @@ def test_tiled_layout_is_a_permutation_of_the_csr_and_bit_reproducible():
     blk_row = t["blk_row"]
     assert blk_row[0] == 0 and blk_row[nb] == G.n_rows and np.all(np.diff(blk_row) >= 0) and np.diff(blk_row).max() <= rmax.value
     rows, cols, vals = [], [], []
-    pidx_bytes = t["pidx"].view(np.uint8)
     for b in range(nb):
         T, e0 = int(t["blk_ntile"][b]), int(rowptr[blk_row[b]])
         lst = t["list_cols"][e0 : e0 + int(t["blk_ndist"][b])]
@@ -143,14 +142,8 @@ def test_tiled_layout_is_a_permutation_of_the_csr_and_bit_reproducible():
         for w in range(nw):
             for tl in range(T):
                 s, e = int(seg[w, tl]), int(seg[w, tl + 1])
-                # 20-bit index words: entry i of the wave's stream at bit 20 i from byte 3 * (position of its first entry)
-                pos = np.arange(s, e, dtype=np.int64) - int(seg[w, 0])
-                byte0 = 3 * (e0 + int(seg[w, 0])) + 5 * (pos >> 1) + 2 * (pos & 1)
-                raw = np.zeros(e - s, dtype=np.int64)
-                for k in range(4):
-                    raw |= pidx_bytes[byte0 + k].astype(np.int64) << (8 * k)
-                ix = (raw >> (4 * (pos & 1))) & 0xFFFFF
-                cl, sl = ix & (cp - 1), ix >> int(np.log2(cp))
+                ix = t["pidx"][e0 + s : e0 + e].view(np.uint32)
+                cl, sl = (ix & (cp - 1)).astype(np.int64), (ix >> int(np.log2(cp))).astype(np.int64)
                 rows.append(blk_row[b] + sl * nw + w)
                 cols.append(lst[int(seg[nw, tl]) * cp + cl])  # row nw of seg: list chunk of the tl-th processed tile
                 vals.append(t["pval"][e0 + s : e0 + e])
