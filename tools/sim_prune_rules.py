@@ -77,6 +77,16 @@ for w in waves:
         seed3 = rf2 * torch.topk(d2[:, lo3:hi3], knn + 1, dim=1, largest=False).values[:, knn]
         add("F with seeds from +-%d index tiles" % side, ((lbmin2 <= thr.max()) & (lb <= seed3.sqrt()[:, None]).any(0)).float().mean())
         add("   seed/thr median ratio, +-%d index tiles" % side, (seed3 / thr).median())
+    # finer granularity: the MFMA block is 32 queries x 32 references -- per (query group, half tile) liveness
+    seed3 = rf2 * torch.topk(d2[:, max(0, 64 * (w - 32)):min(N, 64 * (w + 36))], knn + 1, dim=1, largest=False).values[:, knn]
+    liveB = (lb <= seed3.sqrt()[:, None])                                  # [64 queries, T] full tiles, per query
+    add("F(+-32 seeds) 64q x 64r (the kernel's granularity)", ((lbmin2 <= thr.max()) & liveB.any(0)).float().mean())
+    lvg = torch.stack([liveB[:32].any(0), liveB[32:].any(0)])              # [2 groups, T]
+    add("   32q x 64r: blocks live", lvg.float().mean())
+    liveBh = (lbh <= seed3.sqrt()[:, None, None])                          # [64, T, 2] half tiles
+    add("   64q x 32r: blocks live", liveBh.any(0).float().mean())
+    lvgh = torch.stack([liveBh[:32].any(0), liveBh[32:].any(0)])
+    add("   32q x 32r: blocks live", lvgh.float().mean())
     for q in (0.9, 0.75):
         tq = torch.quantile(thr, q)
         add("A with the %.2f quantile of thr instead of the max (not exact)" % q, (lbmin2 <= tq).float().mean())
