@@ -1466,10 +1466,14 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
       }
+      // (one test per 16 values first: beyond the nearest few tiles no lane has anything to insert)
+      if (__any(min16(c0) + nq[0] < best0[SEED_K - 1])) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        insert(best0, c0[r] + nq[0]);
-        insert(best1, c1[r] + nq[1]);
+        for (int r = 0; r < 16; ++r) insert(best0, c0[r] + nq[0]);
+      }
+      if (__any(min16(c1) + nq[1] < best1[SEED_K - 1])) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) insert(best1, c1[r] + nq[1]);
       }
     }
   }

@@ -687,7 +687,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), split_tail=bool(self.split_tail),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), split_tail=bool(self.split_tail),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
@@ -731,8 +731,10 @@ class HipOps:
                 val = torch.empty(nnz, dtype=torch.float64, device=dev)
                 if nnz > 0:
                     check(lib.meld_csr_compact_rows(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), st), "meld_csr_compact_rows")
+                self.last_assemble = "bucket"
                 return rowptr, col, val
             del cursor, ucnt, tcol, tval, rowptr
+        self.last_assemble = "sort" if n > 0 else "empty"
         keys2, vals2 = self.sort_pairs(keys, vals, N)
         tb = lib.meld_merge_temp_bytes(max(n, 1))
         tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
@@ -943,7 +945,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     tm.stop("anisotropy_degree")
 
     nnz = int(col.shape[0])
-    info.update(N=N, d=d, knn=knn, nnz=nnz, mean_degree=nnz / N, stage_seconds=dict(tm.t))
+    info.update(N=N, d=d, knn=knn, nnz=nnz, mean_degree=nnz / N, stage_seconds=dict(tm.t), assemble=getattr(ops, "last_assemble", None))
     G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=info)
     G.bandwidth = bw
     G.perm = perm
