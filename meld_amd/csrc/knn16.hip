@@ -1444,16 +1444,27 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
   };
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   const int t_own = first_tile + blockIdx.x * SEED_WAVES;
-  for (int tt = -side; tt < SEED_WAVES + side; ++tt) {
-    const int t = t_own + tt;
-    if (t < 0 || t >= n_tiles) continue;  // (uniform)
-    __syncthreads();
+  // (the next tile is requested before the MFMAs of the current one: loading, storing and computing one after the
+  // other left the kernel at a sixth of what its MFMAs need)
+  const int t_lo = max(t_own - side, 0), t_hi = min(t_own + SEED_WAVES + side, n_tiles);
+  float4 stage[NS];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
       const int j = tid + ST * u;  // j-th hi vector: (kb*2+h)*64 + ref  ->  plane-0 slot of the tile
-      if (j < HV) lds_a[j] = R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)];
+      if (j < HV) stage[u] = R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)];
+    }
+  };
+  if (t_lo < t_hi) fetch(t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int j = tid + ST * u;
+      if (j < HV) lds_a[j] = stage[u];
     }
     __syncthreads();
+    if (t + 1 < t_hi) fetch(t + 1);
     const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_a);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
