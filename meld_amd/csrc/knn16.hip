@@ -667,8 +667,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
   // MFMAs of (buf, sub) into (n0, n1) interleaved with the vote on the finished block (c0, c1);
   // then the slow path if any lane of the finished block has a candidate
-  auto segment = [&](const _Float16* tile, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue)
-                     __attribute__((always_inline)) {
+  // (`fresh`, wave-uniform: (c0, c1) hold a block that has not been voted on yet.  A wave that sat tiles out comes back
+  // with a block it has already voted on: gating the slow path is enough -- overwriting the 32 accumulators with +inf
+  // instead made the register allocator copy them at the loop head, 36 v_mov per wave and tile on the hot path)
+  auto segment = [&](const _Float16* tile, int sub, f32x16& n0, f32x16& n1, const f32x16& c0, const f32x16& c1, int ref_base, bool issue,
+                     bool fresh) __attribute__((always_inline)) {
     if (issue) mfma_block(tile, sub, n0, n1);
     if (ABL == 3 || ABL == 4 || ABL == 8 || ABL == 9 || ABL == 10) {  // profiling ablation: MFMAs only, accumulators kept live
       asm volatile("" ::"v"(c0[0]), "v"(c0[15]), "v"(c1[0]), "v"(c1[15]));
@@ -682,7 +685,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       asm volatile("" ::"v"(m0), "v"(m1));
       return;
     }
-    if (__any(hit)) select(c0, c1, m0, m1, ref_base);
+    if (fresh && __any(hit)) select(c0, c1, m0, m1, ref_base);
   };
 
   // Which step follows `after`: the first one of the pruning window that some wave of the workgroup still
@@ -746,17 +749,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     const _Float16* tile_r = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(lds_ring) + rd_b);
     if (live_cur) {
       // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
-      segment(tile_r, 0, accA0, accA1, accB0, accB1, refB, true);
+      segment(tile_r, 0, accA0, accA1, accB0, accB1, refB, true, pend);
       // sub-tile 1 on the pipe while sub-tile 0 is voted on
-      segment(tile_r, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true);
+      segment(tile_r, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true, true);
       refB = t * K16_TS + 32 + 4 * h;
       pend = true;
       ++n_done;
     } else if (pend) {
       // this wave sits the tile out (pruned for its 64 queries): only the vote it still owes
-      segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accB0[r] = accB1[r] = INFINITY;
+      segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false, true);
       pend = false;
     }
 
@@ -822,7 +823,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     wr_b = free_b;
   };
   while (s_cur < n_scan) scan_step();
-  if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false);  // drain: sub-tile 1 of the last tile
+  if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false, true);  // drain: sub-tile 1 of the last tile
   {
     unsigned long long* tiles_done = K16_COLD(tiles_done);
     if (tiles_done && lane == 0) atomicAdd(tiles_done, (unsigned long long)n_done);
