@@ -433,6 +433,14 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
 
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
+  // The base of the reference tiles is needed once per iteration (the copy's buffer descriptor).  Under the kernel's SGPR
+  // pressure the compiler re-read it from the kernel-argument segment each time -- a scalar load and its wait in front of
+  // every copy request -- so it rides in two VGPRs instead (opaque to the rematerialiser) and comes back with
+  // v_readfirstlane.
+  int r4_lo_v, r4_hi_v;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+               : "=v"(r4_lo_v), "=v"(r4_hi_v)
+               : "s"((int)(unsigned)reinterpret_cast<size_t>(R4)), "s"((int)(reinterpret_cast<size_t>(R4) >> 32)));
   // Staging: global -> LDS directly (`buffer_load_dwordx4 ... lds`, gfx950's 16-byte LDS DMA): lane l of a wave
   // writes LDS slot M0-base + 16 l, so a wave copies 64 consecutive LDS vectors per instruction from per-lane
   // global offsets; no staging registers (8 VGPRs at d = 50 that now hold A fragments in flight), no ds_write,
@@ -462,7 +470,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
                : "memory")
 #define K16_LOAD(TILE, DSTB)                                                                                       \
   do {                                                                                                             \
-    const size_t src_ = reinterpret_cast<size_t>(R4 + (size_t)(TILE) * TILE_V4);                                   \
+    const size_t src_ = (((size_t)(unsigned)__builtin_amdgcn_readfirstlane(r4_hi_v) << 32) |                       \
+                         (size_t)(unsigned)__builtin_amdgcn_readfirstlane(r4_lo_v)) +                              \
+                        (size_t)(TILE) * (TILE_V4 * 16);                                                           \
     const k16_i32x4 rsrc = {(int)(unsigned)src_, (int)((src_ >> 32) & 0xffffu), TILE_V4 * 16, 0x00020000};         \
     if constexpr (NS > 0) if (K16_ROUND_OK(0)) K16_DMA(0, DSTB);                                                   \
     if constexpr (NS > 1) if (K16_ROUND_OK(1)) K16_DMA(1, DSTB);                                                   \
