@@ -198,13 +198,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     // asm names v96..v119 itself (values v[96 + 2u : 97 + 2u], packed indices v[112 + u]).
     int ct[U], cn[U];
     const int e_last = max(e_end - 1, e_begin);
+#ifndef PT_NT
+#define PT_NT " nt"
+#endif
 #define PT_SLOT_LOAD(VLO, VHI, IX)                                                                          \
-  asm volatile("global_load_dwordx2 v[" #VLO ":" #VHI "], %0, %2 nt\n\tglobal_load_dword v" #IX ", %1, %3 nt" \
+  asm volatile("global_load_dwordx2 v[" #VLO ":" #VHI "], %0, %2" PT_NT "\n\tglobal_load_dword v" #IX ", %1, %3" PT_NT \
                :                                                                                            \
                : "v"(off8), "v"(off4), "s"(pv), "s"(pi)                                                     \
                : "memory", "v" #VLO, "v" #VHI, "v" #IX)
 #define PT_SLOT_LOAD32(VLO, VHI, IX)                                                                   \
-  asm volatile("global_load_dword v" #VLO ", %0, %1 nt\n\tglobal_load_dword v" #IX ", %0, %2 nt"        \
+  asm volatile("global_load_dword v" #VLO ", %0, %1" PT_NT "\n\tglobal_load_dword v" #IX ", %0, %2" PT_NT        \
                :                                                                                         \
                : "v"(off4), "s"(pv32), "s"(pi)                                                           \
                : "memory", "v" #VLO, "v" #VHI, "v" #IX)
