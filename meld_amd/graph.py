@@ -886,6 +886,11 @@ def _exact_bandwidth(X, rows, knn):
         cand = torch.topk(d2, kk, dim=1, largest=False).indices
         dist = torch.linalg.vector_norm(X[cand] - Xq[:, None, :], dim=2)
         out[lo : lo + 256] = torch.sort(dist, dim=1).values[:, min(knn, kk - 1)]
+    # Two ulps down: the sweep counts the references STRICTLY closer than the bandwidth with its own summation order
+    # (even / odd FMA chains); a value that this routine rounds one ulp above the sweep's would count the bandwidth
+    # entry itself and flag the row again (seen on 11 % of 150k such rows).  4e-16 relative, 1.6e-14 on a kernel value.
+    zero = torch.zeros_like(out)
+    out = torch.nextafter(torch.nextafter(out, zero), zero)
     return out.clamp_(min=float(np.finfo(np.float64).eps))
 
 

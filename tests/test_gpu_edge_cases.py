@@ -85,6 +85,18 @@ def test_far_outliers_go_through_the_fallback_paths():
     assert DG.info["n_researched_rows"] + DG.info["n_flagged_rows"] > 0
 
 
+def test_clusters_of_very_different_scale_settle_through_the_exact_bandwidth():
+    """A tight cluster (spread 0.01) next to a wide one (spread 5, 30 away): inside the tight one every distance lies far
+    below the error allowance of the fp16 search and of its full-split re-search, the candidate lists miss true
+    neighbours, and the rows get their bandwidth from the exact recomputation (``_exact_bandwidth``) before the exact
+    sweep -- which counts with its own summation order (a bandwidth rounded one ulp above the sweep's value used to flag
+    11 % of such rows again and abort the build)."""
+    rng = np.random.default_rng(11)
+    X = np.concatenate([rng.normal(size=(2000, 20)) * 0.01, rng.normal(size=(2000, 20)) * 5.0 + 30.0])
+    DG, G = _check_graph(X, knn=15, rtol=1e-9, algorithm="kd_tree")
+    assert DG.info["n_flagged_rows"] >= 1000 and DG.info["n_rows_bandwidth_recomputed"] > 0
+
+
 @pytest.mark.parametrize("knn", [1, 2, 30, 60])
 def test_knn_range(knn):
     rng = np.random.default_rng(knn)
