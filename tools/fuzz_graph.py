@@ -1,0 +1,41 @@
+"""One-off fuzz of the graph builder against the oracle on small awkward inputs.  python tools/fuzz_graph.py [n_cases] [seed]"""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from scipy import sparse
+import meld_amd
+from oracle import meld_oracle as mo
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+kinds = ["gauss", "clusters", "duplicates", "grid", "multiscale", "line", "heavy"]
+bad = 0
+for c in range(n_cases):
+    kind = kinds[rng.integers(len(kinds))]
+    N = int(rng.integers(300, 20000)); d = int(rng.integers(1, 60)); knn = int(rng.integers(1, 25))
+    decay = float(rng.choice([2, 10, 40, 100])); thresh = float(rng.choice([1e-2, 1e-4, 1e-6])); aniso = float(rng.choice([0, 1]))
+    if kind == "gauss": X = rng.normal(size=(N, d))
+    elif kind == "clusters": X = rng.normal(size=(N, d)) * 0.3 + rng.normal(size=(8, d))[rng.integers(0, 8, N)] * 4
+    elif kind == "duplicates":
+        base = rng.normal(size=(max(N // 3, 10), d)); X = base[rng.integers(0, base.shape[0], N)]
+    elif kind == "grid": X = rng.integers(0, 6, size=(N, d)).astype(float)
+    elif kind == "multiscale": X = np.concatenate([rng.normal(size=(N // 2, d)) * 1e-3, rng.normal(size=(N - N // 2, d)) * 3 + 20])
+    elif kind == "line": X = np.outer(np.linspace(0, 1, N), rng.normal(size=d)) + 1e-4 * rng.normal(size=(N, d))
+    else: X = rng.standard_t(2.0, size=(N, d))
+    knn = min(knn, N - 2)
+    tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g" % (kind, N, d, knn, decay, thresh, aniso)
+    try:
+        G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree")
+        DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso)
+        A, B = sparse.csr_matrix(DG.W), sparse.csr_matrix(G.W)
+        A.sort_indices(); B.sort_indices()
+        if A.nnz != B.nnz or not np.array_equal(A.indices, B.indices):
+            D = abs(A - B); print("MISMATCH pattern", tag, A.nnz, B.nnz, "max|diff|", D.max()); bad += 1; continue
+        err = np.abs(A.data - B.data).max() / max(np.abs(B.data).max(), 1e-300)
+        flag = "" if err < 1e-9 else "  <-- VALUES"
+        bad += err >= 1e-9
+        print("ok  ", tag, "nnz %d err %.1e" % (A.nnz, err), flag, flush=True)
+    except Exception as e:
+        bad += 1
+        print("EXC ", tag, type(e).__name__, str(e)[:120], flush=True)
+print("bad:", bad)
