@@ -129,7 +129,8 @@ class MELD(GraphEstimator):
             X = data.to(device="cuda", dtype=torch.float64)
         else:
             X = torch.from_numpy(data).to("cuda")
-        if not bool(torch.isfinite(X).all()):
+        # (one pass: a NaN or an infinity anywhere makes its column sum non-finite; isfinite(X).all() is three)
+        if not bool(torch.isfinite(X.sum(dim=0)).all()) and not bool(torch.isfinite(X).all()):
             raise ValueError("Input data contains NaN or infinity")
         self.data_nu = None
         if self.n_pca is not None and self.n_pca < min(tuple(X.shape)):
