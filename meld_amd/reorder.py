@@ -18,6 +18,22 @@ from ._lib import check, get_lib, ptr
 __all__ = ["locality_permutation"]
 
 
+def _argsort_bits(keys, n_bits):
+    """Stable argsort of non-negative int64 keys below 2**n_bits: the library's radix sort over just those bits
+    (a 14-bit key takes two passes; torch.argsort sorts all 64)."""
+    lib = get_lib()
+    n = int(keys.shape[0])
+    dev = keys.device
+    keys = keys.contiguous()
+    idx = torch.arange(n, dtype=torch.float64, device=dev)  # (exact up to 2**53)
+    k2, v2 = torch.empty_like(keys), torch.empty_like(idx)
+    tb = lib.meld_sort_temp_bytes(n)
+    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(k2), ptr(idx), ptr(v2), n, int(max(1, n_bits)), ptr(tmp), tb,
+                                      torch.cuda.current_stream().cuda_stream), "meld_sort_pairs_u64_f64")
+    return v2.to(torch.int64)
+
+
 def _chain_order_batched(P):
     """Greedy nearest-neighbour chain over the rows of every P[b] (CUDA fp64 [B, m, d], m <= 64)
     -> rank [B, m] int64: position of each row along its chain (one wave per group on the device)."""
@@ -41,7 +57,7 @@ def _split_level(X, lib, st, group, n_groups, fanout):
     child along its group's chain [n_groups, fanout])."""
     N, d = int(X.shape[0]), int(X.shape[1])
     dev = X.device
-    order = torch.argsort(group, stable=True)
+    order = _argsort_bits(group, int(n_groups - 1).bit_length())
     counts = torch.bincount(group, minlength=n_groups)
     starts = torch.cumsum(counts, 0) - counts
     frac = (torch.arange(fanout, device=dev, dtype=torch.float64) + 0.5) / fanout
@@ -92,4 +108,4 @@ def locality_permutation(X, c1=None, fanouts=(16, 16), seed=0):
         key = key * f + rank[group, child]
         group = group * f + child
         n_groups *= f
-    return torch.argsort(key, stable=True)
+    return _argsort_bits(key, int(n_groups - 1).bit_length())
