@@ -238,10 +238,47 @@ __global__ __launch_bounds__(64) void lanczos_alpha_kernel(double* __restrict__ 
     state[5] = -alpha * state[0];
   }
 }
+// alpha step + axpy in one launch (the device-resident loops): every workgroup reduces the 64 partial sums of <y, u>
+// itself (same order, same value), so the scalar kernel between the SpMV and the axpy -- a launch and its gap per
+// iteration, 40 to 100 iterations per estimate -- is gone; workgroup 0 records alpha.  nrm2 must be zero on entry (the
+// caller at the first iteration, lanczos_beta_kernel afterwards).
+__global__ __launch_bounds__(256) void lanczos_axpy_fused_kernel(double* __restrict__ state, const double* __restrict__ dots,
+                                                                 double* __restrict__ nrm2, double* __restrict__ alphas, int it,
+                                                                 const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+  __shared__ double s_a;
+  __shared__ double s_part[4];
+  if (threadIdx.x < 64) {
+    const double v = wave_sum(dots[threadIdx.x]);
+    if (threadIdx.x == 0) {
+      const double s_cur = state[0];
+      const double alpha = v * s_cur;
+      s_a = -alpha * s_cur;
+      if (blockIdx.x == 0) {
+        alphas[it] = alpha;
+        state[5] = -alpha * s_cur;
+      }
+    }
+  }
+  __syncthreads();
+  const double a = s_a;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = a * x[i] + y[i];
+    y[i] = v;
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&nrm2[blockIdx.x % DOT_SLOTS], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
 __global__ __launch_bounds__(64) void lanczos_beta_kernel(double* __restrict__ state, const double* __restrict__ nrm2,
-                                                          double* __restrict__ dots, double* __restrict__ betas, int it) {
+                                                          double* __restrict__ dots, double* __restrict__ betas, int it,
+                                                          double* __restrict__ nrm2_clear) {
   double v = nrm2[threadIdx.x];
   v = wave_sum(v);
+  // (device-resident loops: read above by every lane, the next fused axpy accumulates into these slots)
+  if (nrm2_clear != nullptr) nrm2_clear[threadIdx.x] = 0.0;
   dots[threadIdx.x] = 0.0;  // the next SpMV accumulates <y, u> and <y, y> into these slots
   dots[DOT_SLOTS + threadIdx.x] = 0.0;
   if (threadIdx.x == 0) {
@@ -341,10 +378,9 @@ extern "C" int meld_lanczos_steps(const int64_t* rowptr, const int32_t* col, con
     // y = s_cur L u - beta_{k-1} s_prev u_prev ;  dots <- <y, u>
     launch_cheby<1, RB>(rowptr, col, val, dw, n_rows, 1, 0, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots, chunk, st,
                         state);
-    hipLaunchKernelGGL(lanczos_alpha_kernel, dim3(1), dim3(64), 0, st, state, dots, nrm2, alphas, it);
-    // w = y - alpha v_k (in y) ;  nrm2 <- |w|^2
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_ax), dim3(256), 0, st, 0.0, u, 1.0, y, n_rows, nrm2, state + 5);
-    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it);
+    // alpha_k = s_cur <y, u>;  w = y - alpha v_k (in y) ;  nrm2 <- |w|^2
+    hipLaunchKernelGGL(lanczos_axpy_fused_kernel, dim3(grid_ax), dim3(256), 0, st, state, dots, nrm2, alphas, it, u, y, n_rows);
+    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it, nrm2);
   }
   MELD_LAUNCH_CHECK("meld_lanczos_steps");
   return MELD_OK;
@@ -386,9 +422,8 @@ extern "C" int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64
     double* y = V[(it + 2) % 3];
     const int rc = pt_step(layout, rowptr, dw, 1, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots, state, st);
     if (rc != MELD_OK) return rc;
-    hipLaunchKernelGGL(lanczos_alpha_kernel, dim3(1), dim3(64), 0, st, state, dots, nrm2, alphas, it);
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_ax), dim3(256), 0, st, 0.0, u, 1.0, y, n_rows, nrm2, state + 5);
-    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it);
+    hipLaunchKernelGGL(lanczos_axpy_fused_kernel, dim3(grid_ax), dim3(256), 0, st, state, dots, nrm2, alphas, it, u, y, n_rows);
+    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it, nrm2);
   }
   MELD_LAUNCH_CHECK("meld_pt_lanczos_steps");
   return MELD_OK;
@@ -424,7 +459,7 @@ extern "C" int meld_lanczos_axpy(const double* x_local, double* y_local, int64_t
 extern "C" int meld_lanczos_beta(double* state, const double* nrm2, double* dots, double* betas, int it,
                                  meld_stream_t stream) {
   MELD_CHECK_ARG(state && nrm2 && dots && betas && it >= 0, "meld_lanczos_beta: bad arguments");
-  hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, S(stream), state, nrm2, dots, betas, it);
+  hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, S(stream), state, nrm2, dots, betas, it, (double*)nullptr);
   MELD_LAUNCH_CHECK("lanczos_beta_kernel");
   return MELD_OK;
 }
