@@ -1041,16 +1041,58 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
     cs[tid] = tid < d ? acc / (float)cnt : 0.0f;
   }
   __syncthreads();
+  // The centre the bounds are measured from is any point; the radius is what the pruning test pays for.  Starting at the
+  // centroid, a few steps of Badoiu-Clarkson (move 1 / (i + 1) of the way towards the farthest cell) approach the centre of
+  // the smallest enclosing ball; the best centre met is kept.  One wave, the cells one per lane.
+  __shared__ float cb[K16_DMAX + 19];
+  __shared__ float s_best_r2;
   if (tid < 64) {
-    float r2 = 0.0f;
-    if (tid < cnt) {
-      for (int k = 0; k < d; ++k) {
-        const float t = xs[tid][k] - cs[k];
-        r2 = fmaf(t, t, r2);
+    const int lane = tid;
+    auto far2 = [&](int* who) {
+      float r2 = -1.0f;
+      if (lane < cnt) {
+        r2 = 0.0f;
+        for (int k = 0; k < d; ++k) {
+          const float t = xs[lane][k] - cs[k];
+          r2 = fmaf(t, t, r2);
+        }
       }
-    }
+      float m = r2;
+      int mi = lane;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+      for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, 64);
+        const int oi = __shfl_xor(mi, off, 64);
+        if (om > m || (om == m && oi < mi)) {
+          m = om;
+          mi = oi;
+        }
+      }
+      *who = mi;
+      return m;
+    };
+    float best = INFINITY;
+    constexpr int MEB_STEPS = 12;
+    for (int it = 1; it <= MEB_STEPS + 1; ++it) {
+      int who;
+      const float r2 = far2(&who);
+      if (r2 < best) {
+        best = r2;
+        for (int k = lane; k < KB * 16; k += 64) cb[k] = cs[k];
+      }
+      if (it <= MEB_STEPS) {
+        const float wgt = 1.0f / (float)(it + 1);
+        for (int k = lane; k < d; k += 64) cs[k] = fmaf(wgt, xs[who][k] - cs[k], cs[k]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // (one wave: its LDS operations complete in order)
+      asm volatile("" ::: "memory");
+    }
+    for (int k = lane; k < KB * 16; k += 64) cs[k] = cb[k];
+    if (lane == 0) s_best_r2 = best;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float r2 = s_best_r2;
     float n = 0.0f;
     for (int k = 0; k < d; ++k) n = fmaf(cs[k], cs[k], n);
     if (tid == 0) {
