@@ -1072,7 +1072,10 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
       return m;
     };
     float best = INFINITY;
-    constexpr int MEB_STEPS = 12;
+#ifndef K16_MEB_STEPS
+#define K16_MEB_STEPS 24
+#endif
+    constexpr int MEB_STEPS = K16_MEB_STEPS;
     for (int it = 1; it <= MEB_STEPS + 1; ++it) {
       int who;
       const float r2 = far2(&who);
