@@ -21,7 +21,20 @@ pad = T * 64 - N
 Xp = torch.cat([Xo, Xo[-1:].expand(pad, -1)]) if pad else Xo
 tiles = Xp.view(T, 64, -1)
 C = tiles.mean(1)
-rho = torch.linalg.vector_norm(tiles - C[:, None, :], dim=2).max(1).values
+rho_centroid = torch.linalg.vector_norm(tiles - C[:, None, :], dim=2).max(1).values
+# centres near the smallest enclosing ball (what tile_spheres_kernel does): 24 Badoiu-Clarkson steps from the centroid
+Cb, rb = C.clone(), rho_centroid.clone()
+Cc = C.clone()
+for it in range(1, 26):
+    dist = torch.linalg.vector_norm(tiles - Cc[:, None, :], dim=2)
+    r, who = dist.max(1)
+    better = r < rb
+    Cb[better], rb[better] = Cc[better], r[better]
+    if it <= 24:
+        far = tiles[torch.arange(T, device=tiles.device), who]
+        Cc = Cc + (far - Cc) / (it + 1)
+print("tile radius: centroid %.4f -> enclosing-ball centre %.4f (mean)" % (rho_centroid.mean(), rb.mean()))
+C, rho = Cb, rb
 # two half-tile spheres (32 + 32 cells in index order)
 C2 = tiles.view(T, 2, 32, -1).mean(2)
 rho2 = torch.linalg.vector_norm(tiles.view(T, 2, 32, -1) - C2[:, :, None, :], dim=3).max(2).values
@@ -46,6 +59,10 @@ for w in waves:
     lb = (Dc - rho[None, :]).clamp_min(0)
     lbmin2 = lb.min(0).values ** 2
     add("ideal (tile holds a candidate)", need.float().mean())
+    # the transposed bound: every reference of tile t against THIS wave's sphere
+    dcw = torch.linalg.vector_norm(Xp - C[w][None, :], dim=1).view(T, 64).min(1).values
+    lbT = (dcw - rho[w]).clamp_min(0)
+    lbsym2 = torch.maximum(lb.min(0).values, lbT) ** 2
     add("A: min_p LB <= max_p thr (final thresholds)", (lbmin2 <= thr.max()).float().mean())
     add("A: ... with the seeds", (lbmin2 <= seed.max()).float().mean())
     add("B: any_p LB_p <= thr_p (final)", (lb <= thr.sqrt()[:, None]).any(0).float().mean())
@@ -58,6 +75,8 @@ for w in waves:
     phi = (thr.sqrt() / seed.sqrt()).max()
     add("E: phi rule  min_p LB_p/s_p <= max_p r_p/s_p (final)", (phis <= phi).float().mean())
     add("F: A(final) and B(seeds)", ((lbmin2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    add("F + transposed bound in A (final)", ((lbsym2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    add("F + transposed bound in A (seeds)", ((lbsym2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     add("G: A(final) and E", ((lbmin2 <= thr.max()) & (phis <= phi)).float().mean())
     add("G at the start: A(seeds) and B(seeds)", ((lbmin2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     lo2, hi2 = max(0, 64 * (w - 16)), min(N, 64 * (w + 20))
