@@ -49,6 +49,7 @@ for w in waves:
     d2 = ((P * P).sum(1)[:, None] + n2[None, :] - 2.0 * P @ Xo.T).clamp_min(0)
     srt = torch.topk(d2, ksel, dim=1, largest=False).values
     thr = torch.minimum(srt[:, ksel - 1], rf2 * srt[:, knn])          # final thresholds (error allowance ignored)
+    seed3 = rf2 * torch.topk(d2[:, max(0, 64 * (w - 32)):min(N, 64 * (w + 36))], knn + 1, dim=1, largest=False).values[:, knn]
     lo, hi = max(0, 64 * (w - 4)), min(N, 64 * (w + 8))
     seed = rf2 * torch.topk(d2[:, lo:hi], knn + 1, dim=1, largest=False).values[:, knn]
     # which tiles hold a candidate
@@ -77,6 +78,13 @@ for w in waves:
     add("F: A(final) and B(seeds)", ((lbmin2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     add("F + transposed bound in A (final)", ((lbsym2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     add("F + transposed bound in A (seeds)", ((lbsym2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    # transposed per-query test: dead if min_r |r - c_w| > max_p (s_p + |p - c_w|)
+    dpc = torch.linalg.vector_norm(P - C[w][None, :], dim=1)
+    for nm, sd in (("seeds +-4", seed), ("seeds +-32", seed3)):
+        kap = (sd.sqrt() + dpc).max()
+        liveT = dcw <= kap
+        add("F(sym A final) + transposed per-query test, %s" % nm, ((lbsym2 <= thr.max()) & (lb <= sd.sqrt()[:, None]).any(0) & liveT).float().mean())
+        add("   same at the start (A with the seeds), %s" % nm, ((lbsym2 <= sd.max()) & (lb <= sd.sqrt()[:, None]).any(0) & liveT).float().mean())
     add("G: A(final) and E", ((lbmin2 <= thr.max()) & (phis <= phi)).float().mean())
     add("G at the start: A(seeds) and B(seeds)", ((lbmin2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     lo2, hi2 = max(0, 64 * (w - 16)), min(N, 64 * (w + 20))
@@ -97,7 +105,6 @@ for w in waves:
         add("F with seeds from +-%d index tiles" % side, ((lbmin2 <= thr.max()) & (lb <= seed3.sqrt()[:, None]).any(0)).float().mean())
         add("   seed/thr median ratio, +-%d index tiles" % side, (seed3 / thr).median())
     # finer granularity: the MFMA block is 32 queries x 32 references -- per (query group, half tile) liveness
-    seed3 = rf2 * torch.topk(d2[:, max(0, 64 * (w - 32)):min(N, 64 * (w + 36))], knn + 1, dim=1, largest=False).values[:, knn]
     liveB = (lb <= seed3.sqrt()[:, None])                                  # [64 queries, T] full tiles, per query
     add("F(+-32 seeds) 64q x 64r (the kernel's granularity)", ((lbmin2 <= thr.max()) & liveB.any(0)).float().mean())
     lvg = torch.stack([liveB[:32].any(0), liveB[32:].any(0)])              # [2 groups, T]
