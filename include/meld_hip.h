@@ -115,7 +115,8 @@ size_t meld_knn16_bounds_bytes(int64_t n_ref, int64_t q_count);
 size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_count);
 int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                       const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
-                      const float* thr_seed, int nprod, void* temp, void* lb2, meld_stream_t stream);
+                      const float* thr_seed, const float* q_norm2 /* optional: Qn of meld_knn16_prepare, per-row allowance */,
+                      int nprod, void* temp, void* lb2, meld_stream_t stream);
 /* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are

@@ -1144,7 +1144,9 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
                                                                 const float* __restrict__ norm2_max,
                                                                 const float* __restrict__ scale_info,
                                                                 const float* __restrict__ thr_seed, int64_t n_seed,
-                                                                float seed_err_coef, int mark_sign, __half* __restrict__ lb2) {
+                                                                float seed_err_coef, int mark_sign,
+                                                                const float* __restrict__ q_norm2, float err_c, float err_l,
+                                                                __half* __restrict__ lb2) {
   constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
   constexpr int NS = (HV + BT - 1) / BT;
@@ -1169,7 +1171,9 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
   const float4* R4 = reinterpret_cast<const float4*>(Rt16);
   float4 p[NS];
   float seed_v = 0.0f;
-  const float seed_margin = seed_err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+  const float nmax_s = norm2_max[0] * scale_info[0] * scale_info[0];
+  const float seed_margin = seed_err_coef * nmax_s;
+  float seed_nq = -1.0f;  // |q|^2 of the cell (scaled), when the caller has it: the allowance of ITS row instead of the global one
   auto load = [&](int step) __attribute__((always_inline)) {
     const int t = first_tile + (b_lo * TPB + step);
 #pragma unroll
@@ -1180,6 +1184,7 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     if (SEEDED && tid < K16_TS) {  // (seeds are numbered from the first query: table row b = queries 64 b .. 64 b + 63)
       const int64_t q = (int64_t)(b_lo * TPB + step) * K16_TS + tid;
       seed_v = q < n_seed ? thr_seed[q] : -1.0f;  // (-1: no cell here, the padding of the last tile)
+      seed_nq = (q_norm2 != nullptr && q < n_seed) ? q_norm2[q] : -1.0f;
     }
   };
   auto store = [&](int buf) __attribute__((always_inline)) {
@@ -1191,7 +1196,10 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     if (SEEDED && tid < K16_TS) {
       // a padding cell (its |r|^2 is +inf, so is every accumulator) must add nothing to +inf; a cell without
       // a seed (+inf) keeps the tile alive: acc - inf = -inf
-      const float sp = seed_v < 0.0f ? 0.0f : sqrtf(seed_v + seed_margin) * 1.0001f;
+      // search-error allowance of the cell's own row (refine's E_i = c_const n_max + c_lin sqrt(n_i n_max), rounded up),
+      // the global one without the norms
+      const float e_row = seed_nq >= 0.0f ? fminf((err_c * nmax_s + err_l * sqrtf(seed_nq * nmax_s)) * 1.001f, seed_margin) : seed_margin;
+      const float sp = seed_v < 0.0f ? 0.0f : sqrtf(seed_v + e_row) * 1.0001f;
       lds_sa[buf][tid] = sp * sp;
       lds_sb[buf][tid] = seed_v < 0.0f || !(sp < INFINITY) ? 0.0f : 2.0f * sp;
     }
@@ -1741,7 +1749,8 @@ extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_c
 
 extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                                  const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
-                                 const float* thr_seed, int nprod, void* temp, void* lb2, meld_stream_t stream) {
+                                 const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* lb2,
+                                 meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_bounds: nprod must be 1 or 3");
   MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 &&
                      q_begin + q_count <= N,
@@ -1767,7 +1776,9 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
 #define K16_BOUNDS_LAUNCH(KBV, SD, BTV)                                                                                   \
   hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, SD, BTV>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr,               \
                      reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,           \
-                     scale_info, thr_seed, q_count, es, symmetric ? 1 : 0, reinterpret_cast<__half*>(lb2))
+                     scale_info, thr_seed, q_count, es, symmetric ? 1 : 0, q_norm2,                                       \
+                     (float)meld_knn16_error_coef_const(nprod, d), (float)meld_knn16_error_coef_lin(nprod),               \
+                     reinterpret_cast<__half*>(lb2))
 #define K16_BOUNDS_CASE(KBV)                                                                                              \
   case KBV:                                                                                                               \
     if (thr_seed)                                                                                                         \

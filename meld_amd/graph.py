@@ -475,7 +475,7 @@ class HipOps:
                 tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 seeded_bounds = seeds is not None and self.seeded_bounds
-                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 if self.block_order and q_main == q_count and n_blocks > 1:
                     # longest query blocks first (the dispatch follows the block index): see meld_knn16_block_work
                     work = torch.empty(n_blocks, dtype=torch.int32, device=dev)

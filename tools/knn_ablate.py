@@ -28,7 +28,7 @@ lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, N), dtype=torch.uint8, device="
 mseed = torch.empty(q_pad, dtype=torch.float32, device="cuda")   # the product's seeds (neighbourhood of the own block, on the matrix pipe)
 check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), ptr(nmax), N, d, 0, N, 15, (-math.log(1e-4)) ** (1 / 40), 1, 0, ptr(mseed), st))
 seeded_table = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
-check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(mseed) if seeded_table else None, 1, ptr(tmpb), ptr(lb2), st))
+check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(mseed) if seeded_table else None, ptr(Qn) if seeded_table else None, 1, ptr(tmpb), ptr(lb2), st))
 ci = torch.empty(q_pad * cap, dtype=torch.int32, device="cuda"); cd = torch.empty(q_pad * cap, dtype=torch.float32, device="cuda"); cc = torch.empty(q_pad, dtype=torch.int32, device="cuda")
 cthr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device="cuda"); done = torch.zeros(1, dtype=torch.int64, device="cuda")
 rf = (-math.log(1e-4)) ** (1 / 40)
