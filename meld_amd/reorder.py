@@ -11,6 +11,7 @@ oracle in the original order); only memory locality changes.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -69,6 +70,13 @@ def _split_level(X, lib, st, group, n_groups, fanout):
     child = torch.empty(N, dtype=torch.int32, device=dev)
     g32 = group.to(torch.int32)
     check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
+    for _ in range(int(os.environ.get("MELD_REORDER_LLOYD", "0"))):
+        # Lloyd step: sub-centroids = means of their cells, cells re-assigned (tuning hook)
+        leaf = group * fanout + child.to(torch.int64)
+        sums = torch.zeros(n_groups * fanout, d, dtype=torch.float64, device=dev).index_add_(0, leaf, X)
+        cnt = torch.zeros(n_groups * fanout, dtype=torch.float64, device=dev).index_add_(0, leaf, torch.ones(N, dtype=torch.float64, device=dev))
+        cents = torch.where(cnt[:, None] > 0, sums / cnt.clamp_min(1.0)[:, None], cents).contiguous()
+        check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
     rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
     return child.to(torch.int64), rank
 
