@@ -35,6 +35,22 @@ for it in range(1, 26):
         Cc = Cc + (far - Cc) / (it + 1)
 print("tile radius: centroid %.4f -> enclosing-ball centre %.4f (mean)" % (rho_centroid.mean(), rb.mean()))
 C, rho = Cb, rb
+# the same for half tiles (32 cells)
+def meb(pts):
+    T2 = pts.shape[0]
+    c0 = pts.mean(1); r0 = torch.linalg.vector_norm(pts - c0[:, None, :], dim=2).max(1).values
+    cb_, rb_, cc = c0.clone(), r0.clone(), c0.clone()
+    for it in range(1, 26):
+        dist = torch.linalg.vector_norm(pts - cc[:, None, :], dim=2)
+        r, who = dist.max(1)
+        better = r < rb_
+        cb_[better], rb_[better] = cc[better], r[better]
+        if it <= 24:
+            far = pts[torch.arange(T2, device=pts.device), who]
+            cc = cc + (far - cc) / (it + 1)
+    return cb_, rb_
+Ch, rh = meb(tiles.reshape(2 * T, 32, -1))
+print("half-tile radius (enclosing-ball centres): %.4f (mean)" % rh.mean())
 # two half-tile spheres (32 + 32 cells in index order)
 C2 = tiles.view(T, 2, 32, -1).mean(2)
 rho2 = torch.linalg.vector_norm(tiles.view(T, 2, 32, -1) - C2[:, :, None, :], dim=3).max(2).values
@@ -76,6 +92,9 @@ for w in waves:
     phi = (thr.sqrt() / seed.sqrt()).max()
     add("E: phi rule  min_p LB_p/s_p <= max_p r_p/s_p (final)", (phis <= phi).float().mean())
     add("F: A(final) and B(seeds)", ((lbmin2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
+    lbH = (torch.cdist(P, Ch).view(64, T, 2) - rh.view(1, T, 2)).clamp_min(0).min(2).values   # nearer of the two half spheres
+    add("two half-tile spheres: A(final) and B(seeds +-32)", ((lbH.min(0).values ** 2 <= thr.max()) & (lbH <= seed3.sqrt()[:, None]).any(0)).float().mean())
+    add("one sphere:            A(final) and B(seeds +-32)", ((lbmin2 <= thr.max()) & (lb <= seed3.sqrt()[:, None]).any(0)).float().mean())
     add("F + transposed bound in A (final)", ((lbsym2 <= thr.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     add("F + transposed bound in A (seeds)", ((lbsym2 <= seed.max()) & (lb <= seed.sqrt()[:, None]).any(0)).float().mean())
     # transposed per-query test: dead if min_r |r - c_w| > max_p (s_p + |p - c_w|)
