@@ -18,6 +18,7 @@ __all__ = [
     "get_meld_cmap",
     "normalize_densities",
     "VertexFrequencyCluster",
+    "Benchmarker",
     "utils",
     "filter",
     "__version__",
@@ -30,4 +31,8 @@ def __getattr__(name):
         from .cluster import VertexFrequencyCluster
 
         return VertexFrequencyCluster
+    if name == "Benchmarker":  # host-side helper of the reference package (meld/benchmark.py), lazy like the above
+        from .benchmark import Benchmarker
+
+        return Benchmarker
     raise AttributeError("module 'meld_amd' has no attribute {!r}".format(name))

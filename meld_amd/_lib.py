@@ -124,13 +124,14 @@ def get_lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MELD_HIP_LIB") or LIB_PATH  # (development: an alternative build of the same library)
+    if not os.path.exists(path):
         raise ImportError(
             "meld_amd: {} not found. The MI355X HIP extension is mandatory (there is no CPU "
             "fallback); build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `python -m meld_amd.build`.".format(LIB_PATH)
+            "or `python -m meld_amd.build`.".format(path)
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res

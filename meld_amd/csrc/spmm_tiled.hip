@@ -298,7 +298,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
         if constexpr (P == 2) pr1 = v * xv.v[1];
         asm volatile("" : "+v"(pr0_sink(pr0)), "+v"(pr0_sink(pr1)));
         const bool same = sl == srow;
-        if (!same && srow >= 0) {
+#ifndef PT_ABL
+#define PT_ABL 0
+#endif
+        if (!(PT_ABL & 1) && !same && srow >= 0) {
           lds_add(myacc + P * srow, s0);
           if constexpr (P == 2) lds_add(myacc + 2 * srow + 1, s1);
         }
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
           accumulate(h_act, h_v, h_sl, h_x);
           if (cur < t) advance(t);
           const double* pan = pans + (size_t)(t & (NB - 1)) * CP * P;
-          const int cl = ix & (CP - 1);
+          const int cl = (PT_ABL & 2) ? lane : (int)(ix & (CP - 1));
           const bool act = lane < n;
           V<P> xv;
           if constexpr (P == 1) {

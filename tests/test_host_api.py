@@ -12,7 +12,7 @@ def test_exports_match_reference_names():
     for name in ("MELD", "get_meld_cmap", "normalize_densities", "utils", "__version__"):
         assert hasattr(meld, name)
     assert meld.VertexFrequencyCluster.__name__ == "VertexFrequencyCluster"
-    assert not hasattr(meld, "Benchmarker")  # outside the path: deliberately not provided
+    assert meld.Benchmarker.__name__ == "Benchmarker"  # host-side helper, reference meld/__init__.py:3
 
 
 def test_constructor_defaults():
@@ -165,3 +165,46 @@ def test_vertex_frequency_cluster_argument_checks():
         vfc.predict()
     vfc.set_kmeans_params(n_clusters=4, n_init=3)
     assert vfc.n_clusters == 4 and vfc._sklearn_params == {"n_init": 3}
+
+
+# ---- Benchmarker (reference meld/benchmark.py, test/test_benchmark.py:34-58): host-side parts ------------------
+def test_benchmarker_messages():
+    b = meld.Benchmarker()
+    assert b.set_seed(0) == 0
+    with pytest.raises(ValueError, match="data_phate must have 3 dimensions"):
+        b.set_phate(np.random.normal(0, 2, (10, 2)))
+    with pytest.raises(ValueError, match=r"data_phate must be set prior to running generate_ground_truth_pdf\(\)."):
+        meld.Benchmarker().generate_ground_truth_pdf()
+    with pytest.raises(NameError, match="Must pass `data` unless graph has already been fit"):
+        meld.Benchmarker().calculate_MELD_likelihood()
+
+
+def test_benchmarker_ground_truth_follows_the_reference_draws():
+    """Same seed -> same pdf and labels as the reference's sequence of global-RNG draws (meld/benchmark.py:154-184),
+    restated here with scipy's zscore / expit."""
+    import scipy.special
+    import scipy.stats
+
+    rng = np.random.default_rng(3)
+    emb = rng.normal(1.0, 2.0, (500, 3))  # not centred: goes through the z-score
+    b = meld.Benchmarker(seed=7)
+    pdf = b.generate_ground_truth_pdf(emb)
+    b.generate_sample_labels()
+
+    z = scipy.stats.zscore(emb, axis=0)
+    np.random.seed(7)
+    w = np.sort(np.random.uniform(size=(2)))
+    w = np.diff(np.hstack([0, w, 1]))
+    np.random.shuffle(w)
+    want = scipy.special.expit(np.sum(z * w, axis=1))
+    np.testing.assert_allclose(pdf, want, rtol=1e-13)
+    np.random.seed(7)
+    ind = np.random.binomial(1, want)
+    assert np.array_equal(b.sample_indicator, ind)
+    assert np.array_equal(b.sample_labels, np.where(ind == 0, "ctrl", "expt"))
+    assert b.calculate_mse(want) < 1e-26
+    # an already centred embedding is kept as it is; one passed again replaces the stored one
+    b.set_phate(z)
+    assert b.data_phate is not None and np.allclose(b.data_phate, z)
+    b.set_phate(b.data_phate + 1)
+    np.testing.assert_allclose(b.data_phate.mean(axis=0), 0, atol=1e-12)
