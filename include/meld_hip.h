@@ -320,20 +320,24 @@ int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_
 int meld_axpby_f64(double a, const double* x, double b, double* y, int64_t n, double* nrm2,
                    meld_stream_t stream);
 
-/* ---- panel-tiled layout of W for the recurrence (csrc/spmm_tiled.hip) --------------------------
+/* ---- panel-tiled, symmetry-folded layout of W for the recurrence (csrc/spmm_tiled.hip) ----------
  * Same operator and same call sites as meld_cheby_step / meld_lanczos_* ([UPSTREAM pygsp cheby_op /
  * estimate_lmax] at reference meld/filter.py:59 / :39), on a copy of W laid out so that the iterate is
- * staged in LDS tile by tile instead of being gathered per nonzero: rows in nb nnz-balanced blocks (one
- * per CU), per block the sorted list of the distinct columns it touches cut into tiles of tile_cols
- * columns, the block's nonzeros re-ordered by (owner wave, tile, row, column).  Built once per graph.
+ * staged in LDS instead of being gathered per nonzero: rows in nb nnz-balanced blocks (one per CU); the
+ * nonzeros whose column lies inside the block's own row range are stored once per symmetric pair (IN
+ * part: 12 instead of 24 bytes per pair); the distinct columns outside it are listed, cut into tiles of
+ * tile_cols columns and staged through a ring of LDS buffers (OUT part); every consumer wave streams its
+ * own contiguous slice of the block in whole chunks of 64 entries.  Built once per graph.  The fold needs
+ * a bitwise symmetric W: the builder verifies it (status 5) and can be told not to fold.  Results are
+ * reproducible to rounding, not bit for bit (several waves add into one LDS accumulator).
  * All arrays are device memory owned by the caller:
  *   blk_row   [nb + 1]  int32   first row of every block
  *   blk_ntile [nb]      int32   tiles of the block (-1: the block could not be laid out, see status)
- *   blk_ndist [nb]      int32   distinct columns of the block
- *   seg       [meld_pt_seg_len(nb)] int32  per (block, wave, tile) entry offsets
- *   list_cols [nnz]     int32   block b's sorted distinct columns start at rowptr[blk_row[b]]
- *   pval      [nnz]     fp64    values in layout order   (+ optional pval32 [nnz] fp32, see the struct)
- *   pidx      [nnz]     uint32  tile-local column | row slot << log2(tile_cols)                   */
+ *   blk_ndist [nb]      int32   distinct OUT columns of the block
+ *   seg       [meld_pt_seg_len(nb)] int32  per (block, wave) chunk schedule and segment offsets
+ *   list_cols [nnz]     int32   block b's sorted distinct OUT columns start at rowptr[blk_row[b]]
+ *   pval      [meld_pt_stream_len(nnz, nb)] fp64  values in stream order (+ optional pval32, fp32, same length)
+ *   pidx      [meld_pt_stream_len(nnz, nb)] uint32  LDS offsets of the entry's column slot and row   */
 typedef struct meld_pt_layout {
   const int32_t* blk_row;
   const int32_t* blk_ntile;
@@ -343,22 +347,31 @@ typedef struct meld_pt_layout {
   const double* pval;
   const uint32_t* pidx;
   int32_t nb;
-  const float* pval32; /* optional [nnz]: pval rounded to fp32, streamed by the Lanczos SpMV of the lmax estimate
+  const float* pval32; /* optional: pval rounded to fp32, streamed by the Lanczos SpMV of the lmax estimate
                           (meld_pt_lanczos_*) instead of pval; NULL = not kept */
+  int64_t stream_len;  /* entries of pval / pidx / pval32 (= meld_pt_stream_len(nnz, nb)) */
+  const uint16_t* cdesc; /* [meld_pt_desc_len(nb)] chunk descriptors of every consumer wave's stream */
 } meld_pt_layout_t;
 int meld_pt_geometry(int* consumer_waves, int* rows_max, int* tile_cols, int* tiles_max);
 int meld_pt_num_blocks(int64_t n_rows); /* nb the builder wants for n_rows local rows */
 int64_t meld_pt_seg_len(int nb);
+int64_t meld_pt_stream_len(int64_t nnz, int nb);
+int64_t meld_pt_desc_len(int nb);
 /* timing-only ablations of the step kernel (tools/spmm_compare.py); results are wrong while mask != 0 */
 int meld_pt_debug_ablate(int mask);
+/* development: per-wave wall-clock stamps of the following step launches into buf[nb][16][8] (NULL: off) */
+int meld_pt_debug_stamps(unsigned long long* buf);
 /* Build the layout of the local rows [0, n_rows) of a CSR matrix with n_cols columns (the arrays of
- * `layout` are written).  status[1] (device) receives 0, or the reason the layout cannot be used:
+ * `layout` are written); local row r is column col_base + r of the matrix (0 on one GPU, the shard's first
+ * row on a row shard); symmetric != 0 folds the in-block pairs.  status[0] (device) receives 0, or the
+ * reason the layout cannot be used:
  * 1 = a block touches too many column panels, 2 = too many distinct columns in a block,
- * 3 = n_cols beyond the builder's index range, 4 = a (wave, tile) segment beyond 65535 entries -- the caller then stays on
- * meld_cheby_step. */
+ * 3 = n_cols beyond the builder's index range, 4 = a segment / a wave's pairs / its padding beyond the
+ * builder's ranges, 5 = W is not bitwise symmetric inside a block (build again with symmetric = 0),
+ * 6 = a diagonal entry -- the caller then stays on meld_cheby_step. */
 int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, int64_t n_rows, int64_t n_cols,
-                  const meld_pt_layout_t* layout, uint32_t* codes /* scratch, nnz entries */, int32_t* status,
-                  meld_stream_t stream);
+                  int64_t col_base, int symmetric, const meld_pt_layout_t* layout,
+                  uint32_t* codes /* scratch, nnz entries */, int32_t* status, meld_stream_t stream);
 /* meld_cheby_step on the layout (p = 1, 2 or any p as passes of 2 + 1 columns; dots as there). */
 int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
                        const double* x_full, int64_t x_row_offset, const double* z, double* y, double* r,

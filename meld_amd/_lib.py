@@ -89,7 +89,10 @@ SIGNATURES = {
     "meld_pt_num_blocks": (_i32, [_i64]),
     "meld_pt_seg_len": (_i64, [_i32]),
     "meld_pt_debug_ablate": (_i32, [_i32]),
-    "meld_pt_build": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "meld_pt_debug_stamps": (_i32, [_ptr]),
+    "meld_pt_stream_len": (_i64, [_i64, _i32]),
+    "meld_pt_desc_len": (_i64, [_i32]),
+    "meld_pt_build": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_pt_cheby_step": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr, _i64, _ptr, _ptr, _ptr, _f64, _f64, _f64, _f64, _ptr, _ptr]),
     "meld_pt_lanczos_steps": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
     "meld_pt_lanczos_spmv": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -109,7 +112,7 @@ class PtLayout(C.Structure):
     """``meld_pt_layout_t`` of include/meld_hip.h (device pointers of the panel-tiled copy of W)."""
 
     _fields_ = [("blk_row", _ptr), ("blk_ntile", _ptr), ("blk_ndist", _ptr), ("seg", _ptr), ("list_cols", _ptr),
-                ("pval", _ptr), ("pidx", _ptr), ("nb", C.c_int32), ("pval32", _ptr)]
+                ("pval", _ptr), ("pidx", _ptr), ("nb", C.c_int32), ("pval32", _ptr), ("stream_len", C.c_int64), ("cdesc", _ptr)]
 
 
 _lib = None

@@ -782,22 +782,31 @@ class HipOps:
 
         lib, dev = self.lib, G.val.device
         nb = int(lib.meld_pt_num_blocks(G.n_rows))
+        slen = int(lib.meld_pt_stream_len(G.nnz, nb))
         i32 = dict(dtype=torch.int32, device=dev)
         t = dict(
             blk_row=torch.empty(nb + 1, **i32), blk_ntile=torch.empty(nb, **i32), blk_ndist=torch.empty(nb, **i32),
             seg=torch.empty(int(lib.meld_pt_seg_len(nb)), **i32), list_cols=torch.empty(G.nnz, **i32),
-            pval=torch.empty(G.nnz, dtype=torch.float64, device=dev), pidx=torch.empty(G.nnz, **i32),
-            pval32=torch.empty(G.nnz, dtype=torch.float32, device=dev),  # fp32 values for the lmax estimate's SpMV
+            pval=torch.empty(slen, dtype=torch.float64, device=dev), pidx=torch.empty(slen, **i32),
+            pval32=torch.empty(slen, dtype=torch.float32, device=dev),  # fp32 values for the lmax estimate's SpMV
+            cdesc=torch.empty(int(lib.meld_pt_desc_len(nb)), dtype=torch.int16, device=dev),
         )
         status = torch.zeros(1, **i32)
         lay = PtLayout(*(t[k].data_ptr() for k in ("blk_row", "blk_ntile", "blk_ndist", "seg", "list_cols", "pval", "pidx")), nb,
-                       t["pval32"].data_ptr())
+                       t["pval32"].data_ptr(), slen, t["cdesc"].data_ptr())
         codes = torch.empty(G.nnz, **i32)  # scratch of the builder
-        with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
-            check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, C.byref(lay), ptr(codes), ptr(status),
-                                    _stream()), "meld_pt_build")
+        # in-block pairs are stored once (W symmetric); the builder verifies the symmetry of every block's own
+        # square and reports status 5 otherwise (a weight matrix uploaded from elsewhere): built again unfolded
+        fold = os.environ.get("MELD_SPMM_FOLD", "1") != "0"
+        for symmetric in ((1, 0) if fold else (0,)):
+            with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
+                check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, G.row_begin, symmetric,
+                                        C.byref(lay), ptr(codes), ptr(status), _stream()), "meld_pt_build")
+            st = int(status.item())
+            if st != 5:
+                break
         del codes
-        st = int(status.item())
+        G.info["spmm_fold"] = bool(symmetric) and st == 0
         if st != 0:  # cannot be laid out (see include/meld_hip.h): stay on the CSR-stream kernel
             G.info["spmm"] = "csr (tiled layout refused: status {})".format(st)
             return None

@@ -1,7 +1,7 @@
 """GPU tests of the panel-tiled recurrence kernel (csrc/spmm_tiled.hip): the same operator as the
 CSR-stream kernel, on the re-laid-out copy of W.  Checked against the oracle's pygsp-style loop
 ([UPSTREAM pygsp cheby_op], reference meld/filter.py:59), against the CSR-stream kernel on the same
-graph, for bit-reproducibility, and on the shapes the row-sharded driver produces (row offset,
+graph, for completeness of the layout and reproducibility, and on the shapes the row-sharded driver produces (row offset,
 padded column range, empty shard)."""
 import numpy as np
 import pytest
@@ -63,7 +63,7 @@ def test_tiled_recurrence_matches_oracle(cells5k, p):
 
 @pytest.mark.parametrize("n,density", [(3, 1.0), (70, 0.3), (257, 0.05), (4481, 0.004), (9000, 0.002), (40000, 0.0005)])
 def test_tiled_step_on_awkward_matrices(n, density):
-    """Tiny graphs, a block boundary inside the row range (4481 = RMAX + 1), empty rows, a dense row, rows longer
+    """Tiny graphs, a block boundary inside the row range (4481 > RMAX), empty rows, a dense row, rows longer
     than a wave; random symmetric sparsity instead of a kNN structure.  One step (y, r) and the p = 1 form
     with its dot products against a scipy evaluation, and against the CSR-stream kernel."""
     from meld_amd.graph import HipOps
@@ -111,9 +111,10 @@ def test_tiled_step_on_awkward_matrices(n, density):
         assert _rel(outs[0], outs[1]) < 1e-13
 
 
-def test_tiled_layout_is_a_permutation_of_the_csr_and_bit_reproducible():
-    """Every nonzero of W appears exactly once in the layout (decoded back through the column lists), and two
-    independent builds + runs give bit-identical results (fixed summation order)."""
+def test_tiled_layout_holds_every_nonzero_once_and_is_reproducible():
+    """Every nonzero of W appears exactly once in the layout -- OUT entries decoded back through the column lists, IN
+    pairs (stored once per symmetric pair) mirrored -- and two independent builds + runs agree to rounding (several
+    waves add into one LDS accumulator, so the order of the additions is not fixed: not bit for bit)."""
     import meld_amd
     from meld_amd.graph import HipOps
     from meld_amd._lib import get_lib
@@ -124,33 +125,60 @@ def test_tiled_layout_is_a_permutation_of_the_csr_and_bit_reproducible():
     G = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=15)
     G.ops = HipOps(spmm="tiled")
     pt = G.ops.pt_layout(G)
-    assert pt is not None
+    assert pt is not None and G.info["spmm_fold"] is True
     t = {k: v.cpu().numpy() for k, v in pt["tensors"].items()}
     nw, rmax, cp, tmax = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     get_lib().meld_pt_geometry(C.byref(nw), C.byref(rmax), C.byref(cp), C.byref(tmax))
-    nw, cp, segw = nw.value, cp.value, tmax.value + 1
+    nw, cp, rmax = nw.value, cp.value, rmax.value
+    slots, segw, segrows, padcap = rmax // nw, 64, 2 * (nw + 1), 64
     rowptr = G.rowptr.cpu().numpy()
     nb = pt["nb"]
     blk_row = t["blk_row"]
-    assert blk_row[0] == 0 and blk_row[nb] == G.n_rows and np.all(np.diff(blk_row) >= 0) and np.diff(blk_row).max() <= rmax.value
+    assert blk_row[0] == 0 and blk_row[nb] == G.n_rows and np.all(np.diff(blk_row) >= 0) and np.diff(blk_row).max() <= rmax
+    pidx = t["pidx"].view(np.uint32)
+
+    def row_of(slot):  # inverse of the kernel's row_slot()
+        return (slot % slots) * nw + slot // slots
+
     rows, cols, vals = [], [], []
+    n_pairs = 0
     for b in range(nb):
-        T, e0 = int(t["blk_ntile"][b]), int(rowptr[blk_row[b]])
+        segp = t["seg"][b * segrows * segw : (b + 1) * segrows * segw].reshape(segrows, segw)
+        T, e0, r0 = int(t["blk_ntile"][b]), int(rowptr[blk_row[b]]), int(blk_row[b])
+        assert segp[segrows - 1, 2] == r0 and segp[segrows - 1, 4] == T
         lst = t["list_cols"][e0 : e0 + int(t["blk_ndist"][b])]
         assert np.all(np.diff(lst) > 0)  # sorted distinct columns
-        seg = t["seg"][b * (nw + 1) * segw : (b + 1) * (nw + 1) * segw].reshape(nw + 1, segw)
+        base_b = e0 + b * nw * padcap
         for w in range(nw):
-            for tl in range(T):
-                s, e = int(seg[w, tl]), int(seg[w, tl + 1])
-                ix = t["pidx"][e0 + s : e0 + e].view(np.uint32)
-                cl, sl = (ix & (cp - 1)).astype(np.int64), (ix >> int(np.log2(cp))).astype(np.int64)
-                rows.append(blk_row[b] + sl * nw + w)
-                cols.append(lst[int(seg[nw, tl]) * cp + cl])  # row nw of seg: list chunk of the tl-th processed tile
-                vals.append(t["pval"][e0 + s : e0 + e])
+            hdr = int(np.uint32(segp[w, 62]))
+            n_in, soff = hdr & 0xFFFF, int(segp[w, 63])
+            eoff = segp[nw + 1 + w]
+            sb = base_b + soff
+            # IN pairs: whole chunks, padded with (0, 0) entries
+            ix, v = pidx[sb : sb + 64 * n_in], t["pval"][sb : sb + 64 * n_in]
+            keep = v != 0
+            ri, rj = row_of((ix[keep] >> 20).astype(np.int64)), row_of(((ix[keep] >> 4) & 0xFFF).astype(np.int64))
+            assert keep.sum() == eoff[62] and np.all(ri < rj) and np.all(ri % nw == w)
+            rows += [r0 + ri, r0 + rj]
+            cols += [r0 + rj, r0 + ri]
+            vals += [v[keep], v[keep]]
+            n_pairs += int(keep.sum())
+            # OUT entries: dense, tile by tile
+            for j in range(T):
+                s, e = sb + 64 * n_in + int(eoff[j]), sb + 64 * n_in + int(eoff[j + 1] if j + 1 < T else eoff[63])
+                ix = pidx[s:e]
+                cs = ((ix >> 4) & 0xFFF).astype(np.int64)
+                assert np.all(cs >> 10 == (j & 3))
+                rl = row_of((ix >> 20).astype(np.int64))
+                assert np.all(rl % nw == w)
+                rows.append(r0 + rl)
+                cols.append(lst[int(segp[nw, j]) * cp + (cs & (cp - 1))])  # row nw of seg: list chunk of the j-th processed tile
+                vals.append(t["pval"][s:e])
     M = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(G.n_rows, G.N))
     ref = sparse.csr_matrix((G.val.cpu().numpy(), G.col.cpu().numpy(), rowptr), shape=(G.n_rows, G.N))
     assert M.nnz == ref.nnz and abs(M - ref).max() == 0.0
-    # bit-reproducible
+    assert n_pairs > 0.1 * ref.nnz  # the fold is doing something on a kNN graph in locality order
+    # reproducible to rounding
     x = torch.rand(G.N, 2, dtype=torch.float64, device="cuda")
     ys = []
     for _ in range(2):
@@ -158,7 +186,36 @@ def test_tiled_layout_is_a_permutation_of_the_csr_and_bit_reproducible():
         y = torch.empty_like(x)
         G.ops.cheby_step(G, 2, x, 0, None, y, None, 1.0, 0.0, 0.0, 0.0)
         ys.append(y.cpu().numpy().copy())
-    assert np.array_equal(ys[0], ys[1])
+    assert _rel(ys[0], ys[1]) < 1e-14
+
+
+def test_a_weight_matrix_that_is_not_symmetric_is_not_folded():
+    """The fold stores one value per in-block pair: a W whose two halves differ (uploaded from elsewhere) must be
+    detected by the builder's symmetry check and laid out unfolded -- same results as the CSR-stream kernel."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    A = sparse.random(n, n, density=0.01, random_state=3, format="csr", dtype=np.float64)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.data = rng.random(A.nnz) + 0.1
+    S = (A + A.T).tocsr()  # symmetric pattern ...
+    S.data = rng.random(S.nnz) + 0.1  # ... with unrelated values in the two halves
+    S.sort_indices()
+    Gt, Gc = _graph_pair(S)
+    x = rng.normal(size=(n, 2))
+    outs = []
+    for G in (Gt, Gc):
+        y = torch.empty(n, 2, dtype=torch.float64, device="cuda")
+        G.ops.cheby_step(G, 2, torch.from_numpy(x).cuda(), 0, None, y, None, 1.0, 0.0, 0.0, 0.0)
+        outs.append(y.cpu().numpy())
+    assert Gt.info["spmm"] == "tiled" and Gt.info["spmm_fold"] is False
+    ref = np.ravel(S.sum(1))[:, None] * x - S @ x
+    assert _rel(outs[0], ref) < 1e-13 and _rel(outs[1], ref) < 1e-13
+    # the symmetric matrix with the same pattern is folded
+    Gs, _ = _graph_pair(((S + S.T) * 0.5).tocsr())
+    y = torch.empty(n, 2, dtype=torch.float64, device="cuda")
+    Gs.ops.cheby_step(Gs, 2, torch.from_numpy(x).cuda(), 0, None, y, None, 1.0, 0.0, 0.0, 0.0)
+    assert Gs.info["spmm_fold"] is True
 
 
 def test_tiled_kernel_on_a_row_shard():

@@ -38,6 +38,7 @@ def timed(fn, reps):
     return min(ts), float(np.median(ts))
 
 
+from meld_amd._lib import get_lib
 res = {}
 MASK = int(os.environ.get("PT_MASK", "0"))  # timing-only ablation mask of meld_pt_debug_ablate (results wrong)
 for mode in ("csr", "tiled"):
@@ -69,3 +70,10 @@ for mode in ("csr", "tiled"):
             err = np.abs(res[("tiled", pp)] - res[("csr", pp)]).max() / np.abs(res[("csr", pp)]).max()
             print("%-28s %s p=%d: best %.1f us median %.1f us  frac(best) %.3f  max rel diff vs csr %.1e"
                   % (tag, G.info.get("spmm"), pp, best, med, byts / best / 1e3 / 8000, err), flush=True)
+
+# the Lanczos SpMV of the lmax estimate (p = 1, fp32 copy of the values, scalars from device memory)
+state = torch.zeros(8, dtype=torch.float64, device="cuda"); state[3], state[4] = 0.5, -0.25
+dots = torch.zeros(2 * G.ops.dot_slots(), dtype=torch.float64, device="cuda")
+x1 = torch.rand(n, dtype=torch.float64, device="cuda"); z1 = torch.rand(n, dtype=torch.float64, device="cuda"); y1 = torch.empty_like(x1)
+best, med = timed(lambda: G.ops.lanczos_spmv(G, x1, z1, y1, state, dots), reps)
+print("%-28s lanczos spmv (p=1, fp32 values): best %.1f us median %.1f us" % (tag, best, med), flush=True)
