@@ -152,6 +152,22 @@ __device__ __forceinline__ void lds_add(char* lds, unsigned off, double v) {
 constexpr int U = 8;  // entry chunks (64 nonzeros each) in flight per consumer wave
 static_assert(U == 8, "the consumer stream names its 8 slots (v96..v119) and waits with vmcnt(2 (U - 1))");
 
+// Wave-uniform read-only words (chunk descriptors, schedule headers) are read through the constant address space: the
+// compiler then issues SCALAR loads for them whatever stores the kernel makes elsewhere (a vector load in the consumer
+// loop would break the hand-counted vmcnt of the entry stream).  The layout is never written by the step kernels.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4* const_u4_ptr;
+typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
+__device__ __forceinline__ uint4 load_u4_const(const void* p) {
+  const u32x4 t = *(const_u4_ptr)(uintptr_t)p;
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ int4 load_i4_const(const void* p) {
+  const u32x4 t = *(const_u4_ptr)(uintptr_t)p;
+  return make_int4((int)t.x, (int)t.y, (int)t.z, (int)t.w);
+}
+__device__ __forceinline__ int32_t load_i32_const(const void* p) { return *(const_i32_ptr)(uintptr_t)p; }
+
 // LDS words shared by the waves of a workgroup, polled / bumped with plain LDS operations (the CU's LDS is
 // coherent for its own waves; a wave's LDS operations complete in order)
 __device__ __forceinline__ int lds_peek(const int* p) {
@@ -178,7 +194,7 @@ __device__ __forceinline__ unsigned long long* symsum_of(int32_t* seg, int b) {
 // sums stay fp64.  Only the Lanczos SpMV of the lmax estimate uses it: rounding W to fp32 moves the largest
 // eigenvalue by < 1e-7 relative, far inside the tolerance that estimate is computed to (and the 1.01 factor on it).
 template <int P, bool F32>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void pt_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void pt_step_kernel(StepArgs a) {
   // LDS map (bytes): [0, 64 Ki) accumulators, row rl of the block at row_slot(rl) * 16;  [64 Ki, 128 Ki) the iterate: first
   // the block's own rows (IN part), then the ring of NB staged tiles (OUT part), column slot c at 64 Ki + c * 16
   // -- no static LDS: the dynamic block starts at LDS address 0, so the fields of an index word ARE addresses --
@@ -206,6 +222,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   if (b >= a.nb) return;  // padding workgroup (whole workgroup leaves: no barrier is left hanging)
 
   double alpha = a.alpha, gamma = a.gamma;
+  const double beta = a.beta, coef = a.coef;
   if (a.coef_dev != nullptr) {  // device-resident Lanczos: scalars written by the previous iteration
     alpha = a.coef_dev[3];
     gamma = a.coef_dev[4];
@@ -218,8 +235,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   // the block's header words (one scalar load instead of a chain of dependent ones: first row, rows, tiles, distinct
   // OUT columns, CSR offset of the first row) sit behind the symmetry sum in the block's last segment row
   const int32_t* segb = a.seg + (size_t)b * SEGROWS * SEGW;
-  const int4 hw0 = *reinterpret_cast<const int4*>(segb + (SEGROWS - 1) * SEGW);
-  const int4 hw1 = *reinterpret_cast<const int4*>(segb + (SEGROWS - 1) * SEGW + 4);
+  const int4 hw0 = load_i4_const(segb + (SEGROWS - 1) * SEGW);
+  const int4 hw1 = load_i4_const(segb + (SEGROWS - 1) * SEGW + 4);
   const int row0 = __builtin_amdgcn_readfirstlane(hw0.z);
   const int nrows = __builtin_amdgcn_readfirstlane(hw0.w);
   if (nrows == 0) return;  // (uniform) an empty block has nothing to stage, accumulate or write
@@ -233,7 +250,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   // The entry stream keeps U chunks (64 entries each) in flight per wave with wait counts placed by hand: hipcc's
   // wait-count pass forgets the order of loads pending over a loop's back edge and drains the queue every round.
   // The loads are issued from inline asm into PHYSICAL registers the compiler does not own (the kernel is limited to
-  // v0..v95 by amdgpu_num_vgpr, the asm names v96..v119: values v[96 + 2u : 97 + 2u], index words v[112 + u]) -- a
+  // v0..v95 by amdgpu_num_vgpr(48) -- on gfx90a and later the attribute counts the unified file, i.e. its value is
+  // doubled -- and the asm names v96..v119: values v[96 + 2u : 97 + 2u], index words v[112 + u]) -- a
   // register with a load in flight must never be copied and the allocator copies asm operands freely.  Loads return
   // in order and every slot is re-issued right after it has been read, so when chunk k is wanted exactly 2 (U - 1)
   // younger loads are in flight: s_waitcnt vmcnt(14).  Past the end of a wave's stream the loads read the next
@@ -307,6 +325,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     return (int)((wd >> ((u & 1) * 16)) & 0xFFFFu);
   };
 
+  const double* xs = a.x_full;
+  const double* zs = a.z;
+  double* ys = a.y;
   int n_in = 0, K = 0;
   const double* pv = nullptr;
   const float* pv32 = nullptr;
@@ -316,16 +337,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   int eo = 0;                                   // entry offset of the next chunk to request
   if (w < NW) {
     // header words of the wave's schedule: [62] IN chunks | all chunks << 16, [63] the wave's offset in the block's stream
-    const int hdr = segb[w * SEGW + 62];
-    const int soff = segb[w * SEGW + 63];
+    const int hdr = load_i32_const(segb + w * SEGW + 62);
+    const int soff = load_i32_const(segb + w * SEGW + 63);
     n_in = __builtin_amdgcn_readfirstlane(hdr & 0xFFFF);
     K = __builtin_amdgcn_readfirstlane((int)((unsigned)hdr >> 16));
     pv = a.pval + ebase + soff;
     pv32 = a.pval32 + ebase + soff;
     pi = a.pidx + ebase + soff;
     cd = a.cdesc + ((size_t)b * NW + w) * (KMAX + KSLACK);
-    dA = *reinterpret_cast<const uint4*>(cd);
-    dB = *reinterpret_cast<const uint4*>(cd + U);
+    dA = load_u4_const(cd);
+    dB = load_u4_const(cd + U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       issue(u, pv + eo, pv32 + eo, pi + eo);
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   // ---- all waves: accumulators to zero, the block's own rows of the iterate into LDS -----------------------------
   for (int i = tid; i < RPAD * STRIDE / 16; i += THREADS) *reinterpret_cast<double2*>(lds + i * 16) = make_double2(0.0, 0.0);
   for (int i = tid; i < nrows; i += THREADS)
-    lds_put<P>(lds, XBASE + row_slot(i) * STRIDE, ldg<P>(a.x_full, a.x_row_offset + row0 + i, a.ld, a.colofs));
+    lds_put<P>(lds, XBASE + row_slot(i) * STRIDE, ldg<P>(xs, a.x_row_offset + row0 + i, a.ld, a.colofs));
   if (tid < NB) {
     s_prod[tid] = 0;
     s_cons[tid] = 0;
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
       }
     };
     for (int k0 = 0; k0 < K; k0 += U) {
-      const uint4 dC = *reinterpret_cast<const uint4*>(cd + k0 + 2 * U);  // (KSLACK zero descriptors follow the last one)
+      const uint4 dC = load_u4_const(cd + k0 + 2 * U);  // (KSLACK zero descriptors follow the last one)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = k0 + u;
@@ -455,7 +476,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
     };
     auto gather = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < PER; ++k) xv[k] = ldg<P>(a.x_full, (ab & 8) ? (col[k] & 1023) : col[k], a.ld, a.colofs);
+      for (int k = 0; k < PER; ++k) xv[k] = ldg<P>(xs, (ab & 8) ? (col[k] & 1023) : col[k], a.ld, a.colofs);
     };
     if (lw < T && !(ab & 4)) {
       load_list(lw);
@@ -494,11 +515,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
   for (int q = 0; q < NR; ++q) {
     const int rl = min(tid + q * THREADS, max(nrows - 1, 0));
     const int64_t row = row0 + rl;
-    xl[q] = ldg<P>(a.x_full, a.x_row_offset + row, a.ld, a.colofs);
+    xl[q] = ldg<P>(xs, a.x_row_offset + row, a.ld, a.colofs);
     dwi[q] = a.dw[row];
 #pragma unroll
     for (int c = 0; c < P; ++c) zl[q].v[c] = rl_[q].v[c] = 0.0;
-    if (gamma != 0.0) zl[q] = ldg<P>(a.z, row, a.ld, a.colofs);
+    if (gamma != 0.0) zl[q] = ldg<P>(zs, row, a.ld, a.colofs);
     if (a.r != nullptr) rl_[q] = ldg<P>(a.r, row, a.ld, a.colofs);
   }
   stamp(5);
@@ -516,12 +537,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(96))) void 
 #pragma unroll
       for (int c = 0; c < P; ++c) {
         const double lx = dwi[q] * xl[q].v[c] - ap.v[c];  // (L x)_i
-        yv.v[c] = alpha * lx + a.beta * xl[q].v[c] + gamma * zl[q].v[c];
-        rl_[q].v[c] += a.coef * yv.v[c];
+        yv.v[c] = alpha * lx + beta * xl[q].v[c] + gamma * zl[q].v[c];
+        rl_[q].v[c] += coef * yv.v[c];
         d_yx += yv.v[c] * xl[q].v[c];
         d_yy += yv.v[c] * yv.v[c];
       }
-      stg<P>(a.y, row, a.ld, a.colofs, yv);
+      stg<P>(ys, row, a.ld, a.colofs, yv);
       if (a.r != nullptr) stg<P>(a.r, row, a.ld, a.colofs, rl_[q]);
     }
   }

@@ -319,3 +319,4 @@ def test_graphs_the_layout_refuses_stay_on_the_csr_kernel():
     assert G.info["spmm"].startswith("csr (tiled layout refused")
     ref = np.ravel(W.sum(1))[:, None] * x - W @ x
     assert _rel(y.cpu().numpy(), ref) < 1e-13
+

@@ -87,7 +87,7 @@ def test_recurrence_kernel_keeps_its_stream_slots_to_itself():
                 for bi, i0 in enumerate(starts):
                     i1 = starts[bi + 1] if bi + 1 < len(starts) else len(lines)
                     label = lines[i0]
-                    in_loop = ("Header=" + header) in label or ("Loop " + header) in label or label.startswith(".L" + header + ":")
+                    in_loop = re.search(r"(Header=|Loop |^\.L)" + header + r"\b", label) is not None
                     if not in_loop and not any(i in wait_set for i in range(i0, i1)):
                         continue
                     inside = False

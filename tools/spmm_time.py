@@ -77,3 +77,4 @@ dots = torch.zeros(2 * G.ops.dot_slots(), dtype=torch.float64, device="cuda")
 x1 = torch.rand(n, dtype=torch.float64, device="cuda"); z1 = torch.rand(n, dtype=torch.float64, device="cuda"); y1 = torch.empty_like(x1)
 best, med = timed(lambda: G.ops.lanczos_spmv(G, x1, z1, y1, state, dots), reps)
 print("%-28s lanczos spmv (p=1, fp32 values): best %.1f us median %.1f us" % (tag, best, med), flush=True)
+
