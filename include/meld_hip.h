@@ -404,10 +404,7 @@ int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, 
  * starting at the row with the smallest first coordinate: rank[g][i] = position of row i along the chain
  * (orders the centroids of the locality permutation so that consecutive groups are close in space). */
 int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream);
-/* out[g][:] = mean of the rows X[order[start[g] .. start[g + 1])] (n_seg segments; an empty one keeps what out[g] held):
- * the centroid update of a Lloyd step on the leaves of the ordering tree. */
-int meld_segment_means(const double* X, int64_t N, int d, const int64_t* order, const int64_t* start, int64_t n_seg,
-                       double* out, meld_stream_t stream);
+
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */

@@ -103,7 +103,6 @@ SIGNATURES = {
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
-    "meld_segment_means": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _ptr]),
 }
 
 

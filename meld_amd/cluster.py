@@ -73,20 +73,47 @@ def _lloyd_step(Y, C, lab, scratch):
     return newC, scratch["in"].sum()
 
 
+def _lloyd_step_library(Y, C, lab):
+    """``_lloyd_step`` for shapes beyond the HIP kernel (d > 32 or k > 64): chunked distance GEMMs, argmin (ties to the
+    lowest index), index_add for the sums -- same outputs."""
+    n, d = Y.shape
+    k = C.shape[0]
+    c2 = (C * C).sum(1)
+    sums = torch.zeros(k, d, dtype=Y.dtype, device=Y.device)
+    cnt = torch.zeros(k, dtype=Y.dtype, device=Y.device)
+    inertia = torch.zeros((), dtype=Y.dtype, device=Y.device)
+    for lo in range(0, n, 1 << 18):
+        Yc = Y[lo : lo + (1 << 18)]
+        d2 = (Yc * Yc).sum(1)[:, None] + c2[None, :] - 2.0 * (Yc @ C.T)
+        best, idx = torch.min(d2, dim=1)
+        lab[lo : lo + Yc.shape[0]] = idx.to(lab.dtype)
+        sums.index_add_(0, idx, Yc)
+        cnt.index_add_(0, idx, torch.ones_like(best))
+        inertia = inertia + best.clamp_(min=0.0).sum()
+    newC = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1.0)[:, None], C)
+    return newC, inertia
+
+
 def _kmeans(Y, k, n_init=10, max_iter=300, tol=1e-4, seed=None):
     """Seeded k-means++ initialisation + Lloyd iterations on the device; best inertia of ``n_init``
     runs (sklearn's ``KMeans`` defaults; its relative tolerance is on the centre shift).  The Lloyd step is
-    the HIP kernel of ``csrc/kmeans.hip`` (d <= 32, k <= 64: what PCA(n_clusters) hands over)."""
+    the HIP kernel of ``csrc/kmeans.hip`` for d <= 32, k <= 64 (what PCA(n_clusters) hands over for up to 32 clusters),
+    library kernels beyond."""
     from ._lib import get_lib
 
     Y = Y.contiguous()
     n, d = Y.shape
-    if d > 32 or k > 64 or not Y.is_cuda:
-        raise NotImplementedError("KMeans on the device is built for d <= 32 features and k <= 64 clusters, got d={}, k={}".format(d, k))
-    nb = int(min(get_lib().meld_kmeans_max_blocks(), max(1, (n + 255) // 256)))
-    scratch = dict(nb=nb, sum=torch.empty(nb * k * d, dtype=torch.float64, device=Y.device),
-                   cnt=torch.empty(nb * k, dtype=torch.float64, device=Y.device),
-                   **{"in": torch.empty(nb, dtype=torch.float64, device=Y.device)})
+    if not Y.is_cuda:
+        raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+    if d > 32 or k > 64:
+        # beyond what csrc/kmeans.hip stages in LDS (VertexFrequencyCluster(n_clusters > 32): PCA hands over n_clusters
+        # features): the same Lloyd step on library kernels (rocBLAS distance GEMM + index_add), any d and k
+        scratch = None
+    else:
+        nb = int(min(get_lib().meld_kmeans_max_blocks(), max(1, (n + 255) // 256)))
+        scratch = dict(nb=nb, sum=torch.empty(nb * k * d, dtype=torch.float64, device=Y.device),
+                       cnt=torch.empty(nb * k, dtype=torch.float64, device=Y.device),
+                       **{"in": torch.empty(nb, dtype=torch.float64, device=Y.device)})
     lab = torch.empty(n, dtype=torch.int32, device=Y.device)
     gen = torch.Generator(device=Y.device)
     gen.manual_seed(0 if seed is None else int(seed))
@@ -105,12 +132,12 @@ def _kmeans(Y, k, n_init=10, max_iter=300, tol=1e-4, seed=None):
             d2 = torch.minimum(d2, ((Y - C[-1]) ** 2).sum(1))
         C = torch.stack(C).contiguous()
         for _it in range(max_iter):
-            newC, _ = _lloyd_step(Y, C, lab, scratch)
+            newC, _ = _lloyd_step(Y, C, lab, scratch) if scratch is not None else _lloyd_step_library(Y, C, lab)
             shift = ((newC - C) ** 2).sum()
             C = newC.contiguous()
             if (_it & 7) == 7 and float(shift) <= var_tol:  # one host sync per 8 iterations
                 break
-        _, inertia = _lloyd_step(Y, C, lab, scratch)
+        _, inertia = _lloyd_step(Y, C, lab, scratch) if scratch is not None else _lloyd_step_library(Y, C, lab)
         inertia = float(inertia)
         if best is None or inertia < best[0]:
             best = (inertia, lab.to(torch.int64).clone())

@@ -279,38 +279,6 @@ extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const doub
   return MELD_OK;
 }
 
-namespace meld {
-// mean of the cells of every segment: segment g = cells order[start[g] .. start[g + 1]) (one wave per segment, a lane per
-// coordinate -- a cell's row is one coalesced read); an empty segment keeps what out[g] held
-__global__ __launch_bounds__(256) void segment_means_kernel(const double* __restrict__ X, int d, const int64_t* __restrict__ order,
-                                                            const int64_t* __restrict__ start, int64_t n_seg,
-                                                            double* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= n_seg) return;
-  const int64_t a = start[g], b = start[g + 1];
-  if (b <= a) return;
-  for (int k0 = 0; k0 < d; k0 += 64) {
-    const int k = k0 + lane;
-    double acc = 0.0;
-    for (int64_t c = a; c < b; ++c) {
-      const int64_t i = order[c];
-      if (k < d) acc += X[i * d + k];
-    }
-    if (k < d) out[g * d + k] = acc / (double)(b - a);
-  }
-}
-}  // namespace meld
-
-extern "C" int meld_segment_means(const double* X, int64_t N, int d, const int64_t* order, const int64_t* start, int64_t n_seg,
-                                  double* out, meld_stream_t stream) {
-  MELD_CHECK_ARG(X && order && start && out && N > 0 && d > 0 && n_seg > 0, "meld_segment_means: bad arguments");
-  hipLaunchKernelGGL(meld::segment_means_kernel, dim3((unsigned)ceil_div(n_seg, 4)), dim3(256), 0, S(stream), X, d, order, start,
-                     n_seg, out);
-  MELD_LAUNCH_CHECK("segment_means_kernel");
-  return MELD_OK;
-}
-
 extern "C" int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream) {
   MELD_CHECK_ARG(P && rank && n_groups > 0 && m >= 1 && m <= 64 && d > 0, "meld_chain_order: bad arguments (1 <= m <= 64)");
   hipLaunchKernelGGL(chain_order_kernel, dim3((unsigned)n_groups), dim3(64), 0, S(stream), P, m, d, rank);

@@ -180,8 +180,9 @@ class DeviceGraph:
     @lmax.setter
     def lmax(self, value):
         self._lmax = None if value is None else float(value)
+        self.lmax_info = {} if value is None else dict(method="injected")
 
-    def estimate_lmax(self, recompute=False, tol=1e-3, max_iter=300, method="lanczos"):
+    def estimate_lmax(self, recompute=False, tol=1e-3, max_iter=300, method=None):
         """Largest Laplacian eigenvalue x 1.01 (pygsp's safety factor, [UPSTREAM pygsp
         ``Graph.estimate_lmax``] at reference ``meld/filter.py:39``).  pygsp stops ARPACK at
         tol=5e-3, which makes its value run-to-run noisy at the 1e-4 level; here a Lanczos
@@ -192,7 +193,12 @@ class DeviceGraph:
         the weights (vectors and sums fp64): that moves the eigenvalue by < 1e-7 relative.  No-op when a value is
         already set (same as pygsp), which is how parity tests inject a common lmax."""
         if self._lmax is not None and not recompute:
-            return self._lmax
+            # a value that is already there is kept (pygsp's no-op) -- unless it came from the OTHER estimator: asking for
+            # the reference's ARPACK number after a Lanczos estimate (or the reverse) computes it
+            have = self.lmax_info.get("method", "injected")
+            if method is None or have == "injected" or have == method:
+                return self._lmax
+        method = method or "lanczos"
         if method == "arpack":
             return self._estimate_lmax_arpack()
         if method != "lanczos":
@@ -201,7 +207,7 @@ class DeviceGraph:
 
         lam, info = lanczos_lmax(self, tol=tol, max_iter=max_iter)
         self._lmax = 1.01 * lam
-        self.lmax_info = info
+        self.lmax_info = dict(info, method="lanczos")
         return self._lmax
 
     def _estimate_lmax_arpack(self):
@@ -282,6 +288,60 @@ class DeviceGraph:
         if getattr(self, "_kdiag", None) is not None:  # dense graph: the diagonal was computed explicitly
             return (self.W + sparse.diags(self._vec_host(self._kdiag), 0)).tocsr()
         return (self.W + sparse.diags(self._vec_host(self.kernel_diagonal()), 0)).tocsr()
+
+    # -- what the reference's side paths read from the graph: graphtools' ``knn`` / ``diff_op``
+    # (reference meld/cluster.py:213, comparison/comparison.py:318-323), pygsp's Fourier basis (meld/cluster.py:235-236) --
+    @property
+    def knn(self):
+        """The ``knn`` the graph was built with (graphtools' attribute; None for a weight matrix uploaded from elsewhere)."""
+        return self.info.get("knn")
+
+    @property
+    def diff_op(self):
+        """graphtools' diffusion operator: the kernel (diagonal included) with rows normalised to sum 1, as scipy CSR in
+        the caller's cell order (built on first use, on the host: an inspection / side-path export like ``K``)."""
+        if getattr(self, "_diff_op", None) is None:
+            from scipy import sparse
+
+            K = self.K
+            self._diff_op = (sparse.diags(1.0 / np.ravel(K.sum(1)), 0) @ K).tocsr()
+        return self._diff_op
+
+    FOURIER_MAX_N = 16384
+
+    def compute_fourier_basis(self, recompute=False):
+        """pygsp's ``compute_fourier_basis``: full eigendecomposition of the combinatorial Laplacian -- ``e`` ascending,
+        ``U`` the eigenvectors (columns), both host arrays in the caller's cell order; also sets ``lmax = e[-1]`` like
+        pygsp.  Dense O(N^3) on the device (rocSOLVER ``eigh``), offered up to FOURIER_MAX_N cells."""
+        if getattr(self, "_U", None) is not None and not recompute:
+            return
+        if self.n_rows != self.N:
+            raise ValueError("the Fourier basis is only defined for an unsharded graph")
+        if self.N > self.FOURIER_MAX_N:
+            raise NotImplementedError("compute_fourier_basis is a dense O(N^3) eigendecomposition; N={} exceeds the {} cells "
+                                      "it is offered for".format(self.N, self.FOURIER_MAX_N))
+        n, dev = self.N, self.val.device
+        row_of = torch.repeat_interleave(torch.arange(n, device=dev), self.rowptr[1:] - self.rowptr[:-1])
+        L = torch.zeros(n, n, dtype=torch.float64, device=dev)
+        L[row_of, self.col.to(torch.int64)] = -self.val
+        L += torch.diag(self.dw_dev[:n])
+        e, U = torch.linalg.eigh(L)
+        e, U = e.cpu().numpy(), U.cpu().numpy()
+        inv = self._inv_perm_host()
+        if inv is not None:
+            U = U[inv]
+        self._e, self._U = e, U
+        self.lmax = float(e[-1])
+
+    @property
+    def U(self):
+        self.compute_fourier_basis()
+        return self._U
+
+    @property
+    def e(self):
+        self.compute_fourier_basis()
+        return self._e
 
     @property
     def landmark_op(self):
@@ -714,9 +774,13 @@ class HipOps:
         ``MELD_ASSEMBLE=sort`` -- by a global radix sort + reduce-by-key."""
         lib, st, dev = self.lib, _stream(), keys.device
         n = int(keys.shape[0])
-        if n > 0 and n_rows > 0 and os.environ.get("MELD_ASSEMBLE", "bucket") != "sort":
+        B = int(lib.meld_csr_bucket_slots())
+        # the buckets cost 12 B x B slots per row whatever the degree (3 KB per row: 3 GB at 1M rows): above a quarter of
+        # the free memory -- very large or tightly sharded runs -- the sort path (32 B per entry) is taken instead
+        bucket_bytes = n_rows * B * 12
+        fits = bucket_bytes <= torch.cuda.mem_get_info(dev)[0] // 4 if n_rows > 0 else True
+        if n > 0 and n_rows > 0 and fits and os.environ.get("MELD_ASSEMBLE", "bucket") != "sort":
             i32 = dict(dtype=torch.int32, device=dev)
-            B = int(lib.meld_csr_bucket_slots())
             cursor = torch.empty(n_rows, **i32)
             tcol = torch.empty(n_rows * B, **i32)
             tval = torch.empty(n_rows * B, dtype=torch.float64, device=dev)
@@ -763,7 +827,50 @@ class HipOps:
     # ---- panel-tiled copy of W for the recurrence (csrc/spmm_tiled.hip) -----------------------------
     PT_MIN_ROWS = 65536  # below this the CSR-stream kernel is launch-bound anyway and the layout does not pay
 
-    def pt_layout(self, G):
+    _pt_selfcheck = {"done": False, "ok": True}
+
+    @classmethod
+    def _pt_self_check(cls):
+        """Once per process, before the tiled recurrence kernel is trusted: one step on a small random symmetric matrix
+        through both kernels.  The tiled kernel keeps loads in flight in registers it names itself and counts its waits
+        by hand; a toolchain that broke those assumptions would return stale data, not an error -- a mismatch here keeps
+        every graph on the CSR-stream kernel (and says so)."""
+        st = cls._pt_selfcheck
+        if st["done"]:
+            return st["ok"]
+        st["done"] = True
+        from scipy import sparse
+
+        rng = np.random.default_rng(0)
+        n = 6000
+        A = sparse.random(n, n, density=20.0 / n, random_state=0, format="csr", dtype=np.float64)
+        A.data = rng.random(A.nnz) + 0.1
+        W = ((A + A.T) * 0.5).tocsr()
+        W.setdiag(0)
+        W.eliminate_zeros()
+        W.sort_indices()
+        outs = []
+        for mode in ("tiled", "csr"):
+            G = DeviceGraph.from_scipy(W)
+            ops = HipOps(spmm=mode)
+            if mode == "tiled" and ops.pt_layout(G, _checking=True) is None:
+                st["ok"] = False
+                break
+            x = torch.from_numpy(rng.random((n, 3))).cuda() if not outs else outs[0][1]
+            y = torch.empty_like(x)
+            ops.cheby_step(G, 3, x, 0, x, y, None, 0.7, -0.2, -1.0, 0.0)
+            outs.append((y, x))
+        if st["ok"]:
+            err = float((outs[0][0] - outs[1][0]).abs().max() / outs[1][0].abs().max())
+            st["ok"] = err < 1e-12
+        if not st["ok"]:
+            import warnings
+
+            warnings.warn("meld_amd: the panel-tiled recurrence kernel failed its self-check against the CSR-stream kernel; "
+                          "every graph stays on the CSR-stream kernel", RuntimeWarning)
+        return st["ok"]
+
+    def pt_layout(self, G, _checking=False):
         """The panel-tiled layout of ``G``'s local rows, built on first use and kept on the graph
         (``G.pt``); None when the graph stays on the CSR-stream kernel (small graphs, ``spmm="csr"``, or a
         graph the builder cannot lay out -- recorded in ``G.info["spmm"]``)."""
@@ -776,6 +883,9 @@ class HipOps:
         if mode == "csr" or G.n_rows == 0 or G.nnz == 0 or not G.val.is_cuda:
             return None
         if mode == "auto" and G.n_rows < self.PT_MIN_ROWS:
+            return None
+        if not _checking and not self._pt_self_check():
+            G.info["spmm"] = "csr (tiled kernel failed its self-check)"
             return None
         from ._lib import PtLayout
         import ctypes as C

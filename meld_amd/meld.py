@@ -106,6 +106,8 @@ class MELD(GraphEstimator):
         if "lmax" in params:
             self._lmax_override = params.pop("lmax")
             self._reset_filter()
+            if self.graph is not None and hasattr(self.graph, "lmax_info"):
+                self.graph.lmax = None  # whatever bound the graph carries came from the previous setting
         return super().set_params(**params)
 
     # -- graph construction (replaces graphtools.Graph(...), reference meld/meld.py:117-118,273) ----

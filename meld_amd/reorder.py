@@ -54,7 +54,7 @@ def _chain_order(P):
     return _chain_order_batched(P[None])[0]
 
 
-def _split_level(X, lib, st, group, n_groups, fanout, lloyd=0):
+def _split_level(X, lib, st, group, n_groups, fanout):
     """One refinement level: every group of cells gets `fanout` sub-centroids (evenly spaced
     members), every cell its nearest one.  Returns (child id within group [N] int64, rank of each
     child along its group's chain [n_groups, fanout])."""
@@ -70,14 +70,6 @@ def _split_level(X, lib, st, group, n_groups, fanout, lloyd=0):
     child = torch.empty(N, dtype=torch.int32, device=dev)
     g32 = group.to(torch.int32)
     check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
-    for _ in range(lloyd):
-        # Lloyd step: sub-centroids = means of their cells (cells sorted by leaf, one wave per leaf), cells re-assigned
-        leaf = group * fanout + child.to(torch.int64)
-        n_leaf = n_groups * fanout
-        order2 = _argsort_bits(leaf, int(n_leaf - 1).bit_length())
-        start = torch.searchsorted(leaf.index_select(0, order2), torch.arange(n_leaf + 1, device=dev, dtype=torch.int64))
-        check(lib.meld_segment_means(ptr(X), N, d, ptr(order2), ptr(start), n_leaf, ptr(cents), st), "meld_segment_means")
-        check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
     rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
     return child.to(torch.int64), rank
 
@@ -102,8 +94,6 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0):
         c1, fanouts = parts[0], tuple(parts[1:])
     st = torch.cuda.current_stream().cuda_stream
     dev = X.device
-    lloyd = int(os.environ.get("MELD_REORDER_LLOYD", "0"))          # Lloyd steps per level (tuning hook)
-    lloyd_all = os.environ.get("MELD_REORDER_LLOYD_ALL", "1") != "0"  # ... on every level, or on the last one only
     if c1 is None:
         c1 = int(min(64, max(8, N // 4096)))
     if fanouts is None:
@@ -124,7 +114,7 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0):
     for f in fanouts:
         if N // (n_groups * f) < 4:
             break
-        child, rank = _split_level(X, lib, st, group, n_groups, f, lloyd=lloyd if (lloyd_all or f is fanouts[-1] or n_groups * f * 4 > N // 4) else 0)
+        child, rank = _split_level(X, lib, st, group, n_groups, f)
         key = key * f + rank[group, child]
         group = group * f + child
         n_groups *= f

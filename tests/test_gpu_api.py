@@ -504,3 +504,58 @@ def test_verbose_prints_the_stage_lines(capsys):
         assert piece in out, out
     meld.MELD(verbose=0, knn=7).fit(X)
     assert capsys.readouterr().out == ""
+
+
+def test_graph_offers_what_the_reference_side_paths_read():
+    """beyond N / lmax the graph object is asked for ``knn``, ``diff_op`` (graphtools; reference
+    meld/cluster.py:213, comparison/comparison.py:318-323) and the Fourier basis ``U`` / ``e`` (pygsp; meld/cluster.py:235-236)
+    -- checked against the oracle's graph (weights and kernel are the ones test_graph_matches_oracle pins)."""
+    meld, mo = _meld(), _oracle()
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(900, 6)) * np.array([3.0, 2.0, 1.5, 1.0, 0.7, 0.5])
+    op = meld.MELD(knn=7, verbose=0).fit(X)
+    G = op.graph
+    Go = mo.build_graph(X, knn=7)
+    assert G.knn == 7
+    P = G.diff_op
+    Pref = Go.K.multiply(1.0 / np.ravel(Go.K.sum(1))[:, None]).tocsr()
+    assert np.allclose(np.ravel(P.sum(1)), 1.0, atol=1e-13)
+    assert abs(P - Pref).max() < 1e-10
+    G.compute_fourier_basis()
+    e_ref = np.linalg.eigvalsh(Go.L.toarray())
+    assert np.abs(G.e - e_ref).max() < 1e-9 * max(1.0, e_ref[-1])
+    assert abs(G.lmax - e_ref[-1]) < 1e-9 * e_ref[-1]  # pygsp: the exact largest eigenvalue once the basis exists
+    U = G.U
+    assert U.shape == (900, 900) and np.abs(U.T @ U - np.eye(900)).max() < 1e-9
+    L = Go.L.toarray()
+    assert np.abs(L @ U - U * G.e[None, :]).max() < 1e-8 * e_ref[-1]  # eigenvectors of the ORACLE's Laplacian, caller's cell order
+    with pytest.raises(NotImplementedError):
+        meld.MELD(knn=15, verbose=0).fit(rng.normal(size=(17000, 5))).graph.compute_fourier_basis()
+
+
+def test_lmax_method_is_remembered():
+    """An estimate made by one method is not silently kept when the other one is asked for (and an injected value is)."""
+    meld = _meld()
+    rng = np.random.default_rng(6)
+    X = rng.normal(size=(4000, 8))
+    labels = rng.integers(0, 2, 4000)
+    op = meld.MELD(knn=10, verbose=0)
+    op.fit_transform(X, labels)
+    G = op.graph
+    lm_lanczos = G.lmax
+    assert G.lmax_info["method"] == "lanczos"
+    op.set_params(lmax="arpack")
+    op.transform(labels)
+    assert G.lmax_info["method"] == "arpack" and abs(G.lmax - lm_lanczos) < 2e-2 * lm_lanczos
+    lm_arpack = G.lmax
+    G.estimate_lmax(method="lanczos")  # asked for explicitly: computed again
+    assert G.lmax_info["method"] == "lanczos" and abs(G.lmax - lm_lanczos) < 1e-9 * lm_lanczos
+    op.set_params(lmax=3.25)
+    op.transform(labels)
+    assert G.lmax == 3.25 and G.lmax_info["method"] == "injected"
+    G.estimate_lmax(method="arpack")  # an injected value stays (pygsp's no-op)
+    assert G.lmax == 3.25
+    op.set_params(lmax=None)
+    op.transform(labels)
+    assert G.lmax_info["method"] == "lanczos" and abs(G.lmax - lm_lanczos) < 1e-9 * lm_lanczos
+    assert lm_arpack > 0

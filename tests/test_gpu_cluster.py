@@ -175,8 +175,25 @@ def test_kmeans_kernel_equals_a_plain_lloyd_step():
     assert abs(float(inertia) - float(D.gather(1, ref_lab[:, None]).sum())) <= 1e-9 * float(inertia)
     out = _kmeans(Y, 4, n_init=2, seed=1)
     assert out.shape == (70_001,) and set(out.unique().tolist()) == {0, 1, 2, 3}
-    with pytest.raises(NotImplementedError):
-        _kmeans(torch.zeros(10, 40, dtype=torch.float64, device="cuda"), 3)
+    # beyond the kernel's LDS staging (d > 32 or k > 64): the library Lloyd step, same outputs
+    from meld_amd.cluster import _lloyd_step_library
+
+    lab2 = torch.empty_like(lab)
+    newC2, inertia2 = _lloyd_step_library(Y, C, lab2)
+    assert torch.equal(lab2, lab) and torch.allclose(newC2, newC, rtol=1e-12, atol=1e-12)
+    assert abs(float(inertia2) - float(inertia)) <= 1e-9 * float(inertia)
+    Yw = torch.from_numpy(rng.normal(size=(5000, 40)) + 6.0 * rng.integers(0, 2, size=(5000, 1))).cuda()
+    out = _kmeans(Yw, 3, n_init=2, seed=0)
+    assert out.shape == (5000,) and set(out.unique().tolist()) == {0, 1, 2}
+
+
+def test_more_clusters_than_the_kmeans_kernel_stages(setup):
+    """n_clusters = 40 (reference meld/cluster.py:340-345 has no limit: PCA to n_clusters features, KMeans): the
+    device KMeans falls back to the library Lloyd step beyond 32 features / 64 clusters."""
+    meld = setup["meld"]
+    vfc = meld.VertexFrequencyCluster(n_clusters=40, random_state=0, window_sizes=np.array([2, 4, 8, 24]))
+    labels = vfc.fit_predict(setup["op"].graph, sample_indicator=setup["ind"]["expt"], likelihood=setup["lik"]["expt"])
+    assert labels.shape == (600,) and len(np.unique(labels)) > 30 and labels.min() == 0 and labels.max() <= 39
 
 
 def test_filterbank_at_a_size_the_dense_method_cannot_reach():

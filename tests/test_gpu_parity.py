@@ -668,44 +668,3 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         assert torch.equal(a, b)
     # row 0 of the subset is global row 100: its nearest candidate is itself
     assert int(res[1][0][0, 0]) == 100
-
-
-def test_segment_means_kernel():
-    """meld_segment_means (the centroid update of the ordering's optional Lloyd steps) against numpy, with empty segments."""
-    from meld_amd._lib import check, get_lib, ptr
-
-    lib = get_lib()
-    rng = np.random.default_rng(8)
-    N, d, n_seg = 5000, 50, 300
-    X = rng.normal(size=(N, d))
-    leaf = rng.integers(0, n_seg, size=N)
-    leaf[leaf == 7] = 8  # an empty segment
-    order = np.argsort(leaf, kind="stable")
-    start = np.searchsorted(leaf[order], np.arange(n_seg + 1))
-    out = torch.full((n_seg, d), -1.0, dtype=torch.float64, device="cuda")
-    Xd, od, sd = torch.from_numpy(X).cuda(), torch.from_numpy(order).cuda(), torch.from_numpy(start).cuda()
-    check(lib.meld_segment_means(ptr(Xd), N, d, ptr(od), ptr(sd), n_seg, ptr(out), torch.cuda.current_stream().cuda_stream))
-    got = out.cpu().numpy()
-    for g in range(n_seg):
-        rows = X[leaf == g]
-        if rows.shape[0]:
-            np.testing.assert_allclose(got[g], rows.mean(0), rtol=1e-12, atol=1e-14)
-        else:
-            assert np.all(got[g] == -1.0)
-
-
-def test_lloyd_refinement_of_the_ordering_leaves_the_graph_unchanged(monkeypatch):
-    """MELD_REORDER_LLOYD (tuning hook) only changes the cell order: same graph."""
-    import meld_amd
-
-    mo = _oracle()
-    X, _ = mo.synthetic_cells(20000, n_dims=50, seed=3)
-    Xd = torch.from_numpy(X).cuda()
-    G0 = meld_amd.build_knn_graph(Xd, knn=15)
-    monkeypatch.setenv("MELD_REORDER_LLOYD", "1")
-    G1 = meld_amd.build_knn_graph(Xd, knn=15)
-    assert not torch.equal(G0.perm, G1.perm)
-    A, B = sparse.csr_matrix(G0.W), sparse.csr_matrix(G1.W)
-    A.sort_indices(); B.sort_indices()
-    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
-    np.testing.assert_allclose(A.data, B.data, rtol=1e-12)
