@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="(kept for older command lines: the default is the full protocol now)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the extra untimed-region passes with X on the host")
     ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
+    ap.add_argument("--vfc", action="store_true", help="also time VertexFrequencyCluster (filter-bank method) on the benchmark graph "
+                                                       "(BASELINE configs[4] on one GPU) and report `vfc` / `roofline_vfc`")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded driver even with one rank (testing)")
     args = ap.parse_args()
 
@@ -361,6 +363,40 @@ def main():
         op2.transform(labels)
         torch.cuda.synchronize()
         out["stages"] = dict(op2.graph.info["stage_seconds"], fit_total=t_fit, transform_total=time.perf_counter() - t0)
+    if args.vfc and world == 1:
+        # BASELINE configs[4] on one GPU: the filter-bank VertexFrequencyCluster on the graph just built -- n_probes
+        # columns through the same recurrence kernel (2 M + 1 SpMMs), Ritz pairs + band energies, PCA + KMeans
+        lik = meld_amd.utils.normalize_densities(dens)
+        mgraph.record_events(True)
+        t0 = time.perf_counter()
+        vfc = meld_amd.VertexFrequencyCluster(n_clusters=6, random_state=0, n_init=2)
+        vfc.fit(G)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        vfc.transform(op.sample_indicators["expt"], lik["expt"])
+        t2 = time.perf_counter()
+        clusters = vfc.predict()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ev2 = mgraph.event_times_ms()
+        mgraph.record_events(False)
+        out["vfc"] = {
+            "method": vfc.method_, "cells": N, "n_probes": int(vfc.n_probes), "n_bands": int(vfc.n_bands), "windows": len(vfc.window_sizes),
+            "chebyshev_order": int(vfc._fb["order"]), "fit_s": t1 - t0, "transform_s": t2 - t1, "predict_s": t3 - t2,
+            "clusters": int(len(np.unique(clusters))),
+            "note": "filter-bank method (a new algorithm: the reference's dense one needs an N x N Fourier basis); fit = "
+                    "2 M + 1 SpMMs of n_probes columns on the recurrence kernel + QR / Rayleigh-Ritz (library)",
+        }
+        if "vfc_spmm" in ev2:
+            R = int(vfc.n_probes)
+            t_sp = float(np.mean(ev2["vfc_spmm"])) * 1e-3
+            byts = cheby_bytes_per_step(G.nnz, N, R)
+            out["roofline_vfc"] = {
+                "kernel": "pt_step_kernel<P=2>, {} launches per SpMM of {} columns (the matrix is streamed once per column pair)".format((R + 1) // 2, R),
+                "bound": "hbm", "achieved": byts / t_sp / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byts / t_sp / 1e9 / PEAK_HBM_GBS,
+                "algorithmic": "{} B per SpMM (12*nnz + 4(N+1) + 8N + 40*N*p, p = {}: the matrix bytes counted once)".format(byts, R),
+                "ms_per_spmm": 1e3 * t_sp, "spmms": len(ev2["vfc_spmm"]), "traffic": None,
+            }
     if host_ms:
         # SURVEY 8d's metric counts the H2D copy of X: this is the figure to compare with it (`value` starts X-resident)
         out["value_host_input"] = N / (1e-3 * float(np.median(host_ms)))

@@ -73,6 +73,20 @@ def _lloyd_step(Y, C, lab, scratch):
     return newC, scratch["in"].sum()
 
 
+def _tall_gram(A, B, chunk=4096):
+    """A^T B for tall-skinny A [n, r], B [n, s] (n ~ 1e6, r, s ~ 64): as a batch of chunk-row products summed at the end.
+    The library GEMM runs this shape -- a 64 x 64 result with a million-long inner dimension -- on a handful of
+    workgroups (54 ms at 1M x 64); split over the inner dimension it is bandwidth-bound (~1 ms)."""
+    n = A.shape[0]
+    nb = n // chunk
+    out = torch.zeros(A.shape[1], B.shape[1], dtype=A.dtype, device=A.device)
+    if nb > 0:
+        out += torch.bmm(A[: nb * chunk].view(nb, chunk, -1).transpose(1, 2), B[: nb * chunk].view(nb, chunk, -1)).sum(0)
+    if nb * chunk < n:
+        out += A[nb * chunk :].T @ B[nb * chunk :]
+    return out
+
+
 def _lloyd_step_library(Y, C, lab):
     """``_lloyd_step`` for shapes beyond the HIP kernel (d > 32 or k > 64): chunked distance GEMMs, argmin (ties to the
     lowest index), index_add for the sums -- same outputs."""
@@ -343,26 +357,64 @@ class VertexFrequencyCluster:
         gen.manual_seed(0 if self.random_state is None else int(self.random_state))
         Z = (torch.randint(0, 2, (n, R), device=dev, generator=gen, dtype=torch.int8).to(torch.float64) * 2.0 - 1.0).contiguous()
         a1 = a2 = lmax / 2.0
+        from .graph import _EventSpan
+
+        # The recurrence kernel takes the iterate two columns at a time.  Handed [n, R] row-major, every launch would
+        # gather 16 bytes out of each 8 R-byte row (1M cells, R = 64: 248 us per launch instead of 110); the iterates
+        # are therefore kept PAIR-MAJOR, [R / 2][n][2], each pair a contiguous [n, 2] array like MELD's own signal, and
+        # turned into [n, R] once per step for the dense algebra of `visit` (a 2 x 8 n R-byte copy).
+        Rp = R + (R & 1)
+
+        def to_pairs(A):  # [n, R] -> [Rp / 2, n, 2]
+            if Rp != R:
+                A = torch.cat([A, torch.zeros(n, 1, dtype=A.dtype, device=dev)], dim=1)
+            return A.view(n, Rp // 2, 2).permute(1, 0, 2).contiguous()
+
+        def from_pairs(T):  # [Rp / 2, n, 2] -> [n, R]
+            return T.permute(1, 0, 2).reshape(n, Rp)[:, :R]
+
+        def spmm(t_in, t_zy, alpha, beta, gamma):
+            with _EventSpan("vfc_spmm", N=n, p=R, nnz=G.nnz):
+                for i in range(Rp // 2):
+                    ops.cheby_step(G, 2, t_in[i], 0, t_zy[i] if gamma != 0.0 else None, t_zy[i], None, alpha, beta, gamma, 0.0)
 
         def recurrence(Z0, visit):
-            """visit(k, T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, p = R columns)."""
-            t_old, t_cur = Z0.clone(), torch.empty_like(Z0)
-            visit(0, t_old)
-            ops.cheby_step(G, R, t_old, 0, None, t_cur, None, 1.0 / a1, -a2 / a1, 0.0, 0.0)
-            visit(1, t_cur)
+            """visit(k, T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, R columns as R / 2 pairs)."""
+            t_old, t_cur = to_pairs(Z0), torch.empty(Rp // 2, n, 2, dtype=torch.float64, device=dev)
+            visit(0, Z0)
+            spmm(t_old, t_cur, 1.0 / a1, -a2 / a1, 0.0)
+            visit(1, from_pairs(t_cur))
             for k in range(2, M + 1):
-                ops.cheby_step(G, R, t_cur, 0, t_old, t_old, None, 2.0 / a1, -2.0 * a2 / a1, -1.0, 0.0)
-                visit(k, t_old)
+                spmm(t_cur, t_old, 2.0 / a1, -2.0 * a2 / a1, -1.0)
+                visit(k, from_pairs(t_old))
                 t_old, t_cur = t_cur, t_old
+
+        def orthonormalise(Y):
+            """Q with orthonormal columns spanning those of Y [n, R]: CholeskyQR2 -- two rounds of (Gram matrix, Cholesky
+            factor, triangular solve), all tall-skinny GEMMs and R x R factorisations (on a row-sharded graph the Gram
+            matrix is the only thing that crosses ranks).  The filtered probes are far from orthogonal: if the first
+            factorisation breaks down (condition number beyond ~1e8) the Householder QR of the library takes over."""
+            Q = Y
+            for _ in range(2):
+                Gm = _tall_gram(Q, Q)
+                Lc, info = torch.linalg.cholesky_ex(0.5 * (Gm + Gm.T))
+                if int(info) != 0:
+                    Qh, _ = torch.linalg.qr(Y)
+                    return Qh.contiguous()
+                # Q <- Q L^-T through the inverse of the small factor (a triangular solve with n right-hand sides asks the
+                # library for an n-sized workspace)
+                Linv = torch.linalg.solve_triangular(Lc, torch.eye(Lc.shape[0], dtype=Lc.dtype, device=Lc.device), upper=False)
+                Q = (Q @ Linv.T).contiguous()
+            return Q
 
         # pass 1: low-pass filtered probes -> basis of the low end of the spectrum -> Ritz pairs
         Y = torch.zeros_like(Z)
         recurrence(Z, lambda k, Tk: Y.add_(Tk, alpha=float(c_phi[k])))
-        Q, _ = torch.linalg.qr(Y)
-        Q = Q.contiguous()  # (the solver hands back a column-major tensor; the kernels take row-major [n, R])
-        LQ = torch.empty(n, R, dtype=torch.float64, device=dev)
-        ops.cheby_step(G, R, Q, 0, None, LQ, None, 1.0, 0.0, 0.0, 0.0)  # L Q
-        H = Q.T @ LQ
+        Q = orthonormalise(Y)
+        qp, lqp = to_pairs(Q), torch.empty(Rp // 2, n, 2, dtype=torch.float64, device=dev)
+        spmm(qp, lqp, 1.0, 0.0, 0.0)  # L Q
+        LQ = from_pairs(lqp)
+        H = _tall_gram(Q, LQ)
         theta, V = torch.linalg.eigh(0.5 * (H + H.T))
         Ur = Q @ V  # approximate eigenvectors [n, R]
         theta = theta.clamp(0.0, lmax)
@@ -373,16 +425,16 @@ class VertexFrequencyCluster:
         Pth = (Cd @ Tm).clamp_(min=0.0)  # [T*B, R]
         E_low = (Ur * Ur) @ Pth.T  # [n, T*B]
         # pass 2: Hutchinson on the deflated operator
-        Zd = Z - Q @ (Q.T @ Z)
-        mom = torch.empty(n, M + 1, dtype=torch.float64, device=dev)
+        Zd = Z - Q @ _tall_gram(Q, Z)
+        mom = torch.empty(M + 1, n, dtype=torch.float64, device=dev)
 
         def visit2(k, Tk):
-            W = Tk - Q @ (Q.T @ Tk)
-            mom[:, k] = (Z * W).mean(1)
+            W = Tk - Q @ _tall_gram(Q, Tk)
+            torch.mean(Z * W, dim=1, out=mom[k])
 
         recurrence(Zd, visit2)
         T, B = len(self.window_sizes), self.n_bands
-        E_res = (mom @ Cd.T).view(n, T, B).clamp_(min=0.0)  # band energies outside the Ritz subspace
+        E_res = (Cd @ mom).T.contiguous().view(n, T, B).clamp_(min=0.0)  # band energies outside the Ritz subspace
         E_lowb = E_low.view(n, T, B)
         tot = (E_lowb + E_res).sum(2)  # [n, T]: [p_t(L)]_jj, the squared norm of vertex j's window signature
         tot = torch.where(tot > 0, tot, torch.ones_like(tot))

@@ -161,3 +161,33 @@ def test_filter_stage_matches_the_cpu_oracle_at_full_size(full):
     dens = op.transform(labels)
     assert list(dens.columns) == list(samples)
     assert np.abs(dens.values[perm] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_filterbank_vertex_frequency_cluster_at_one_million_cells():
+    """BASELINE configs[4] on one GPU: the filter-bank VertexFrequencyCluster at the 1M-cell size (the reference's dense
+    algorithm cannot run beyond ~2e4 cells).  Properties that do not depend on the size: finite non-negative spectrogram
+    of n_probes + n_bands columns, every row non-zero, window norms positive, the Ritz values
+    inside [0, lmax] and ascending, clusters sorted by mean likelihood, and the same result for the same seed."""
+    import meld_amd
+    from bench import synthetic_cells
+
+    N = 1_000_000
+    X, labels = synthetic_cells(N, 50, seed=0)
+    op = meld_amd.MELD(knn=15, chebyshev_order=30, verbose=0)
+    lik = meld_amd.utils.normalize_densities(op.fit_transform(X, labels))
+    ind = op.sample_indicators["expt"]
+    vfc = meld_amd.VertexFrequencyCluster(n_clusters=5, random_state=0, n_probes=32, n_init=2)
+    out = vfc.fit_predict(op.graph, sample_indicator=ind, likelihood=lik["expt"])
+    assert vfc.method_ == "filterbank" and vfc.spectrogram.shape == (N, 32 + 16)
+    spec = vfc.spectrogram
+    assert np.isfinite(spec).all() and spec.min() >= 0.0
+    assert np.all(spec.sum(1) > 0.0)  # (the indicator is centred by default: no cell is outside it)
+    ritz = vfc._fb["ritz"].cpu().numpy()
+    assert np.all(np.diff(ritz) >= -1e-9) and ritz[0] >= 0.0 and ritz[-1] <= vfc._fb["lmax"]
+    assert float(vfc._fb["window_norm2"].min()) > 0.0
+    assert out.shape == (N,) and set(np.unique(out).tolist()) == set(range(5))
+    means = [lik["expt"].values[out == c].mean() for c in range(5)]
+    assert means == sorted(means)
+    vfc2 = meld_amd.VertexFrequencyCluster(n_clusters=5, random_state=0, n_probes=32, n_init=2)
+    out2 = vfc2.fit_predict(op.graph, sample_indicator=ind, likelihood=lik["expt"])
+    assert np.abs(vfc2.spectrogram - spec).max() < 1e-6 and (out2 == out).mean() > 0.999
