@@ -121,6 +121,13 @@ int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, con
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are
  * identical).  The norm pieces live in the hi plane and are exact in either mode. */
+/* meld_knn16_prepare for a search between two point sets (the blocks between two samples of graphtools' MNN kernel,
+ * reached through reference meld/meld.py:117-118 with sample_idx=, test/test_meld.py:34): X holds n_total rows, the
+ * references are rows [0, n_refs), the queries a range of the rest.  Scaling over all rows; norm2 / norm2_max cover the
+ * references only (the caller merges the queries' norms from Qn). */
+int meld_knn16_prepare_cross(const double* X, int64_t n_refs, int64_t n_total, int d, const double* mean, int64_t q_begin,
+                             int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
+                             float* scale_info, meld_stream_t stream);
 /* query operands for a list of local rows (rows[i] + q_begin = global index): the re-search of the
  * rows a reduced-precision first pass could not certify */
 int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "meld_knn16_tile_bytes": (_sz, [_i32]),
     "meld_knn16_query_bytes": (_sz, [_i32]),
     "meld_knn16_prepare": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn16_prepare_cross": (_i32, [_ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_rows": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),
     "meld_knn16_bounds_temp_bytes": (_sz, [_i64, _i32, _i64]),

@@ -1681,6 +1681,33 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
   return MELD_OK;
 }
 
+// The same for a search between two point sets (the blocks of graphtools' MNN kernel between two samples): X holds
+// n_total rows, the references are its rows [0, n_refs), the queries any range of it (the caller puts the query set
+// behind the references).  Scaling over all n_total rows; norm2 / norm2_max cover the references (the caller adds the
+// queries' from Qn).
+extern "C" int meld_knn16_prepare_cross(const double* X, int64_t n_refs, int64_t n_total, int d, const double* mean,
+                                        int64_t q_begin, int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2,
+                                        float* norm2_max, float* scale_info, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && Rt16 && Q16 && Qn && norm2 && norm2_max && scale_info && n_refs > 0 && n_total >= n_refs,
+                 "meld_knn16_prepare_cross: null/empty argument");
+  MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= n_total, "meld_knn16_prepare_cross: bad query range");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  hipStream_t st = S(stream);
+  MELD_HIP_CALL(hipMemsetAsync(scale_info, 0, 4 * sizeof(float), st));
+  MELD_HIP_CALL(hipMemsetAsync(norm2_max, 0, sizeof(float), st));
+  hipLaunchKernelGGL(absmax_centered_kernel, dim3(2048), dim3(256), 0, st, X, n_total * (int64_t)d, d, mean, scale_info);
+  hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
+  const int64_t n_pad = ceil_div(n_refs, K16_TS) * K16_TS;
+  hipLaunchKernelGGL((prepare16_kernel<true>), dim3((unsigned)(n_pad / K16_TS)), dim3(256), 0, st, X, n_refs, d, mean, scale_info,
+                     KB, (int64_t)0, n_refs, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
+  const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
+  hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, st, X, n_total, d, mean, scale_info,
+                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
+  MELD_LAUNCH_CHECK("meld_knn16_prepare_cross");
+  return MELD_OK;
+}
+
 // Query operands for a list of rows (second search stage); scale_info / mean as produced by
 // meld_knn16_prepare for the same X.
 extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,

@@ -412,12 +412,21 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
-    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False):
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
-        key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2)."""
+        key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
+
+        ``n_refs``: search BETWEEN two point sets (the cross blocks of the MNN kernel, ``meld_amd.mnn``): the references
+        are the rows [0, n_refs) of X only, the queries lie behind them, there is no self among a row's candidates --
+        the caller passes knn - 1 so that the bandwidth is the knn-th nearest reference.  No pruning table, no seeds
+        (both rest on tile = query block)."""
         lib, st, dev = self.lib, _stream(), X.device
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
+        cross = n_refs is not None
+        NR = int(n_refs) if cross else N  # references of the search
+        if cross and not (0 < NR <= q_begin and q_begin + q_count <= N):
+            raise ValueError("cross search: the queries must lie behind the n_refs references")
         tm.start()
         if d <= 256:
             sums = torch.empty(d, dtype=torch.float64, device=dev)
@@ -432,6 +441,8 @@ class HipOps:
         used_prune = used_seed = used_seeded_bounds = used_block_order = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
+        if cross and search != "f16x3":
+            raise NotImplementedError("the search between two point sets runs on the split-fp16 MFMA kernel only (d <= 141)")
         if search == "wide":
             # Library path for wide data that was not reduced by PCA: chunked fp64 GEMMs (rocBLAS) for
             # |q|^2 + |r|^2 - 2 q.r and torch.topk merges, feeding the same exact refinement.  No hand-written
@@ -486,13 +497,20 @@ class HipOps:
                 check(cap, "meld_knn16_row_capacity")
             err_coef = lib.meld_knn16_error_coef_const(nprod, d)
             err_lin = lib.meld_knn16_error_coef_lin(nprod)
-            n_tiles = (N + TS - 1) // TS
+            n_tiles = (NR + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
             Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device=dev)
             Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device=dev)
             Qn = torch.empty(q_pad, dtype=torch.float32, device=dev)
             scale_info = torch.empty(4, dtype=torch.float32, device=dev)
-            check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
+            if cross:
+                check(lib.meld_knn16_prepare_cross(ptr(X), NR, N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare_cross")
+                # the error bounds speak of the largest norm among ALL points of the search, and refine reads the
+                # query's own norm at its row
+                norm2[q_begin : q_begin + q_count] = Qn[:q_count]
+                nmax = torch.maximum(nmax, Qn[:q_count].max().reshape(1))
+            else:
+                check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
             tm.stop("prepare")
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
@@ -504,7 +522,7 @@ class HipOps:
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
             lb2 = block_order = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
-            will_prune = self.prune and q_begin % TS == 0 and N >= 16384
+            will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
             # of the chip idle is searched separately with the references cut into slices, so that its
             # few query blocks x slices fill the chip again.
@@ -520,7 +538,7 @@ class HipOps:
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
             seeds = None
-            if self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1:
+            if self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1 and not cross:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
                 if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
@@ -543,7 +561,7 @@ class HipOps:
                     block_order = torch.argsort(work, descending=True, stable=True).to(torch.int32)
                 tm.stop("bounds")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), N, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
+                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 if q_main < q_count:
                     q_tail = q_count - q_main
                     qt_pad = q_pad - q_main
@@ -551,7 +569,7 @@ class HipOps:
                     t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
                     t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
                     t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), N, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), None, st), "meld_knn16_topk(tail)")
+                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), NR, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), 0 if cross else q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), None, st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
             used_prune, used_seed = lb2 is not None, seeds is not None
@@ -646,7 +664,7 @@ class HipOps:
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)
             with _EventSpan("knn_topk_stage2", N=N, d=d, q=n_flag_h):
-                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), N, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, None, None, st), "meld_knn16_topk(stage 2)")
+                check(lib.meld_knn16_topk(ptr(Q2), ptr(Qn2), ptr(research["Rt"]), ptr(research["scale_info"]), NR, d, n_flag_h, ksel, 3, n_slices, None, ptr(nmax), 0, ptr(thr2), 0, 1.0, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, None, None, st), "meld_knn16_topk(stage 2)")
                 if n_slices > 1:
                     m_idx = torch.empty(q2_pad * cap, dtype=torch.int32, device=dev)
                     m_d2 = torch.empty(q2_pad * cap, dtype=torch.float32, device=dev)
@@ -676,7 +694,7 @@ class HipOps:
         # ksel = 64, 0.63 s; none at ksel = 128, 32 ms).  Same graph either way.
         if (n_flag_h > max(1024, q_count // 100) and ksel < 128 and search == "f16x3" and not force_fallback
                 and os.environ.get("MELD_KNN_RETRY", "1") != "0"):
-            out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False)
+            out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -692,7 +710,7 @@ class HipOps:
             cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)  # count pass: references closer than bw
             check(
                 lib.meld_knn_radius_exact(
-                    ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
+                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
                     ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
                 ),
                 "meld_knn_radius_exact(count)",
@@ -704,13 +722,13 @@ class HipOps:
                 # sweep is counted again (graphtools re-searches such rows with more neighbours)
                 bad = torch.nonzero(fb_cnt < 0).reshape(-1)
                 rows_bad = flag_rows[bad].to(torch.int64)
-                bw[rows_bad] = _exact_bandwidth(X, q_begin + rows_bad, knn)
+                bw[rows_bad] = _exact_bandwidth(X, q_begin + rows_bad, knn, n_refs=NR)
                 fb_cnt.zero_()
                 cursor.zero_()
                 err.zero_()
                 check(
                     lib.meld_knn_radius_exact(
-                        ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
+                        ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
                         ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
                     ),
                     "meld_knn_radius_exact(recount)",
@@ -725,7 +743,7 @@ class HipOps:
             fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
             check(  # (the count pass left the cursors at zero)
                 lib.meld_knn_radius_exact(
-                    ptr(X), N, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 1,
+                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 1,
                     None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,
                 ),
                 "meld_knn_radius_exact(fill)",
@@ -991,19 +1009,21 @@ class HipOps:
         check(self.lib.meld_axpby_f64(float(a), ptr(x), float(b), ptr(y), y.numel(), ptr(nrm2), _stream()), "meld_axpby_f64")
 
 
-def _exact_bandwidth(X, rows, knn):
-    """Distance to the (knn+1)-th nearest cell (self included) of the given rows over ALL references, exactly:
+def _exact_bandwidth(X, rows, knn, n_refs=None):
+    """Distance to the (knn+1)-th nearest cell (self included) of the given rows over ALL references (the first
+    ``n_refs`` rows of X, by default all of them), exactly:
     an fp64 GEMM-form screen keeps the 4 (knn + 1) nearest, their distances are recomputed by direct differences.
     Library path for the handful of rows the exact sweep finds with an incomplete candidate list."""
-    n2 = (X * X).sum(1)
+    Xr = X if n_refs is None else X[: int(n_refs)]
+    n2 = (Xr * Xr).sum(1)
     out = torch.empty(rows.shape[0], dtype=torch.float64, device=X.device)
-    kk = min(int(X.shape[0]), 4 * (knn + 1))
+    kk = min(int(Xr.shape[0]), 4 * (knn + 1))
     for lo in range(0, rows.shape[0], 256):
         r = rows[lo : lo + 256]
         Xq = X[r]
-        d2 = n2[r][:, None] + n2[None, :] - 2.0 * (Xq @ X.T)
+        d2 = (Xq * Xq).sum(1)[:, None] + n2[None, :] - 2.0 * (Xq @ Xr.T)
         cand = torch.topk(d2, kk, dim=1, largest=False).indices
-        dist = torch.linalg.vector_norm(X[cand] - Xq[:, None, :], dim=2)
+        dist = torch.linalg.vector_norm(Xr[cand] - Xq[:, None, :], dim=2)
         out[lo : lo + 256] = torch.sort(dist, dim=1).values[:, min(knn, kk - 1)]
     # Two ulps down: the sweep counts the references STRICTLY closer than the bandwidth with its own summation order
     # (even / odd FMA chains); a value that this routine rounds one ulp above the sweep's would count the bandwidth

@@ -11,10 +11,9 @@
 * the block from sample i to another sample j is the alpha-decay kernel from i's cells to j's cells with the
   bandwidth at the knn-th nearest cell *of j* (no self among the references), each row scaled by
   ``min(1, within / between) * beta`` (row sum of the diagonal block over row sum of this block) -- built
-  by ``cross_kernel`` below: chunked fp64 distance GEMMs (rocBLAS) + ``topk`` for the bandwidth, a second
-  sweep for everything inside the kernel radius, exact direct-difference distances for what is kept.  A
-  library path, not a hand-written kernel: two different point sets do not fit the self-search kernel's
-  tile = query-block layout, and the reference only smoke-tests this option;
+  by the same hot path with the references restricted to sample j (``_cross_block``: the MFMA search takes the
+  queries and the references from different row ranges; no pruning table or seeds there, they rest on tile = query
+  block).  ``cross_kernel`` (chunked fp64 rocBLAS GEMMs + ``topk``) remains for data wider than the search kernels;
 * the assembled matrix goes through the common symmetrise / anisotropy / degree steps (``csrc/assemble.hip``).
 """
 from __future__ import annotations
@@ -102,6 +101,25 @@ def cross_kernel(Xq, Yr, knn, decay, thresh, q_chunk=4096, r_chunk=32768):
     return torch.cat(rows), torch.cat(cols), torch.cat(vals)
 
 
+def _cross_block(ops, Xq, Yr, knn, decay, thresh, ksel=None):
+    """Directed kernel from the cells of one sample (``Xq``) to the cells of another (``Yr``) on the hot path: the MFMA
+    candidate search of ``csrc/knn16.hip`` with the references restricted to ``Yr`` (queries stacked behind them,
+    ``HipOps.directed_kernel_coo(n_refs=)``), exact refinement, certification / exact sweep as for a sample's own block.
+    There is no self among a query's candidates, so the bandwidth is its knn-th -- not (knn+1)-th -- nearest reference.
+    Data wider than the search kernels (d > 141) keeps the library path (``cross_kernel``)."""
+    from .graph import default_ksel
+
+    nq, nr, d = int(Xq.shape[0]), int(Yr.shape[0]), int(Xq.shape[1])
+    knn_c = int(min(knn, nr))  # graphtools clips knn to the size of the reference sample
+    if ops.search != "f16x3" or ops.lib.meld_knn16_kblocks(d) < 0 or knn_c < 2 or nr < 3:
+        return cross_kernel(Xq, Yr, knn, decay, thresh)
+    Xcat = torch.cat([Yr, Xq], dim=0).contiguous()
+    ks = int(ksel) if ksel is not None else default_ksel(knn_c)
+    keys, vals, _, _ = ops.directed_kernel_coo(Xcat, nr, nq, knn_c - 1, decay, thresh, ks, n_refs=nr)
+    M = keys.shape[0] // 2
+    return (keys[:M] >> 32) - nr, keys[:M] & 0xFFFFFFFF, 2.0 * vals[:M]  # (the COO stream carries K / 2)
+
+
 def build_mnn_graph(X, sample_idx, knn=5, decay=40, thresh=1e-4, anisotropy=1, beta=1.0, ksel=None):
     """Data [N, d] (CUDA fp64) + per-cell sample labels -> DeviceGraph of the MNN kernel (cells keep their order)."""
     if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dtype == torch.float64 and X.dim() == 2):
@@ -143,7 +161,7 @@ def build_mnn_graph(X, sample_idx, knn=5, decay=40, thresh=1e-4, anisotropy=1, b
         for j, (mj, Xj) in enumerate(zip(members, parts)):
             if i == j:
                 continue
-            r, c, v = cross_kernel(Xi, Xj, knn, decay, thresh)
+            r, c, v = _cross_block(ops, Xi, Xj, knn, decay, thresh, ksel)
             between = torch.zeros(int(Xi.shape[0]), dtype=torch.float64, device=dev)
             between.index_add_(0, r, v)
             scale = torch.clamp(within[i] / between, max=1.0) * float(beta)
@@ -162,7 +180,7 @@ def build_mnn_graph(X, sample_idx, knn=5, decay=40, thresh=1e-4, anisotropy=1, b
     dw = ops.row_sums(rowptr, val, N, 0.0)
     nnz = int(col.shape[0])
     info = dict(N=N, d=d, knn=int(knn), nnz=nnz, mean_degree=nnz / N, graph="mnn", n_samples=len(samples),
-                n_flagged_rows=n_flagged, search="f16x3 within samples, library GEMM between")
+                n_flagged_rows=n_flagged, search="f16x3 within and between samples")
     G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=info)
     G.ops = ops
     return G

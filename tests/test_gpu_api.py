@@ -466,6 +466,31 @@ def test_mnn_graph_matches_the_oracle(decay):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nq,nr,d,knn,decay", [(700, 333, 6, 5, 40), (30000, 20011, 50, 15, 40), (4097, 9000, 20, 10, float("inf"))])
+def test_cross_blocks_on_the_search_kernel_equal_the_library_path(nq, nr, d, knn, decay):
+    """The blocks between two samples of the MNN kernel come from the MFMA search with the references restricted to
+    the other sample (HipOps.directed_kernel_coo(n_refs=)): same entries as the fp64 GEMM + topk library path
+    (cross_kernel, which test_oracle pins against the definition), values to 1e-12."""
+    import torch
+    from meld_amd.graph import HipOps
+    from meld_amd.mnn import _cross_block, cross_kernel
+
+    rng = np.random.default_rng(nq)
+    lat = min(d, 8)
+    A = rng.normal(size=(lat, d))
+    Xq = torch.from_numpy(rng.normal(size=(nq, lat)) @ A + 0.05 * rng.normal(size=(nq, d))).cuda()
+    Yr = torch.from_numpy((rng.normal(size=(nr, lat)) + 0.3) @ A + 0.05 * rng.normal(size=(nr, d))).cuda()  # a shifted batch
+    ops = HipOps()
+    r1, c1, v1 = _cross_block(ops, Xq, Yr, knn, decay, 1e-4)
+    r0, c0, v0 = cross_kernel(Xq, Yr, knn, decay, 1e-4)
+    k1 = torch.sort(r1 * nr + c1)
+    k0 = torch.sort(r0 * nr + c0)
+    assert k1.values.shape == k0.values.shape and torch.equal(k1.values, k0.values)
+    assert float((v1[k1.indices] - v0[k0.indices]).abs().max()) <= 1e-12
+    assert int(torch.bincount(r1, minlength=nq).min()) >= knn  # every query reaches its knn nearest references
+
+
+@pytest.mark.gpu
 def test_mnn_three_samples_and_argument_checks():
     import meld_amd
     from oracle import meld_oracle as mo
