@@ -372,7 +372,7 @@ int meld_pt_debug_stamps(unsigned long long* buf);
  * `layout` are written); local row r is column col_base + r of the matrix (0 on one GPU, the shard's first
  * row on a row shard); symmetric != 0 folds the in-block pairs.  status[0] (device) receives 0, or the
  * reason the layout cannot be used:
- * 1 = a block touches too many column panels, 2 = too many distinct columns in a block,
+ * 1 = (no longer raised: a block's column panels are handled in groups), 2 = too many distinct columns in a block,
  * 3 = n_cols beyond the builder's index range, 4 = a segment / a wave's pairs / its padding beyond the
  * builder's ranges, 5 = W is not bitwise symmetric inside a block (build again with symmetric = 0),
  * 6 = a diagonal entry -- the caller then stays on meld_cheby_step. */

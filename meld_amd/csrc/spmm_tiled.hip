@@ -639,7 +639,7 @@ __device__ __forceinline__ uint64_t lanes_below(int l) { return ((uint64_t)1 << 
 //                        last pair of its row (part) << 12 | j - row0
 //   lower in-block entry T_SKIP << 26 | j - row0   (dropped: its twin (j, i) is stored by the wave that owns row j)
 // plus the per-wave chunk schedule (seg).  `sym` = 0: no IN part, every column goes through the tiles.
-// status[0] = max over blocks of an error code (1: a block touches more than TP_MAX column panels, 2: more than TMAX
+// status[0] = max over blocks of an error code (1: unused since the panel groups, 2: more than TMAX
 // tiles, 3: n_cols too large, 4: a segment / a wave's pairs / its padding beyond the code's range, 6: a diagonal entry).
 __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_cols, int64_t col_base, int sym,
@@ -718,31 +718,44 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     }
     int total;
     int pre = block_exscan(c, s_scan, &total);
-    if (total > TP_MAX) {
-      if (tid == 0) {
-        atomicMax(status, 1);
-        blk_ntile[b] = -1;
-        blk_ndist[b] = 0;
-      }
-      return;
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int pn = tid * 4 + k;
-      if (pn < NPAN_MAX) {
-        if (f[k]) {
-          s_pmap[pn] = (int16_t)pre;
-          s_cpan[pre] = (int16_t)pn;
-          ++pre;
-        } else {
-          s_pmap[pn] = -1;
-        }
-      }
+      if (pn < NPAN_MAX) s_pmap[pn] = f[k] ? (int16_t)(pre++) : (int16_t)-1;
     }
     if (tid == 0) s_scan[0] = total;
   }
   __syncthreads();
-  const int tp = s_scan[0];
+  const int tp_all = s_scan[0];  // column panels the block touches
+  __syncthreads();
+
+  // The bitmap in LDS holds TP_MAX panels (786k columns' worth).  A block of a graph of up to ~1M cells touches
+  // fewer; beyond that (2M cells in one chain order: 500+) the touched panels are handled TP_MAX at a time, in
+  // ascending order -- passes B, the prefix sums, the column list and the walk below run once per group, ranks and
+  // segment positions simply continue.  Within a (wave, tile) segment the entries are then ordered by (panel
+  // group, row, column) instead of (row, column): a row's run may be cut in two at a group boundary (two flushes).
+  constexpr int RU = 8;  // work items in flight
+  const int nmine = (w < NW && nrows > w) ? (nrows - w + NW - 1) / NW : 0;
+  const int64_t elast = max(e1 - 1, e0);
+  int curs = 0;       // lane t: entries of list chunk t seen so far
+  int in_cur = 0;     // (uniform) IN pairs of this wave so far
+  int dist_base = 0;  // distinct OUT columns of the panel groups already done
+  bool bad_range = false, bad_diag = false;
+  const int n_groups_p = max(1, (tp_all + TP_MAX - 1) / TP_MAX);
+  for (int pg = 0; pg < n_groups_p; ++pg) {
+  const int pbase = pg * TP_MAX;
+  const int tp = min(TP_MAX, tp_all - pbase);  // panels of this group (compact indices pbase .. pbase + tp - 1)
+  auto panel_slot = [&](int c) -> int {        // row of the bitmap, or -1: not in this group
+    const int ci = (int)s_pmap[c >> BP_BITS] - pbase;
+    return ((unsigned)ci < (unsigned)TP_MAX) ? ci : -1;
+  };
+  if (pg > 0) {
+    for (int i = tid; i < TP_MAX * (BP / 32); i += THREADS) (&s_bits[0][0])[i] = 0u;
+  }
+  for (int pn = tid; pn < npan; pn += THREADS) {
+    const int ci = (int)s_pmap[pn] - pbase;
+    if (s_pmap[pn] >= 0 && (unsigned)ci < (unsigned)TP_MAX) s_cpan[ci] = (int16_t)pn;
+  }
   __syncthreads();
 
   // pass B: one bit per distinct OUT column
@@ -751,11 +764,14 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
 #pragma unroll
     for (int u = 0; u < MU; ++u) c[u] = col[min(eb + (int64_t)u * THREADS, e1 - 1)];
 #pragma unroll
-    for (int u = 0; u < MU; ++u)
-      if (!in_block(c[u])) atomicOr(&s_bits[s_pmap[c[u] >> BP_BITS]][(c[u] & (BP - 1)) >> 5], 1u << (c[u] & 31));
+    for (int u = 0; u < MU; ++u) {
+      if (in_block(c[u])) continue;
+      const int ci = panel_slot(c[u]);
+      if (ci >= 0) atomicOr(&s_bits[ci][(c[u] & (BP - 1)) >> 5], 1u << (c[u] & 31));
+    }
   }
   __syncthreads();
-  int ndist;
+  int ndist_g;
   {  // distinct columns before every group of GW words (<= GROUPS_MAX groups, GPT consecutive ones per thread)
     const int ngroups = tp * GPP;
     int cntk[GPT], c = 0;
@@ -771,18 +787,17 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
       cntk[k] = sgrp;
       c += sgrp;
     }
-    int pre = block_exscan(c, s_scan, &ndist);
+    int pre = block_exscan(c, s_scan, &ndist_g);
 #pragma unroll
     for (int k = 0; k < GPT; ++k) {
       const int g = tid * GPT + k;
       if (g < ngroups) s_gpre[g] = pre;
       pre += cntk[k];
     }
-    if (tid == 0) s_gpre[ngroups] = ndist;
+    if (tid == 0) s_gpre[ngroups] = ndist_g;
   }
   __syncthreads();
-  const int T = (ndist + CP - 1) / CP;
-  if (T > TMAX) {
+  if ((dist_base + ndist_g + CP - 1) / CP > TMAX) {
     if (tid == 0) {
       atomicMax(status, 2);
       blk_ntile[b] = -1;
@@ -790,11 +805,10 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     }
     return;
   }
-  // rank of a column among the block's distinct OUT columns
-  auto col_rank = [&](int c) -> int {
-    const int ci = s_pmap[c >> BP_BITS];
+  // rank of a column (of this panel group) among the block's distinct OUT columns
+  auto col_rank = [&](int c, int ci) -> int {
     const int wd = (c & (BP - 1)) >> 5;
-    int g = s_gpre[ci * GPP + wd / GW];
+    int g = dist_base + s_gpre[ci * GPP + wd / GW];
     const uint32_t* wp = &s_bits[ci][wd & ~(GW - 1)];
     // words of the group below wd, branch-free (GW - 1 reads, masked)
 #pragma unroll
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
     const int ci = i / (BP / 32), wd = i % (BP / 32);
     uint32_t bits = s_bits[ci][wd];
     if (bits) {
-      int g = s_gpre[ci * GPP + wd / GW];
+      int g = dist_base + s_gpre[ci * GPP + wd / GW];
       const uint32_t* wp = &s_bits[ci][wd & ~(GW - 1)];
       for (int q = 0; q < (wd & (GW - 1)); ++q) g += __popc(wp[q]);
       const int cbase = ((int)s_cpan[ci] << BP_BITS) + wd * 32;
@@ -825,11 +839,6 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
   // consecutive (skipping that run).  The per-tile counters of a wave live in ONE VGPR (lane t = list chunk t;
   // T <= 61) that the entry lanes read with ds_bpermute and the run heads update with ds_permute -- no loop over the
   // tiles of a row, no LDS memory in the dependent chain.
-  constexpr int RU = 8;  // work items in flight
-  const int nmine = (w < NW && nrows > w) ? (nrows - w + NW - 1) / NW : 0;
-  const int64_t elast = max(e1 - 1, e0);
-  int curs = 0;    // lane t: entries of list chunk t seen so far
-  int in_cur = 0;  // (uniform) IN pairs of this wave so far
   if (w < NW) {
     // Work items = (row, 64-entry part of it), in order.  The fetch cursor runs ahead of the walk on its own (row
     // bounds come from LDS), so the walk itself is ONE loop without inner loops or loads behind branches -- hipcc's
@@ -857,7 +866,6 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
 #pragma unroll
     for (int u = 0; u < RU; ++u) fetch(u);
     bool busy = nmine > 0;
-    bool bad_range = false, bad_diag = false;
     const uint64_t below = lanes_below(lane);
     while (busy) {
 #pragma unroll
@@ -870,12 +878,14 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
         const int rl_self = w + k * NW;
         const int cg = (int)((int64_t)c - cb0);  // column relative to the block's own rows
         const bool inb = act && in_block(c);
-        const bool upper = inb && cg > rl_self;
-        const bool outl = act && !inb;
-        bad_diag |= inb && cg == rl_self;
+        const bool first = pg == 0;             // the in-block lanes are dealt with in the first panel group
+        const bool upper = first && inb && cg > rl_self;
+        const int ci = (act && !inb) ? panel_slot(c) : -1;
+        const bool outl = ci >= 0;
+        bad_diag |= first && inb && cg == rl_self;
         // ---- OUT lanes: runs of equal list chunk among the OUT lanes (non-decreasing along them)
         const uint64_t om = __ballot(outl);
-        const int g = outl ? col_rank(c) : 0;
+        const int g = outl ? col_rank(c, ci) : 0;
         const int ch = g >> CP_BITS;
         const uint64_t ob = om & below;
         const int pl = ob ? 63 - __clzll((unsigned long long)ob) : 0;  // previous OUT lane
@@ -893,19 +903,15 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
         const uint64_t um = __ballot(upper);
         const int ipos = in_cur + __popcll(um & below);
         const bool ilast = upper && (um >> lane) == 1;  // highest upper lane of this part
-        if (act) {
-          uint32_t code;
-          if (outl) {
-            bad_range |= pos > 0x7FFF;
-            code = ((uint32_t)ch << 26) | ((uint32_t)(runlen == 1) << 25) | ((uint32_t)(pos & 0x7FFF) << CP_BITS) |
-                   (uint32_t)(g & (CP - 1));
-          } else if (upper) {
-            bad_range |= ipos > 0x1FFF;
-            code = ((uint32_t)T_IN << 26) | ((uint32_t)(ipos & 0x1FFF) << 13) | ((uint32_t)ilast << 12) | (uint32_t)cg;
-          } else {
-            code = ((uint32_t)T_SKIP << 26) | (uint32_t)(cg & 0xFFF);
-          }
-          codes[e0 + off + lane] = code;
+        if (outl) {
+          bad_range |= pos > 0x7FFF;
+          codes[e0 + off + lane] = ((uint32_t)ch << 26) | ((uint32_t)(runlen == 1) << 25) | ((uint32_t)(pos & 0x7FFF) << CP_BITS) |
+                                   (uint32_t)(g & (CP - 1));
+        } else if (upper) {
+          bad_range |= ipos > 0x1FFF;
+          codes[e0 + off + lane] = ((uint32_t)T_IN << 26) | ((uint32_t)(ipos & 0x1FFF) << 13) | ((uint32_t)ilast << 12) | (uint32_t)cg;
+        } else if (first && inb) {
+          codes[e0 + off + lane] = ((uint32_t)T_SKIP << 26) | (uint32_t)(cg & 0xFFF);
         }
         // every run head adds the length of its run to the counter of its tile (lane 63 is the dump of the other
         // lanes: list chunks are <= 60)
@@ -914,6 +920,13 @@ __global__ __launch_bounds__(THREADS) void pt_build_kernel(
         if (u == RU - 1) busy = ik[0] < nmine;  // (uniform) items are in order: nothing left once slot 0 is past the end
       }
     }
+  }
+  dist_base += ndist_g;
+  __syncthreads();  // (the bitmap is reused by the next panel group)
+  }  // panel groups
+  const int ndist = dist_base;
+  const int T = (ndist + CP - 1) / CP;
+  if (w < NW) {
     if (__any(bad_range)) atomicMax(status, 4);
     if (__any(bad_diag)) atomicMax(status, 6);
     s_cnt[w][lane] = (lane < T) ? curs : 0;

@@ -191,3 +191,29 @@ def test_filterbank_vertex_frequency_cluster_at_one_million_cells():
     vfc2 = meld_amd.VertexFrequencyCluster(n_clusters=5, random_state=0, n_probes=32, n_init=2)
     out2 = vfc2.fit_predict(op.graph, sample_indicator=ind, likelihood=lik["expt"])
     assert np.abs(vfc2.spectrogram - spec).max() < 1e-6 and (out2 == out).mean() > 0.999
+
+
+def test_two_million_cells_get_the_tiled_recurrence_kernel():
+    """Beyond ~1M cells a row block's columns spread over more bitmap panels than the layout builder holds in LDS at
+    once (384 x 2048 columns); it then works through them in groups.  2M cells: the layout is accepted, holds every
+    nonzero (one step equals the CSR-stream kernel's to rounding) and the fold is on."""
+    import torch
+    import meld_amd
+    from meld_amd.graph import HipOps
+    from bench import synthetic_cells
+
+    N = 2_000_000
+    X, _ = synthetic_cells(N, 50, seed=0)
+    G = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=15)
+    del X
+    G.ops = HipOps(spmm="tiled")
+    assert G.ops.pt_layout(G) is not None and G.info["spmm"] == "tiled" and G.info["spmm_fold"] is True
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(N, 2, dtype=torch.float64, device="cuda", generator=gen)
+    z = torch.rand(N, 2, dtype=torch.float64, device="cuda", generator=gen)
+    y_t, y_c = torch.empty_like(x), torch.empty_like(x)
+    G.ops.cheby_step(G, 2, x, 0, z, y_t, None, 0.7, -0.2, -1.0, 0.0)
+    Gc = meld_amd.DeviceGraph(G.rowptr, G.col, G.val, G.dw_dev)
+    Gc.ops = HipOps(spmm="csr")
+    Gc.ops.cheby_step(Gc, 2, x, 0, z, y_c, None, 0.7, -0.2, -1.0, 0.0)
+    assert float((y_t - y_c).abs().max() / y_c.abs().max()) < 1e-13
