@@ -62,6 +62,9 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_PINNED = {}  # (shape, dtype) -> pinned host staging buffer of the last result copied back
+
+
 def spectral_kernel(name, beta, offset, order, lmax):
     """h(lambda) of reference ``meld/filter.py:42-53``."""
     lname = name.lower()
@@ -429,10 +432,11 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
             r = r_orig
         # D2H through a pinned staging buffer kept on the graph (pageable copies run at a few GB/s)
         if r.is_cuda:
-            stage = getattr(graph, "_pinned_out", None)
-            if stage is None or stage.shape != r.shape:
+            stage = _PINNED.get((tuple(r.shape), r.dtype))  # (process-wide: a new graph per fit would pin 16 MB each time)
+            if stage is None:
+                _PINNED.clear()
                 stage = torch.empty(r.shape, dtype=r.dtype, pin_memory=True)
-                graph._pinned_out = stage
+                _PINNED[(tuple(r.shape), r.dtype)] = stage
             stage.copy_(r, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             out = stage.numpy().copy()

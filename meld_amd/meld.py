@@ -290,7 +290,12 @@ class MELD(GraphEstimator):
         if raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1):
             flat = raw.reshape(-1)
             dev = getattr(getattr(self.graph, "val", None), "device", None)
-            if flat.shape[0] >= self._DEVICE_FACTORIZE_MIN and dev is not None and dev.type == "cuda":
+            pre = getattr(self, "_prefactored", None)
+            if pre is not None and pre[0] is sample_labels and dev is not None and pre[1][0].device == dev:
+                on_device = pre[1]  # (fit_transform factorised them before the graph build)
+                factorized = on_device[:2]
+                self._label_counts = on_device[2]
+            elif flat.shape[0] >= self._DEVICE_FACTORIZE_MIN and dev is not None and dev.type == "cuda":
                 on_device = self._factorize_device(flat, dev)
                 if on_device is not None:
                     factorized = on_device[:2]
@@ -359,5 +364,20 @@ class MELD(GraphEstimator):
     def fit_transform(self, X, sample_labels, **kwargs):
         """Builds the graph on ``X`` and estimates the density of each sample in
         ``sample_labels`` (reference ``meld/meld.py:252-274``)."""
+        # the labels are factorised first: on the device path that is a few small launches and two read-backs, which
+        # cost a millisecond of host latency behind a finished graph build and nothing in front of it
+        self._prefactored = None
+        try:
+            raw = np.asarray(getattr(sample_labels, "values", sample_labels))
+            if (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
+                    and torch.cuda.is_available() and not isinstance(X, str):
+                fz = self._factorize_device(raw.reshape(-1), torch.device("cuda", torch.cuda.current_device()))
+                if fz is not None:
+                    self._prefactored = (sample_labels, fz)
+        except Exception:  # (anything unusual about the labels is reported by transform's own checks)
+            self._prefactored = None
         self.fit(X, **kwargs)
-        return self.transform(sample_labels)
+        try:
+            return self.transform(sample_labels)
+        finally:
+            self._prefactored = None

@@ -54,6 +54,16 @@ def _chain_order(P):
     return _chain_order_batched(P[None])[0]
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _split_level(X, lib, st, group, n_groups, fanout):
     """One refinement level: every group of cells gets `fanout` sub-centroids (evenly spaced
     members), every cell its nearest one.  Returns (child id within group [N] int64, rank of each
@@ -69,8 +79,15 @@ def _split_level(X, lib, st, group, n_groups, fanout):
     cents = X.index_select(0, order[pick.reshape(-1)]).contiguous()  # [n_groups * fanout, d]
     child = torch.empty(N, dtype=torch.int32, device=dev)
     g32 = group.to(torch.int32)
+    # the chains over the sub-centroids (one wave per group, a latency-bound walk of <= 64 greedy steps: 0.14-0.27 ms)
+    # do not depend on the assignment of the cells: they run beside it on a second stream
+    main = torch.cuda.current_stream()
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
     check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
-    rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
+    main.wait_stream(side)
     return child.to(torch.int64), rank
 
 
@@ -107,8 +124,13 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0):
     idx1 = torch.from_numpy(np.sort(rng.choice(N, size=c1, replace=False))).to(dev)
     cents1 = X.index_select(0, idx1).contiguous()
     a1 = torch.empty(N, dtype=torch.int32, device=dev)
+    main, side = torch.cuda.current_stream(), _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        rank1 = _chain_order(cents1)  # (one wave, 63 dependent steps: hidden behind the assignment)
     check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents1), c1, None, None, ptr(a1), st), "meld_assign_nearest")
-    key = _chain_order(cents1)[a1.to(torch.int64)]  # order of the coarse cell of every point
+    main.wait_stream(side)
+    key = rank1[a1.to(torch.int64)]  # order of the coarse cell of every point
     group = a1.to(torch.int64)
     n_groups = c1
     for f in fanouts:
