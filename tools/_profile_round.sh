@@ -1,12 +1,37 @@
 #!/bin/bash
-# Round profile set (run on the GPU box): bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3)
-# usage: bash tools/_profile_round.sh r02
-tag=${1:-r02}; out=gpurun_out/prof_$tag; mkdir -p $out; export TMPDIR=/tmp
+# Evidence set of a round, all from ONE build (run on the GPU box; .git does not travel, so the commit is passed in):
+#   gpurun -- 'bash tools/_profile_round.sh r03 <commit> [quick]'
+# bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3), fabric traffic (PMC) of the hot kernels,
+# PMC passes over the search and the recurrence kernels, the per-wave timeline of a recurrence step, and the full-oracle
+# parity runs at 1M and 500k.  Every file carries the commit; copy gpurun_out/prof_<tag>/* to profiles/.
+tag=${1:-r03}; commit=${2:-unknown}; quick=${3:-}
+out=gpurun_out/prof_$tag; mkdir -p $out/pmc; export TMPDIR=/tmp
+stamp() { echo "# commit $commit, $(date -u +%Y-%m-%dT%H:%MZ), $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"; }
+cpu="--cpu-sample 40000"; [ -z "$quick" ] && cpu=""
 for n in 1000000 500000; do
-  python bench.py --cells $n 2>$out/bench_$n.err > $out/bench_$n.json
+  c=$cpu; [ $n != 1000000 ] && c="--cpu-sample 0"
+  python bench.py --cells $n $c 2>$out/bench_$n.err > $out/bench_$n.json
+  python - $out/bench_$n.json $commit <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); d["commit"] = sys.argv[2]
+open(sys.argv[1], "w").write(json.dumps(d) + "\n")
+PY
   (cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/trace_$n -o t -- python $OLDPWD/bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input > $OLDPWD/$out/trace_${n}_stdout.log 2>&1)
   db=$(ls $out/trace_$n/*.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/kernel_stats_$n.md
-  rm -rf $out/trace_$n   # (the rocpd database is ~50 MB; gpurun_out is capped at 64 MiB)
+  [ -n "$db" ] && { stamp; echo "# rocprofv3 --kernel-trace --stats -- python bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input"; python tools/rocpd_summary.py $db; } > $out/kernel_stats_$n.md
+  rm -rf $out/trace_$n $out/trace_${n}_stdout.log   # (the rocpd database is ~50 MB; gpurun_out is capped at 64 MiB)
+  python tools/pmc_traffic.py --cells $n --out $out/pmc/traffic.json > /dev/null 2>&1
 done
-ls -la $out
+python - $out/pmc/traffic.json $commit <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for v in d.values():
+    if isinstance(v, dict): v["commit"] = sys.argv[2]
+json.dump(d, open(sys.argv[1], "w"), indent=1, sort_keys=True)
+PY
+{ stamp; bash tools/pmc_knn.sh gpurun_out/pmc_knn_$tag 1000000 2>&1 | grep -v "^pass"; } > $out/pmc/knn16_pmc_summary.txt
+{ stamp; bash tools/pmc_spmm.sh gpurun_out/pmc_spmm_$tag 1000000 0 2>&1 | grep -v "^pass\|^saved"; } > $out/pmc/spmm_pmc_summary.txt
+rm -rf gpurun_out/pmc_knn_$tag gpurun_out/pmc_spmm_$tag
+{ stamp; python tools/save_graph.py 1000000 /tmp/g1m.pt > /dev/null; for p in 2 1; do echo "## p = $p"; python tools/spmm_stamps.py /tmp/g1m.pt $p 2>/dev/null; done; python tools/spmm_time.py /tmp/g1m.pt 2>/dev/null | grep "tiled p\|lanczos"; } > $out/recurrence_step_timeline.txt
+{ stamp; for n in 1000000 500000; do echo "## N = $n"; python tools/parity_200k.py $n 2>&1 | grep -v amdgpu.ids; done; } > $out/full_oracle_parity.txt
+ls -la $out $out/pmc
