@@ -241,9 +241,9 @@ class VertexFrequencyCluster:
 
         self.graph = utils._check_pygsp_graph(G)
         G = self.graph
-        if G.n_rows != G.N:
-            raise ValueError("VertexFrequencyCluster needs an unsharded graph")
         self.method_ = self.method if self.method != "auto" else ("dense" if G.N <= DENSE_MAX_N else "filterbank")
+        if G.n_rows != G.N and self.method_ != "filterbank":
+            raise ValueError("the dense VertexFrequencyCluster needs an unsharded graph (method='filterbank' runs row-sharded)")
         if self.method_ == "filterbank":
             return self._fit_filterbank(G)
         if G.N > DENSE_MAX_N:
@@ -327,9 +327,24 @@ class VertexFrequencyCluster:
 
         dev, n = G.val.device, G.N
         ops = _ops_of(G)
+        # Row-sharded graph (meld_amd.distributed): this rank holds the rows [r0, r0 + nl) of the padded cell range
+        # [0, npad).  The tall arrays of the method (probes, their filtered images, Ritz vectors, moments) are LOCAL
+        # rows; what crosses ranks is the iterate of the recurrence (an all-gather per SpMM, as in MELD's own filter)
+        # and R x R matrices (Gram matrices of the CholeskyQR, Rayleigh-Ritz, the deflation: one all-reduce each).
+        comm = getattr(G, "comm", None)
+        npad, r0, nl, nreal = int(G.n_pad), int(G.row_begin), int(G.rows_pad), int(G.n_rows)
+
+        def allsum(t):
+            return comm.all_reduce_sum(t) if comm is not None else t
+
+        def gram(A, B):
+            return allsum(_tall_gram(A, B))
+
         lmax = float(G.lmax)
-        kdiag = G.kernel_diagonal()[:n]
-        dbar = float((G.dw_dev[:n] + kdiag).mean())  # mean row sum of the kernel: P = I - D^-1 L
+        kdiag = G.kernel_diagonal()
+        kdiag = kdiag[r0 : r0 + nreal] if kdiag.shape[0] != nreal else kdiag
+        dsum = allsum((G.dw_dev[:nreal] + kdiag).sum().reshape(1).clone())
+        dbar = float(dsum) / n  # mean row sum of the kernel: P = I - D^-1 L
         self._fb = dict(lmax=lmax, dbar=dbar)
         t_max = float(np.max(self.window_sizes))
         M = self.chebyshev_order
@@ -355,32 +370,48 @@ class VertexFrequencyCluster:
         R = int(min(self.n_probes, n))
         gen = torch.Generator(device=dev)
         gen.manual_seed(0 if self.random_state is None else int(self.random_state))
-        Z = (torch.randint(0, 2, (n, R), device=dev, generator=gen, dtype=torch.int8).to(torch.float64) * 2.0 - 1.0).contiguous()
+        # (every rank draws the same [n, R] signs and keeps its rows; padding rows stay zero through the recurrence)
+        Zall = torch.randint(0, 2, (n, R), device=dev, generator=gen, dtype=torch.int8)
+        Z = torch.zeros(nl, R, dtype=torch.float64, device=dev)
+        Z[:nreal] = Zall[r0 : r0 + nreal].to(torch.float64) * 2.0 - 1.0
+        del Zall
         a1 = a2 = lmax / 2.0
         from .graph import _EventSpan
 
         # The recurrence kernel takes the iterate two columns at a time.  Handed [n, R] row-major, every launch would
         # gather 16 bytes out of each 8 R-byte row (1M cells, R = 64: 248 us per launch instead of 110); the iterates
-        # are therefore kept PAIR-MAJOR, [R / 2][n][2], each pair a contiguous [n, 2] array like MELD's own signal, and
-        # turned into [n, R] once per step for the dense algebra of `visit` (a 2 x 8 n R-byte copy).
+        # are therefore kept PAIR-MAJOR, [R / 2][npad][2], each pair a contiguous [npad, 2] array like MELD's own signal,
+        # and the local rows are turned into [nl, R] once per step for the dense algebra of `visit`.
         Rp = R + (R & 1)
 
-        def to_pairs(A):  # [n, R] -> [Rp / 2, n, 2]
-            if Rp != R:
-                A = torch.cat([A, torch.zeros(n, 1, dtype=A.dtype, device=dev)], dim=1)
-            return A.view(n, Rp // 2, 2).permute(1, 0, 2).contiguous()
+        def local(T):  # rows of this rank of a full-length pair-major iterate
+            return T[:, r0 : r0 + nl]
 
-        def from_pairs(T):  # [Rp / 2, n, 2] -> [n, R]
-            return T.permute(1, 0, 2).reshape(n, Rp)[:, :R]
+        def to_pairs(A):  # local [nl, R] -> full-length [Rp / 2, npad, 2] (gathered from every rank)
+            if Rp != R:
+                A = torch.cat([A, torch.zeros(nl, 1, dtype=A.dtype, device=dev)], dim=1)
+            P = A.view(nl, Rp // 2, 2).permute(1, 0, 2).contiguous()
+            if comm is None:
+                return P
+            T = torch.zeros(Rp // 2, npad, 2, dtype=A.dtype, device=dev)
+            for i in range(Rp // 2):
+                comm.all_gather_rows(T[i], P[i])
+            return T
+
+        def from_pairs(T):  # full-length [Rp / 2, npad, 2] -> local [nl, R]
+            return local(T).permute(1, 0, 2).reshape(nl, Rp)[:, :R]
 
         def spmm(t_in, t_zy, alpha, beta, gamma):
             with _EventSpan("vfc_spmm", N=n, p=R, nnz=G.nnz):
                 for i in range(Rp // 2):
-                    ops.cheby_step(G, 2, t_in[i], 0, t_zy[i] if gamma != 0.0 else None, t_zy[i], None, alpha, beta, gamma, 0.0)
+                    y_loc = t_zy[i, r0 : r0 + nl]
+                    ops.cheby_step(G, 2, t_in[i], r0, y_loc if gamma != 0.0 else None, y_loc, None, alpha, beta, gamma, 0.0)
+                    if comm is not None:
+                        comm.all_gather_rows(t_zy[i], y_loc)
 
         def recurrence(Z0, visit):
-            """visit(k, T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, R columns as R / 2 pairs)."""
-            t_old, t_cur = to_pairs(Z0), torch.empty(Rp // 2, n, 2, dtype=torch.float64, device=dev)
+            """visit(k, local rows of T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, R columns as R / 2 pairs)."""
+            t_old, t_cur = to_pairs(Z0), torch.zeros(Rp // 2, npad, 2, dtype=torch.float64, device=dev)
             visit(0, Z0)
             spmm(t_old, t_cur, 1.0 / a1, -a2 / a1, 0.0)
             visit(1, from_pairs(t_cur))
@@ -390,15 +421,18 @@ class VertexFrequencyCluster:
                 t_old, t_cur = t_cur, t_old
 
         def orthonormalise(Y):
-            """Q with orthonormal columns spanning those of Y [n, R]: CholeskyQR2 -- two rounds of (Gram matrix, Cholesky
-            factor, triangular solve), all tall-skinny GEMMs and R x R factorisations (on a row-sharded graph the Gram
-            matrix is the only thing that crosses ranks).  The filtered probes are far from orthogonal: if the first
-            factorisation breaks down (condition number beyond ~1e8) the Householder QR of the library takes over."""
+            """Q with orthonormal columns spanning those of Y [rows, R]: CholeskyQR2 -- two rounds of (Gram matrix, Cholesky
+            factor, triangular solve), all tall-skinny GEMMs and R x R factorisations; on a row-sharded graph the Gram
+            matrix (one all-reduce) is the only thing that crosses ranks.  The filtered probes are far from orthogonal:
+            if the first factorisation breaks down (condition number beyond ~1e8) the Householder QR of the library
+            takes over (one GPU only)."""
             Q = Y
             for _ in range(2):
-                Gm = _tall_gram(Q, Q)
+                Gm = gram(Q, Q)
                 Lc, info = torch.linalg.cholesky_ex(0.5 * (Gm + Gm.T))
                 if int(info) != 0:
+                    if comm is not None:
+                        raise RuntimeError("CholeskyQR of the filtered probes broke down on a sharded graph; use fewer probes")
                     Qh, _ = torch.linalg.qr(Y)
                     return Qh.contiguous()
                 # Q <- Q L^-T through the inverse of the small factor (a triangular solve with n right-hand sides asks the
@@ -411,42 +445,50 @@ class VertexFrequencyCluster:
         Y = torch.zeros_like(Z)
         recurrence(Z, lambda k, Tk: Y.add_(Tk, alpha=float(c_phi[k])))
         Q = orthonormalise(Y)
-        qp, lqp = to_pairs(Q), torch.empty(Rp // 2, n, 2, dtype=torch.float64, device=dev)
+        qp, lqp = to_pairs(Q), torch.zeros(Rp // 2, npad, 2, dtype=torch.float64, device=dev)
         spmm(qp, lqp, 1.0, 0.0, 0.0)  # L Q
         LQ = from_pairs(lqp)
-        H = _tall_gram(Q, LQ)
+        H = gram(Q, LQ)
         theta, V = torch.linalg.eigh(0.5 * (H + H.T))
-        Ur = Q @ V  # approximate eigenvectors [n, R]
+        Ur = Q @ V  # approximate eigenvectors (local rows) [nl, R]
         theta = theta.clamp(0.0, lmax)
         Cd = torch.from_numpy(Cm).to(dev)
         # p_tb(theta_i) by the Clenshaw-free direct sum (R values, M + 1 terms)
         xt = (2.0 * theta / lmax - 1.0).clamp(-1.0, 1.0)
         Tm = torch.cos(torch.arange(M + 1, device=dev, dtype=torch.float64)[:, None] * torch.acos(xt)[None, :])  # [M+1, R]
         Pth = (Cd @ Tm).clamp_(min=0.0)  # [T*B, R]
-        E_low = (Ur * Ur) @ Pth.T  # [n, T*B]
+        E_low = (Ur * Ur) @ Pth.T  # [nl, T*B]
         # pass 2: Hutchinson on the deflated operator
-        Zd = Z - Q @ _tall_gram(Q, Z)
-        mom = torch.empty(M + 1, n, dtype=torch.float64, device=dev)
+        Zd = Z - Q @ gram(Q, Z)
+        mom = torch.empty(M + 1, nl, dtype=torch.float64, device=dev)
 
         def visit2(k, Tk):
-            W = Tk - Q @ _tall_gram(Q, Tk)
+            W = Tk - Q @ gram(Q, Tk)
             torch.mean(Z * W, dim=1, out=mom[k])
 
         recurrence(Zd, visit2)
         T, B = len(self.window_sizes), self.n_bands
-        E_res = (Cd @ mom).T.contiguous().view(n, T, B).clamp_(min=0.0)  # band energies outside the Ritz subspace
-        E_lowb = E_low.view(n, T, B)
-        tot = (E_lowb + E_res).sum(2)  # [n, T]: [p_t(L)]_jj, the squared norm of vertex j's window signature
+        E_res = (Cd @ mom).T.contiguous().view(nl, T, B).clamp_(min=0.0)  # band energies outside the Ritz subspace
+        E_lowb = E_low.view(nl, T, B)
+        tot = (E_lowb + E_res).sum(2)  # [nl, T]: [p_t(L)]_jj, the squared norm of vertex j's window signature
         tot = torch.where(tot > 0, tot, torch.ones_like(tot))
         # columns 0 .. R-1: the Ritz vectors, each treated like a frequency of the reference spectrogram --
         # sum_t tanh(|u_i[j]| h_t(theta_i) / norm_t[j]); columns R ..: what is left per band, as amplitudes
         pt_theta = Pth.view(T, B, R).sum(1).clamp_(min=0.0)  # [T, R]: p_t(theta_i)
-        ritz_feat = torch.zeros(n, R, dtype=torch.float64, device=dev)
+        ritz_feat = torch.zeros(nl, R, dtype=torch.float64, device=dev)
         absU = Ur.abs()
         for ti in range(T):
             ritz_feat += torch.tanh(absU * torch.sqrt(pt_theta[ti])[None, :] / torch.sqrt(tot[:, ti])[:, None])
-        res_feat = torch.tanh(torch.sqrt(E_res / tot[:, :, None])).sum(1)  # [n, B]
-        self._fb_spectrogram = torch.cat([ritz_feat, res_feat], dim=1)  # [n, R + B], internal cell order
+        res_feat = torch.tanh(torch.sqrt(E_res / tot[:, :, None])).sum(1)  # [nl, B]
+        spec = torch.cat([ritz_feat, res_feat], dim=1).contiguous()  # local rows [nl, R + B], internal cell order
+        if comm is not None:  # every rank ends up with the whole spectrogram (transform / predict are host-side)
+            full = torch.empty(npad, spec.shape[1], dtype=spec.dtype, device=dev)
+            comm.all_gather_rows(full, spec)
+            spec = full[:n]
+            tot_full = torch.empty(npad, tot.shape[1], dtype=tot.dtype, device=dev)
+            comm.all_gather_rows(tot_full, tot.contiguous())
+            tot = tot_full[:n]
+        self._fb_spectrogram = spec  # [n, R + B]
         self._fb["window_norm2"] = tot
         self._fb["ritz"] = theta
         self.eigenvectors = None
