@@ -320,6 +320,7 @@ def main():
             "traffic": (measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch"),
             "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
+            "traffic_commit": (measured_traffic("knn16_topk", N, d) or {}).get("commit"),
             "algorithmic": "2*Nq*N*d = {:.3e} flop per launch".format(flops),
             "algorithmic_equiv_tflops": flops / t_knn / 1e12,
             "algorithmic_equiv_frac_of_peak": flops / t_knn / 1e12 / peak,
@@ -340,7 +341,7 @@ def main():
         byts = cheby_bytes_per_step(G.nnz, rows, p)
         tiled = G.info.get("spmm") == "tiled"
         out["roofline_cheby"] = {
-            "kernel": ("pt_step_kernel<P=2> (panel-tiled Laplacian recurrence, iterate staged in LDS)" if tiled else
+            "kernel": ("pt_step_kernel<P=2> (panel-tiled, symmetry-folded Laplacian recurrence, iterate staged in LDS)" if tiled else
                        "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence)") + ", {} launches".format(steps),
             "bound": "hbm",
             "achieved": byts * steps / t_ch / 1e9,
@@ -350,6 +351,7 @@ def main():
             "traffic": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get("bytes_per_launch"),
             "traffic_note": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json)"),
+            "traffic_commit": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get("commit"),
             "algorithmic": "{} B per launch (12*nnz + 4(N+1) + 8N + 40*N*p)".format(byts),
             "us_per_launch": 1e6 * t_ch / steps,
         }
