@@ -261,6 +261,14 @@ int meld_csr_from_keys(const uint64_t* ukeys, int64_t nnz, int64_t row_begin, in
  * caller must use the sort-based calls above, whose summation order is defined), and after an exclusive scan of ucnt
  * (rowptr) meld_csr_compact_rows copies the merged buckets to their final place.  Entries whose row lies outside
  * [row_begin, row_begin + n_rows) are ignored. */
+/* Row-sharded build: the transposed entries this rank owes to the other ranks (owner of key k = (k >> 32) / rows_per_rank,
+ * clipped to world - 1; entries of self_rank are left out: the caller hands its whole transposed array to
+ * meld_coo_scatter_rows, which ignores foreign rows) laid out for ONE equal-split all-to-all with no host round trip:
+ * send[world][2][cap] int64 -- [o][0][slot] keys, [o][1][slot] the bits of the values; unused slots hold the key ~0, a row
+ * outside every slice.  counts[world] (int32) ends as the number of entries owed to each rank, fitted or not: a count above
+ * cap means the caller must fall back to a variable-length exchange. */
+int meld_coo_partition_remote(const uint64_t* keys, const double* vals, int64_t n, int64_t rows_per_rank, int world,
+                              int self_rank, int64_t cap, int32_t* counts, int64_t* send, meld_stream_t stream);
 int meld_csr_bucket_slots(void);
 int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
                           int32_t* cursor, int32_t* tcol, double* tval, meld_stream_t stream);
@@ -321,6 +329,19 @@ int meld_lanczos_alpha(double* state, const double* dots, double* nrm2, double* 
 int meld_lanczos_axpy(const double* x_local, double* y_local, int64_t n_rows, const double* state, double* nrm2,
                       meld_stream_t stream);
 int meld_lanczos_beta(double* state, const double* nrm2, double* dots, double* betas, int it, meld_stream_t stream);
+/* One-reduction form of the sharded iteration (one all-reduce + one all-gather per iteration instead of two + one):
+ * the iterate stays un-normalised, u_{k+1} = w_k, so meld_lanczos_spmv (with state[3] = 1, state[4] = 0) computes
+ * z = L u_k without a scalar and adds the partial sums of <z, u_k> to acc[0 .. slots); meld_lanczos_axpy3 of the previous
+ * iteration has added |u_k|^2 to acc[2 slots .. 3 slots).  The caller all-reduces acc (3 * slots doubles, ONCE), then
+ *   meld_lanczos_fold:  alpha_k = <z, u_k> / |u_k|^2 -> alphas[it]; n_k = |u_k| -> betas[it - 1] (it > 0); coefficients
+ *                       of the update into state[5..7], n_k into state[2]; acc zeroed;
+ *   meld_lanczos_axpy3: y <- y / n_k - (alpha_k / n_k) u - (n_k / n_{k-1}) u_prev  (= u_{k+1}, local rows, in place of z)
+ *                       and acc[2 slots ..) += |u_{k+1}|^2 (pass nrm2 = acc + 2 * slots).
+ * Before iteration 0: acc[2 slots ..) holds the partial sums of |u_0|^2, the rest of acc and state[2] are zero.
+ * beta_{k} (= n_{k+1}) is written one iteration late. */
+int meld_lanczos_fold(double* state, double* acc, double* alphas, double* betas, int it, meld_stream_t stream);
+int meld_lanczos_axpy3(double* y_local, const double* u_local, const double* u_prev_local, int64_t n_rows,
+                       const double* state, double* nrm2, meld_stream_t stream);
 int meld_scale_f64(const double* x, double a, double* r, int64_t n, meld_stream_t stream);
 /* y = a * x + b * y  (n doubles) -- Lanczos vector update.  If nrm2 != NULL it receives
  * meld_spmm_dot_slots() partial sums of <y, y> (zeroed by the call; the caller adds them up). */

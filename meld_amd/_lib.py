@@ -72,6 +72,7 @@ SIGNATURES = {
     "meld_csr_from_keys": (_i32, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
     "meld_csr_bucket_slots": (_i32, []),
     "meld_coo_scatter_rows": (_i32, [_ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
+    "meld_coo_partition_remote": (_i32, [_ptr, _ptr, _i64, _i64, _i32, _i32, _i64, _ptr, _ptr, _ptr]),
     "meld_csr_rows_sort_merge": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_compact_rows": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),
@@ -86,6 +87,8 @@ SIGNATURES = {
     "meld_lanczos_alpha": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_lanczos_axpy": (_i32, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_lanczos_beta": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "meld_lanczos_fold": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "meld_lanczos_axpy3": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_pt_geometry": (_i32, [_ptr, _ptr, _ptr, _ptr]),
     "meld_pt_num_blocks": (_i32, [_i64]),
     "meld_pt_seg_len": (_i64, [_i32]),

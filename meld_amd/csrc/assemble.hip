@@ -305,6 +305,43 @@ __global__ __launch_bounds__(256) void coo_scatter_rows_kernel(const unsigned lo
   }
 }
 
+// Row-sharded symmetrisation without a host round trip: the transposed entries a rank owes to the OTHER ranks go into a
+// fixed-capacity send buffer, one segment of `cap` slots per owner (owner = row / rows_per_rank), keys and values of a
+// segment next to each other -- send[o][0][slot] = key, send[o][1][slot] = value bits -- so that ONE equal-split
+// all-to-all moves everything.  Unused slots keep the sentinel key ~0 (row 2^32 - 1: outside every slice, ignored by
+// coo_scatter_rows_kernel).  counts[o] ends as the number of entries rank o is owed, whether they fitted or not.
+__global__ __launch_bounds__(256) void coo_partition_remote_kernel(const unsigned long long* __restrict__ keys,
+                                                                   const double* __restrict__ vals, int64_t n,
+                                                                   int64_t rows_per_rank, int world, int self_rank, int64_t cap,
+                                                                   int* __restrict__ counts, long long* __restrict__ send) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int owner = -1;
+  unsigned long long k = 0;
+  if (e < n) {
+    k = keys[e];
+    const int o = (int)min((int64_t)(k >> 32) / rows_per_rank, (int64_t)world - 1);
+    if (o != self_rank) owner = o;
+  }
+  unsigned long long todo = __ballot(owner >= 0);
+  while (todo) {  // one atomic per owner present in the wave
+    const int lead = __ffsll((long long)todo) - 1;
+    const int o = __shfl(owner, lead, 64);
+    const unsigned long long mine = __ballot(owner == o);
+    int base = 0;
+    if (lane == lead) base = atomicAdd(counts + o, __popcll(mine));
+    base = __shfl(base, lead, 64);
+    if (owner == o) {
+      const int64_t slot = base + __popcll(mine & ((1ull << lane) - 1ull));
+      if (slot < cap) {
+        send[((int64_t)o * 2 + 0) * cap + slot] = (long long)k;
+        send[((int64_t)o * 2 + 1) * cap + slot] = __double_as_longlong(vals[e]);
+      }
+    }
+    todo &= ~mine;
+  }
+}
+
 template <int SL>
 __device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], int lane) {
   constexpr int NE = 64 * SL;
@@ -463,6 +500,21 @@ extern "C" int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, i
   hipLaunchKernelGGL(coo_scatter_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, S(stream),
                      reinterpret_cast<const unsigned long long*>(keys), vals, n, row_begin, n_rows, cursor, tcol, tval);
   MELD_LAUNCH_CHECK("coo_scatter_rows_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_coo_partition_remote(const uint64_t* keys, const double* vals, int64_t n, int64_t rows_per_rank, int world,
+                                         int self_rank, int64_t cap, int32_t* counts, int64_t* send, meld_stream_t stream) {
+  MELD_CHECK_ARG(counts && send && n >= 0 && (n == 0 || (keys && vals)) && rows_per_rank > 0 && world >= 1 && self_rank >= 0 &&
+                     self_rank < world && cap >= 0,
+                 "meld_coo_partition_remote: bad arguments");
+  MELD_HIP_CALL(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)world, S(stream)));
+  if (cap > 0) MELD_HIP_CALL(hipMemsetAsync(send, 0xFF, sizeof(int64_t) * 2 * (size_t)world * (size_t)cap, S(stream)));
+  if (n == 0) return MELD_OK;
+  hipLaunchKernelGGL(coo_partition_remote_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const unsigned long long*>(keys), vals, n, rows_per_rank, world, self_rank, cap, counts,
+                     reinterpret_cast<long long*>(send));
+  MELD_LAUNCH_CHECK("coo_partition_remote_kernel");
   return MELD_OK;
 }
 

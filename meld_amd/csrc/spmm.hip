@@ -293,6 +293,49 @@ __global__ __launch_bounds__(64) void lanczos_beta_kernel(double* __restrict__ s
   }
 }
 
+// One-reduction form of the iteration for the row-sharded driver.  With u_k = w_{k-1} kept un-normalised
+// (v_k = u_k / n_k, n_k = |u_k| = beta_{k-1}) the SpMV z = L u_k needs no scalar, and both sums of an iteration --
+// <z, u_k> (SpMV) and |u_k|^2 (accumulated by the axpy that formed u_k) -- sit in one buffer acc = dots (2 slots
+// blocks) | nrm2 (1 block), so ONE all-reduce per iteration serves both:  alpha_k = <z, u_k> / |u_k|^2,
+//   u_{k+1} = w_k = z / n_k - (alpha_k / n_k) u_k - (n_k / n_{k-1}) u_{k-1}.
+// |w|^2 is still summed from the vector itself (the shortcut |y|^2 - alpha^2 is unstable); beta_{k-1} = n_k becomes
+// known one iteration late, which only delays the convergence check by one iteration.
+// state: [2] n_{k-1} -> n_k, [5] c1 = 1 / n_k, [6] c2 = -alpha_k / n_k, [7] c3 = -n_k / n_{k-1} (0 at it == 0)
+__global__ __launch_bounds__(64) void lanczos_fold_kernel(double* __restrict__ state, double* __restrict__ acc,
+                                                          double* __restrict__ alphas, double* __restrict__ betas, int it) {
+  const double a = wave_sum(acc[threadIdx.x]);
+  const double b = wave_sum(acc[2 * DOT_SLOTS + threadIdx.x]);
+  acc[threadIdx.x] = 0.0;  // the next SpMV / axpy accumulate into these slots
+  acc[DOT_SLOTS + threadIdx.x] = 0.0;
+  acc[2 * DOT_SLOTS + threadIdx.x] = 0.0;
+  if (threadIdx.x == 0) {
+    const double n = sqrt(b), alpha = a / b, n_prev = state[2];
+    alphas[it] = alpha;
+    if (it > 0) betas[it - 1] = n;
+    state[5] = 1.0 / n;
+    state[6] = -alpha / n;
+    state[7] = it > 0 ? -n / n_prev : 0.0;
+    state[2] = n;
+  }
+}
+__global__ __launch_bounds__(256) void lanczos_axpy3_kernel(double* __restrict__ y, const double* __restrict__ u,
+                                                            const double* __restrict__ u_prev, int64_t n,
+                                                            const double* __restrict__ state, double* __restrict__ nrm2) {
+  __shared__ double s_part[4];
+  const double c1 = state[5], c2 = state[6], c3 = state[7];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = c1 * y[i] + c2 * u[i];
+    if (c3 != 0.0) v += c3 * u_prev[i];
+    y[i] = v;
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&nrm2[blockIdx.x % DOT_SLOTS], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 template <int P, int RB>
 static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows,
                         int ld, int colofs, const double* x_full, int64_t x_row_offset, const double* z, double* y,
@@ -461,6 +504,25 @@ extern "C" int meld_lanczos_beta(double* state, const double* nrm2, double* dots
   MELD_CHECK_ARG(state && nrm2 && dots && betas && it >= 0, "meld_lanczos_beta: bad arguments");
   hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, S(stream), state, nrm2, dots, betas, it, (double*)nullptr);
   MELD_LAUNCH_CHECK("lanczos_beta_kernel");
+  return MELD_OK;
+}
+
+// One-reduction Lanczos iteration (row-sharded driver): acc = [3 * slots] = <z, u> | (unused) | |u|^2 partial sums, summed
+// over the ranks by ONE all-reduce between meld_lanczos_spmv (state[3] = 1, state[4] = 0: z = L u) and this call;
+// meld_lanczos_axpy3 then forms u_{k+1} in place of z and accumulates |u_{k+1}|^2 into acc + 2 * slots.
+extern "C" int meld_lanczos_fold(double* state, double* acc, double* alphas, double* betas, int it, meld_stream_t stream) {
+  MELD_CHECK_ARG(state && acc && alphas && betas && it >= 0, "meld_lanczos_fold: bad arguments");
+  hipLaunchKernelGGL(lanczos_fold_kernel, dim3(1), dim3(64), 0, S(stream), state, acc, alphas, betas, it);
+  MELD_LAUNCH_CHECK("lanczos_fold_kernel");
+  return MELD_OK;
+}
+extern "C" int meld_lanczos_axpy3(double* y_local, const double* u_local, const double* u_prev_local, int64_t n_rows,
+                                  const double* state, double* nrm2, meld_stream_t stream) {
+  MELD_CHECK_ARG(y_local && u_local && u_prev_local && state && nrm2 && n_rows >= 0, "meld_lanczos_axpy3: bad arguments");
+  if (n_rows == 0) return MELD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(2048, ceil_div(n_rows, 256));
+  hipLaunchKernelGGL(lanczos_axpy3_kernel, dim3(grid), dim3(256), 0, S(stream), y_local, u_local, u_prev_local, n_rows, state, nrm2);
+  MELD_LAUNCH_CHECK("lanczos_axpy3_kernel");
   return MELD_OK;
 }
 

@@ -20,6 +20,8 @@ tests inject a NumPy stand-in to exercise exactly this communication code under 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pandas as pd
 import torch
@@ -53,6 +55,15 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
+    def exchange_fixed(self, send, cap):
+        """ONE equal-split all-to-all of the fixed-capacity send buffer [world, 2, cap] (``ops.partition_remote``): no
+        split sizes, hence no host read-back.  Returns (keys, vals) of world * cap slots each; unused slots carry the
+        sentinel key ~0, which the assembly ignores."""
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        r = recv.view(self.world, 2, cap)
+        return r[:, 0, :].reshape(-1), r[:, 1, :].reshape(-1).view(torch.float64)
+
     def exchange_by_owner(self, keys_sorted, vals_sorted, rows_per_rank):
         """keys are (row << 32 | col), sorted; entry e goes to rank row // rows_per_rank.
         Returns the (keys, vals) received from every rank (concatenated)."""
@@ -72,6 +83,20 @@ class Comm:
         dist.all_to_all_single(rk, keys_sorted.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l, group=self.group)
         dist.all_to_all_single(rv, vals_sorted.contiguous(), output_split_sizes=recv_l, input_split_sizes=send_l, group=self.group)
         return rk, rv
+
+
+def exchange_capacity(rows_per_rank, ksel, world):
+    """Slots per peer of the fixed-capacity exchange of transposed entries.  A rank emits at most rows_per_rank * ksel
+    directed entries (ksel candidates per row, typically a third of them survive the kernel threshold), spread over the
+    owners; twice the even share (never more than everything) -- with the cells in locality order most entries stay on
+    their own rank and never enter the exchange.  ``MELD_EXCHANGE_CAP`` overrides (the tests force the fallback with
+    it)."""
+    env = os.environ.get("MELD_EXCHANGE_CAP")
+    if env:
+        return int(env)
+    total = int(rows_per_rank) * int(ksel)
+    cap = min(total, 2 * total // max(world, 1) + 1024)
+    return ((cap + 255) // 256) * 256
 
 
 def shard_range(N, world, rank):
@@ -107,31 +132,51 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
         bw, info = torch.empty(0, dtype=torch.float64, device=dev), dict(ksel=ksel, n_flagged_rows=0, nnz_directed=0)
     M = keys.shape[0] // 2
     direct_k, direct_v = keys[:M], vals[:M]  # rows owned by this rank
-    trans_k, trans_v = ops.sort_pairs(keys[M:].contiguous(), vals[M:].contiguous(), N)  # rows owned by anyone
-    recv_k, recv_v = comm.exchange_by_owner(trans_k, trans_v, R)
-    all_k = torch.cat([direct_k, recv_k])
-    all_v = torch.cat([direct_v, recv_v])
+    trans_k, trans_v = keys[M:].contiguous(), vals[M:].contiguous()  # rows owned by anyone
     rows_here = max(n_loc, 1)
-    rowptr, col, val = ops.assemble_rows(all_k, all_v, r0, rows_here, N)
-    if n_loc == 0:
-        rowptr = torch.zeros(2, dtype=torch.int64, device=dev)
+    cap = exchange_capacity(R, ksel, comm.world)
 
-    # kernel row sums (diag = K_ii = 1 included) of every row, for the anisotropy of remote columns
-    ksum_loc = torch.ones(R, dtype=torch.float64, device=dev)
-    if n_loc > 0:
-        ksum_loc[:n_loc] = ops.row_sums(rowptr, val, n_loc, 1.0)
-    ksum_all = torch.empty(R * comm.world, dtype=torch.float64, device=dev)
-    comm.all_gather_rows(ksum_all, ksum_loc)
-    if n_loc > 0:
-        ops.anisotropy(rowptr, col, val, n_loc, ksum_all, r0, anisotropy)
-        dw = ops.row_sums(rowptr, val, n_loc, 0.0)
-    else:
-        dw = torch.zeros(1, dtype=torch.float64, device=dev)
+    def assemble(fixed):
+        if fixed:
+            # the entries owed to other ranks go out in one equal-split all-to-all (capacity `cap` per peer, no split
+            # sizes to read back); this rank's own transposed entries need no partition: the assembly ignores rows
+            # outside its slice, so the whole array is handed over
+            send, counts = ops.partition_remote(trans_k, trans_v, R, comm.world, comm.rank, cap)
+            over = (counts.to(torch.int64) - cap).clamp_(min=0).sum().reshape(1)  # entries that did not fit (device)
+            recv_k, recv_v = comm.exchange_fixed(send, cap)
+            all_k = torch.cat([direct_k, trans_k, recv_k])
+            all_v = torch.cat([direct_v, trans_v, recv_v])
+            rowptr, col, val = ops.assemble_rows(all_k, all_v, r0, rows_here, N, foreign=True)
+        else:
+            sk, sv = ops.sort_pairs(trans_k, trans_v, N)
+            recv_k, recv_v = comm.exchange_by_owner(sk, sv, R)
+            over = torch.zeros(1, dtype=torch.int64, device=dev)
+            rowptr, col, val = ops.assemble_rows(torch.cat([direct_k, recv_k]), torch.cat([direct_v, recv_v]), r0, rows_here, N)
+        if n_loc == 0:
+            rowptr = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    nnz_loc = torch.tensor([int(col.shape[0]), int(info["n_flagged_rows"])], dtype=torch.int64, device=dev)
-    comm.all_reduce_sum(nnz_loc)
-    info.update(N=N, d=d, knn=knn, nnz=int(col.shape[0]), nnz_global=int(nnz_loc[0]), n_flagged_rows=int(nnz_loc[1]),
-                rows_per_rank=R, row_begin=r0, rows_local=n_loc, world=comm.world)
+        # kernel row sums (diag = K_ii = 1 included) of every row, for the anisotropy of remote columns
+        ksum_loc = torch.ones(R, dtype=torch.float64, device=dev)
+        if n_loc > 0:
+            ksum_loc[:n_loc] = ops.row_sums(rowptr, val, n_loc, 1.0)
+        ksum_all = torch.empty(R * comm.world, dtype=torch.float64, device=dev)
+        comm.all_gather_rows(ksum_all, ksum_loc)
+        if n_loc > 0:
+            ops.anisotropy(rowptr, col, val, n_loc, ksum_all, r0, anisotropy)
+            dw = ops.row_sums(rowptr, val, n_loc, 0.0)
+        else:
+            dw = torch.zeros(1, dtype=torch.float64, device=dev)
+        tot = torch.cat([torch.tensor([int(col.shape[0]), int(info["n_flagged_rows"])], dtype=torch.int64, device=dev), over])
+        comm.all_reduce_sum(tot)
+        return rowptr, col, val, dw, ksum_all, [int(v) for v in tot.tolist()]
+
+    fixed = os.environ.get("MELD_EXCHANGE", "fixed") != "variable" and hasattr(ops, "partition_remote") and cap > 0
+    rowptr, col, val, dw, ksum_all, (nnz_global, n_flagged, n_over) = assemble(fixed)
+    if n_over > 0:  # some rank owed a peer more than the capacity (every rank sees the same total): variable-length exchange
+        rowptr, col, val, dw, ksum_all, (nnz_global, n_flagged, _) = assemble(False)
+    info.update(N=N, d=d, knn=knn, nnz=int(col.shape[0]), nnz_global=nnz_global, n_flagged_rows=n_flagged,
+                rows_per_rank=R, row_begin=r0, rows_local=n_loc, world=comm.world,
+                exchange="fixed" if fixed and n_over == 0 else "variable", exchange_capacity=cap, exchange_overflow=n_over)
     G = DeviceGraph(rowptr, col, val, dw, ksum=ksum_all, anisotropy=anisotropy, row_begin=r0, n_total=N, info=info)
     G.n_rows = n_loc
     G.rows_pad = R

@@ -15,6 +15,8 @@ Host code here only evaluates the M+1 scalar coefficients and sequences kernel l
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -283,6 +285,53 @@ def _lanczos_lmax_phases(G, ops, comm, u0, tol, max_iter, check_every):
     return theta, dict(iterations=it, residual=resid, tol=tol, device_resident=True)
 
 
+def _lanczos_lmax_folded(G, ops, comm, u0, tol, max_iter, check_every):
+    """The sharded iteration with ONE all-reduce: the iterate stays un-normalised (u_{k+1} = w_k), so the SpMV
+    z = L u_k needs no scalar and the sums <z, u_k> (SpMV) and |u_k|^2 (the axpy that formed u_k) travel in one
+    buffer (``meld_lanczos_fold`` / ``meld_lanczos_axpy3``).  Per iteration: SpMV, all-reduce of 3 x slots doubles,
+    a one-wave scalar kernel, the three-term update, all-gather of the new vector -- against two all-reduces in
+    ``_lanczos_lmax_phases``.  beta_k = |u_{k+1}| is known one iteration late, so a batch runs one iteration past
+    the prefix it examines; the prefixes examined and the value returned are those of the other two drivers."""
+    dev, n_pad = G.val.device, G.n_pad
+    slots = ops.dot_slots()
+    V = torch.zeros(3, n_pad, dtype=torch.float64, device=dev)
+    V[1].copy_(u0)
+    state = torch.zeros(8, dtype=torch.float64, device=dev)
+    state[3] = 1.0  # SpMV arguments: z = 1 * L u + 0 * u_prev
+    alphas_d = torch.zeros(max_iter + 1, dtype=torch.float64, device=dev)
+    betas_d = torch.zeros(max_iter + 1, dtype=torch.float64, device=dev)
+    acc = torch.zeros(3 * slots, dtype=torch.float64, device=dev)
+    nrm2 = acc[2 * slots :]
+    u_loc0 = _local(G, V[1])
+    nrm2[0] = torch.dot(u_loc0, u_loc0)
+    it, theta, resid = 0, 0.0, float("inf")  # it = iterations run; prefixes 1 .. it - 1 have their beta
+    examined = 0
+    target = min(4 * check_every, max_iter)
+    while examined < max_iter:
+        while it < min(target + 1, max_iter + 1):
+            k = it
+            u_prev, u, y = V[k % 3], V[(k + 1) % 3], V[(k + 2) % 3]
+            ops.lanczos_spmv(G, u, _local(G, u_prev), _local(G, y), state, acc)
+            if comm is not None:
+                comm.all_reduce_sum(acc)
+            ops.lanczos_fold(state, acc, alphas_d, betas_d, k)
+            ops.lanczos_axpy3(_local(G, y), _local(G, u), _local(G, u_prev), state, nrm2)
+            if comm is not None:
+                comm.all_gather_rows(y, _local(G, y))
+            it += 1
+        ab = torch.stack([alphas_d[:it], betas_d[:it]]).cpu().numpy()  # the one synchronisation per batch
+        alphas, betas = ab[0], ab[1]
+        for k in range(examined + 1, it):  # beta_k = betas[k - 1] was written by iteration k (0-based), i.e. k + 1 <= it
+            done = betas[k - 1] <= 1e-14 * max(abs(alphas[k - 1]), 1e-300) or not np.isfinite(betas[k - 1])
+            if k % check_every == 0 or done or k == max_iter:
+                theta, resid = _ritz_check(alphas[:k], betas[:k], tol)
+                if resid <= tol or done:
+                    return theta, dict(iterations=k, residual=resid, tol=tol, device_resident=True, all_reduces_per_iteration=1)
+        examined = it - 1
+        target = min(examined + check_every, max_iter)
+    return theta, dict(iterations=examined, residual=resid, tol=tol, device_resident=True, all_reduces_per_iteration=1)
+
+
 def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
     """Largest eigenvalue of L = diag(dw) - W by the Lanczos recurrence on the device SpMV.
 
@@ -305,6 +354,8 @@ def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
     max_iter = min(max_iter, G.N)
     if comm is None and hasattr(ops, "lanczos_steps") and G.n_pad == G.N:
         return _lanczos_lmax_device(G, ops, u, tol, max_iter, check_every)
+    if hasattr(ops, "lanczos_fold") and os.environ.get("MELD_LANCZOS_FOLD", "1") != "0":
+        return _lanczos_lmax_folded(G, ops, comm, u, tol, max_iter, check_every)
     if hasattr(ops, "lanczos_spmv"):
         return _lanczos_lmax_phases(G, ops, comm, u, tol, max_iter, check_every)
     nrm = float(torch.linalg.vector_norm(u).item())

@@ -786,10 +786,23 @@ class HipOps:
         check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(keys2), ptr(vals), ptr(vals2), n, end_bit, ptr(tmp), tb, st), "meld_sort_pairs_u64_f64")
         return keys2, vals2
 
-    def assemble_rows(self, keys, vals, row_begin, n_rows, N):
+    def partition_remote(self, keys, vals, rows_per_rank, world, rank, cap):
+        """Row-sharded build: the entries owed to the other ranks in a fixed-capacity send buffer [world, 2, cap] (keys |
+        value bits, sentinel key ~0 in unused slots) and the per-owner counts, all on the device
+        (``meld_coo_partition_remote``)."""
+        dev = keys.device
+        counts = torch.empty(world, dtype=torch.int32, device=dev)
+        send = torch.empty(world * 2 * cap, dtype=torch.int64, device=dev)
+        check(self.lib.meld_coo_partition_remote(ptr(keys), ptr(vals), int(keys.shape[0]), int(rows_per_rank), int(world), int(rank),
+                                                 int(cap), ptr(counts), ptr(send), _stream()), "meld_coo_partition_remote")
+        return send, counts
+
+    def assemble_rows(self, keys, vals, row_begin, n_rows, N, foreign=False):
         """Sum duplicate keys, build the CSR (sorted rows) of the local rows: by row buckets sorted inside one wave
         each (include/meld_hip.h, meld_coo_row_counts ...), or -- for the inputs that path refuses, and with
-        ``MELD_ASSEMBLE=sort`` -- by a global radix sort + reduce-by-key."""
+        ``MELD_ASSEMBLE=sort`` -- by a global radix sort + reduce-by-key.  ``foreign``: the input may hold entries of
+        rows outside the slice (the fixed-capacity exchange of the sharded build: other ranks' rows, sentinel keys);
+        the bucket path ignores them, the sort path drops them first."""
         lib, st, dev = self.lib, _stream(), keys.device
         n = int(keys.shape[0])
         B = int(lib.meld_csr_bucket_slots())
@@ -817,6 +830,11 @@ class HipOps:
                 return rowptr, col, val
             del cursor, ucnt, tcol, tval, rowptr
         self.last_assemble = "sort" if n > 0 else "empty"
+        if foreign and n > 0:
+            rows = keys >> 32  # (the sentinel ~0 is -1 as int64: its row is negative)
+            own = (rows >= row_begin) & (rows < row_begin + n_rows)
+            keys, vals = keys[own].contiguous(), vals[own].contiguous()
+            n = int(keys.shape[0])
         keys2, vals2 = self.sort_pairs(keys, vals, N)
         tb = lib.meld_merge_temp_bytes(max(n, 1))
         tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
@@ -1001,6 +1019,14 @@ class HipOps:
 
     def lanczos_beta(self, state, nrm2, dots, betas, it):
         check(self.lib.meld_lanczos_beta(ptr(state), ptr(nrm2), ptr(dots), ptr(betas), int(it), _stream()), "meld_lanczos_beta")
+
+    # one-reduction form of the sharded iteration (filter._lanczos_lmax_folded)
+    def lanczos_fold(self, state, acc, alphas, betas, it):
+        check(self.lib.meld_lanczos_fold(ptr(state), ptr(acc), ptr(alphas), ptr(betas), int(it), _stream()), "meld_lanczos_fold")
+
+    def lanczos_axpy3(self, y_local, u_local, u_prev_local, state, nrm2):
+        check(self.lib.meld_lanczos_axpy3(ptr(y_local), ptr(u_local), ptr(u_prev_local), int(y_local.shape[0]), ptr(state), ptr(nrm2),
+                                          _stream()), "meld_lanczos_axpy3")
 
     def scale(self, x, a, r):
         check(self.lib.meld_scale_f64(ptr(x), float(a), ptr(r), x.numel(), _stream()), "meld_scale_f64")

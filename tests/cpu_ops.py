@@ -37,7 +37,27 @@ class CpuOps:
         order = torch.argsort(keys, stable=True)
         return keys[order].contiguous(), vals[order].contiguous()
 
-    def assemble_rows(self, keys, vals, row_begin, n_rows, N):
+    def partition_remote(self, keys, vals, rows_per_rank, world, rank, cap):
+        """meld_coo_partition_remote: entries owed to the other ranks, [world, 2, cap] with sentinel keys, + counts."""
+        k, v = keys.numpy(), vals.numpy()
+        owner = np.minimum((k >> 32) // rows_per_rank, world - 1)
+        send = np.full((world, 2, cap), -1, dtype=np.int64)
+        counts = np.zeros(world, dtype=np.int32)
+        for o in range(world):
+            if o == rank:
+                continue
+            sel = np.nonzero(owner == o)[0]
+            counts[o] = sel.shape[0]
+            sel = sel[:cap]
+            send[o, 0, : sel.shape[0]] = k[sel]
+            send[o, 1, : sel.shape[0]] = v[sel].view(np.int64)
+        return torch.from_numpy(send.reshape(-1)), torch.from_numpy(counts)
+
+    def assemble_rows(self, keys, vals, row_begin, n_rows, N, foreign=False):
+        if foreign:  # other ranks' rows and sentinel keys are ignored
+            rows = keys >> 32
+            own = (rows >= row_begin) & (rows < row_begin + n_rows)
+            keys, vals = keys[own], vals[own]
         k = keys.numpy()
         uk, inv = np.unique(k, return_inverse=True)
         uv = np.zeros(uk.shape[0])
@@ -114,6 +134,23 @@ class CpuOps:
         s_cur = st[0]
         st[1], st[2], st[0], st[3], st[4] = s_cur, beta, 1.0 / beta, 1.0 / beta, -beta * s_cur
         dots.zero_()
+
+    # one-reduction form (meld_lanczos_fold / meld_lanczos_axpy3)
+    def lanczos_fold(self, state, acc, alphas, betas, it):
+        st, a = state.numpy(), acc.numpy()
+        s = self.dot_slots()
+        zu, uu = float(a[:s].sum()), float(a[2 * s :].sum())
+        a[:] = 0.0
+        n, alpha, n_prev = np.sqrt(uu), zu / uu, st[2]
+        alphas.numpy()[it] = alpha
+        if it > 0:
+            betas.numpy()[it - 1] = n
+        st[5], st[6], st[7], st[2] = 1.0 / n, -alpha / n, (-n / n_prev if it > 0 else 0.0), n
+
+    def lanczos_axpy3(self, y_local, u_local, u_prev_local, state, nrm2):
+        st, y = state.numpy(), y_local.numpy()
+        y[:] = st[5] * y + st[6] * u_local.numpy() + st[7] * u_prev_local.numpy()
+        nrm2.numpy()[0] += float(y @ y)
 
     def scale(self, x, a, r):
         r.copy_(a * x)

@@ -24,10 +24,17 @@ def main(out_path, n, d, knn, n_labels, n_pca=0):
     op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
     G = op.graph
+    # the same estimate with two all-reduces per iteration (the unfolded phases): every collective again, on every rank
+    os.environ["MELD_LANCZOS_FOLD"] = "0"
+    from meld_amd.filter import lanczos_lmax
+
+    theta2, info2 = lanczos_lmax(G, tol=G.lmax_info["tol"])
+    os.environ["MELD_LANCZOS_FOLD"] = "1"
     np.savez(
         out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, columns=np.asarray(dens.columns, dtype=str),
-        lmax=G.lmax, lanczos_iters=G.lmax_info["iterations"], row_begin=G.row_begin, n_rows=G.n_rows,
-        rowptr=G.rowptr.numpy(), col=G.col.numpy(), val=G.val.numpy(), dw=G.dw_dev.numpy(), nnz_global=G.info["nnz_global"],
+        lmax=G.lmax, lanczos_iters=G.lmax_info["iterations"],
+        lanczos_all_reduces=G.lmax_info.get("all_reduces_per_iteration", 2), theta_unfolded=theta2, iters_unfolded=info2["iterations"], row_begin=G.row_begin, n_rows=G.n_rows,
+        rowptr=G.rowptr.numpy(), col=G.col.numpy(), val=G.val.numpy(), dw=G.dw_dev.numpy(), nnz_global=G.info["nnz_global"], exchange=G.info["exchange"], exchange_overflow=G.info["exchange_overflow"],
     )
     dist.destroy_process_group()
 

@@ -44,6 +44,10 @@ def main(out_path, n, d, knn):
             rk, rv = super().exchange_by_owner(keys_sorted.cpu(), vals_sorted.cpu(), rows_per_rank)
             return rk.to(keys_sorted.device), rv.to(vals_sorted.device)
 
+        def exchange_fixed(self, send, cap):
+            rk, rv = super().exchange_fixed(send.cpu(), cap)
+            return rk.to(send.device), rv.to(send.device)
+
     torch.cuda.set_device(0)
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
@@ -52,6 +56,7 @@ def main(out_path, n, d, knn):
     np.savez(
         out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, lmax=G.lmax, row_begin=G.row_begin, n_rows=G.n_rows,
         nnz_global=G.info["nnz_global"], iters=G.lmax_info["iterations"], device_resident=bool(G.lmax_info.get("device_resident", False)),
+        exchange=G.info["exchange"], all_reduces=G.lmax_info.get("all_reduces_per_iteration", 2),
     )
     dist.destroy_process_group()
 

@@ -25,12 +25,12 @@ def _free_port():
     return p
 
 
-def _run(world, tmp_path, n, d, knn, n_labels, n_pca=0):
+def _run(world, tmp_path, n, d, knn, n_labels, n_pca=0, extra_env=None):
     out = str(tmp_path / "res")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(d), str(knn), str(n_labels), str(n_pca)]
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
@@ -57,6 +57,8 @@ def test_sharded_fit_transform_equals_oracle(world, n, n_labels, d, n_pca, tmp_p
     assert [int(r["row_begin"]) for r in ranks] == [min(i * per_rank, n) for i in range(world)]
     assert [int(r["n_rows"]) for r in ranks] == [max(0, min(n, (i + 1) * per_rank) - min(n, i * per_rank)) for i in range(world)]
     assert W.nnz == G.W.nnz == int(ranks[0]["nnz_global"])
+    # the transposed entries travelled in ONE fixed-capacity all-to-all (no split sizes read back on the host)
+    assert all(str(r["exchange"]) == "fixed" and int(r["exchange_overflow"]) == 0 for r in ranks)
     wtol = 1e-13 if not n_pca else 1e-8  # PCA scores by two different routes (covariance eigh vs full SVD)
     assert abs(W - G.W).max() < wtol
     np.testing.assert_allclose(np.concatenate([r["dw"][: int(r["n_rows"])] for r in ranks]), G.dw, rtol=1e-12 if not n_pca else 1e-8)
@@ -65,6 +67,11 @@ def test_sharded_fit_transform_equals_oracle(world, n, n_labels, d, n_pca, tmp_p
     for r in ranks:
         assert float(r["lmax"]) == float(ranks[0]["lmax"])
     assert abs(float(ranks[0]["lmax"]) / 1.01 - lam) / lam < 5e-5  # default Lanczos tolerance 1e-3: eigenvalue error ~ tol^2
+    # the estimate ran with ONE all-reduce per iteration and stops at the same prefix with the same value as the
+    # two-all-reduce form of the iteration
+    assert int(ranks[0]["lanczos_all_reduces"]) == 1
+    assert int(ranks[0]["lanczos_iters"]) == int(ranks[0]["iters_unfolded"])
+    assert abs(float(ranks[0]["lmax"]) / 1.01 - float(ranks[0]["theta_unfolded"])) < 1e-10 * lam
     # densities: identical on every rank and equal to the oracle with the same lmax
     samples, ind = mo.sample_indicators(labels)
     ref = mo.meld_filter(ind, G, beta=40, chebyshev_order=25, lmax=float(ranks[0]["lmax"]))
@@ -72,6 +79,24 @@ def test_sharded_fit_transform_equals_oracle(world, n, n_labels, d, n_pca, tmp_p
         assert list(r["columns"]) == list(samples)
         assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < (1e-11 if not n_pca else 1e-6)
         np.testing.assert_array_equal(r["dens"], ranks[0]["dens"])
+
+
+def test_exchange_overflow_falls_back_to_the_variable_length_exchange(tmp_path):
+    """A capacity too small for what some rank owes a peer is seen by every rank (the overflow count rides in the build's
+    last all-reduce) and the build repeats the exchange with split sizes: same graph, same densities."""
+    n, d, knn, world = 700, 8, 7, 3
+    ranks = _run(world, tmp_path, n, d, knn, 2, extra_env=dict(MELD_EXCHANGE_CAP="16"))
+    assert all(str(r["exchange"]) == "variable" and int(r["exchange_overflow"]) > 0 for r in ranks)
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    G = mo.build_graph(X, knn=knn, algorithm="brute")
+    W = sparse.vstack([
+        sparse.csr_matrix((r["val"], r["col"], r["rowptr"][: int(r["n_rows"]) + 1]), shape=(int(r["n_rows"]), n)) for r in ranks
+    ]).tocsr()
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() < 1e-13
+    samples, ind = mo.sample_indicators(labels)
+    ref = mo.meld_filter(ind, G, beta=40, chebyshev_order=25, lmax=float(ranks[0]["lmax"]))
+    for r in ranks:
+        assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < 1e-11
 
 
 def test_shard_range_covers_everything():

@@ -584,3 +584,26 @@ def test_lmax_method_is_remembered():
     op.transform(labels)
     assert G.lmax_info["method"] == "lanczos" and abs(G.lmax - lm_lanczos) < 1e-9 * lm_lanczos
     assert lm_arpack > 0
+
+
+@pytest.mark.parametrize("n", [4000, 90000])  # CSR-stream kernel / panel-tiled layout
+def test_one_reduction_lanczos_equals_the_device_resident_loop(n):
+    """The sharded driver's iteration with one all-reduce (meld_lanczos_fold / meld_lanczos_axpy3: un-normalised iterate,
+    beta known one iteration late) stops at the same prefix with the same Ritz value as the single-GPU loop and as the
+    two-all-reduce phases."""
+    meld = _meld()
+    import torch
+
+    from meld_amd import filter as mf
+
+    rng = np.random.default_rng(8)
+    X = rng.normal(size=(n, 6))
+    G = meld.MELD(knn=10, verbose=0).fit(X).graph
+    ops = G.ops
+    idx = torch.arange(G.n_pad, dtype=torch.float64, device=G.val.device)
+    u = torch.frac(torch.sin(idx * 12.9898 + 1.0) * 43758.5453) - 0.5
+    t_dev, i_dev = mf._lanczos_lmax_device(G, ops, u, 1e-3, 300, 5)
+    t_pha, i_pha = mf._lanczos_lmax_phases(G, ops, None, u, 1e-3, 300, 5)
+    t_fld, i_fld = mf._lanczos_lmax_folded(G, ops, None, u, 1e-3, 300, 5)
+    assert i_fld["iterations"] == i_dev["iterations"] == i_pha["iterations"] and i_fld["all_reduces_per_iteration"] == 1
+    assert abs(t_fld - t_dev) < 1e-10 * t_dev and abs(t_pha - t_dev) < 1e-10 * t_dev

@@ -432,6 +432,8 @@ def test_two_ranks_on_one_gpu(tmp_path):
     assert [int(r["row_begin"]) for r in ranks] == [0, -(-((n + 1) // 2) // 256) * 256]  # shards = whole search workgroups
     assert int(ranks[0]["nnz_global"]) == single.graph.nnz
     assert bool(ranks[0]["device_resident"])  # the phase-wise Lanczos ran, not the host loop
+    assert int(ranks[0]["all_reduces"]) == 1  # ... in its one-reduction form
+    assert all(str(r["exchange"]) == "fixed" for r in ranks)  # meld_coo_partition_remote + one equal-split all-to-all
     for r in ranks:
         assert abs(float(r["lmax"]) - single.graph.lmax) <= 1e-9 * single.graph.lmax
         assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
@@ -668,3 +670,34 @@ def test_knn16_reference_slices_merge_to_the_same_rows():
         assert torch.equal(a, b)
     # row 0 of the subset is global row 100: its nearest candidate is itself
     assert int(res[1][0][0, 0]) == 100
+
+
+def test_partition_of_remote_entries_matches_numpy():
+    """meld_coo_partition_remote: every entry owed to another rank lands in that rank's segment exactly once (keys and
+    value bits side by side), own entries are left out, unused slots carry the sentinel key, counts say what was owed
+    even when it did not fit."""
+    import meld_amd
+    from meld_amd.graph import HipOps
+
+    ops = HipOps()
+    rng = np.random.default_rng(3)
+    n, R, world, rank = 200000, 4096, 5, 2
+    rows = rng.integers(0, R * world - 100, n)
+    cols = rng.integers(0, R * world, n)
+    keys = torch.from_numpy((rows << 32) | cols).cuda()
+    vals = torch.from_numpy(rng.normal(size=n)).cuda()
+    owner = np.minimum(rows // R, world - 1)
+    for cap in (65536, 1000):
+        send, counts = ops.partition_remote(keys, vals, R, world, rank, cap)
+        send = send.cpu().numpy().reshape(world, 2, cap)
+        counts = counts.cpu().numpy()
+        for o in range(world):
+            want = np.nonzero(owner == o)[0] if o != rank else np.empty(0, dtype=np.int64)
+            assert counts[o] == want.shape[0]
+            got_k, got_v = send[o, 0], send[o, 1].view(np.float64)
+            used = got_k != -1
+            assert used.sum() == min(want.shape[0], cap)
+            pairs = set(zip(keys.cpu().numpy()[want].tolist(), vals.cpu().numpy()[want].tolist()))
+            assert set(zip(got_k[used].tolist(), got_v[used].tolist())) <= pairs
+            if want.shape[0] <= cap:
+                assert len(set(zip(got_k[used].tolist(), got_v[used].tolist()))) == len(pairs)
