@@ -30,6 +30,8 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace meld {
 namespace pt {
@@ -579,6 +581,57 @@ __global__ __launch_bounds__(1024) void pt_plan_kernel(const int64_t* __restrict
     while (lo < hi) {  // first row index whose prefix reaches the target
       const int64_t mid = (lo + hi) >> 1;
       if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    blk_row[b + 1] = (int32_t)((b == nb - 1) ? n_rows : lo);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t prev = 0;
+    blk_row[0] = 0;
+    for (int b = 0; b < nb; ++b) {
+      int64_t cut = blk_row[b + 1];
+      const int64_t must = n_rows - (int64_t)(nb - 1 - b) * RMAX;
+      cut = max(cut, must);
+      cut = min(cut, prev + RMAX);
+      cut = min(max(cut, prev), n_rows);
+      blk_row[b + 1] = (int32_t)cut;
+      prev = cut;
+    }
+  }
+}
+
+// Time-balanced plan.  A block's time is not its entry count: fitted on the 1M benchmark graph (per-wave stamps,
+// profiles/r03_recurrence_step_timeline.txt) it is 0.361 us per 1000 entries + 1.077 us per 1000 DISTINCT out-of-block
+// columns + 2.84 us per 1000 rows, and with equal entries the block of the sparsest region (rows at the cap, 38 k distinct
+// columns against a mean of 24 k) ends 20 us after the median one.  The distinct count of a block is not known before the
+// blocks are, but the entries that reach further than half a block from their own row are a per-row quantity that tracks
+// it (tools/sim_plan.py: the slowest block of the model falls from 109 to 103 us with weights a deg + 0.7 b far + c).
+// pt_row_weight_kernel writes those weights (integers, 1e-6 us), an exclusive scan turns them into the prefix the plan
+// bisects instead of rowptr.
+constexpr int W_ENTRY = 361, W_FAR = 754, W_ROW = 2840;
+__global__ __launch_bounds__(256) void pt_row_weight_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            int64_t n_rows, int64_t col_base, int win, int32_t* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
+  const int64_t self = col_base + i;
+  int far = 0;
+  for (int64_t e = e0; e < e1; ++e) {
+    const int64_t dlt = (int64_t)col[e] - self;
+    far += (dlt > win || dlt < -win) ? 1 : 0;
+  }
+  const int64_t v = (int64_t)W_ENTRY * (e1 - e0) + (int64_t)W_FAR * far + W_ROW;
+  w[i] = (int32_t)min(v, (int64_t)0x3fffffff);
+}
+__global__ __launch_bounds__(1024) void pt_plan_weighted_kernel(const int64_t* __restrict__ wpre, int64_t n_rows, int nb,
+                                                                int32_t* __restrict__ blk_row) {
+  const int64_t tot = wpre[n_rows];
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    const int64_t target = (tot / nb) * (b + 1) + ((tot % nb) * (b + 1)) / nb;
+    int64_t lo = 0, hi = n_rows;
+    while (lo < hi) {  // first row index whose prefix reaches the target
+      const int64_t mid = (lo + hi) >> 1;
+      if (wpre[mid] < target) lo = mid + 1; else hi = mid;
     }
     blk_row[b + 1] = (int32_t)((b == nb - 1) ? n_rows : lo);
   }
@@ -1235,7 +1288,25 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
     return MELD_OK;
   }
   int32_t* seg = const_cast<int32_t*>(layout->seg);
-  hipLaunchKernelGGL(pt::pt_plan_kernel, dim3(1), dim3(1024), 0, st, rowptr, n_rows, nb, const_cast<int32_t*>(layout->blk_row));
+  // plan: by estimated time when the scratch for the weights fits the (not yet written) value stream, by entries otherwise
+  {
+    static const bool by_entries = getenv("MELD_PT_PLAN") && !strcmp(getenv("MELD_PT_PLAN"), "entries");
+    const size_t scan_bytes = meld_scan_temp_bytes(n_rows);
+    const size_t off_w = sizeof(int64_t) * (size_t)(n_rows + 1), off_t = (off_w + sizeof(int32_t) * (size_t)n_rows + 255) / 256 * 256;
+    if (!by_entries && nb > 1 && off_t + scan_bytes <= sizeof(double) * (size_t)layout->stream_len) {
+      char* scratch = reinterpret_cast<char*>(const_cast<double*>(layout->pval));
+      int64_t* wpre = reinterpret_cast<int64_t*>(scratch);
+      int32_t* w = reinterpret_cast<int32_t*>(scratch + off_w);
+      const int win = (int)std::max<int64_t>(1, n_rows / nb / 2);
+      hipLaunchKernelGGL(pt::pt_row_weight_kernel, dim3((unsigned)ceil_div(n_rows, 256)), dim3(256), 0, st, rowptr, col, n_rows,
+                         col_base, win, w);
+      const int rc = meld_exclusive_scan_i32_i64(w, wpre, n_rows, scratch + off_t, scan_bytes, stream);
+      if (rc != MELD_OK) return rc;
+      hipLaunchKernelGGL(pt::pt_plan_weighted_kernel, dim3(1), dim3(1024), 0, st, wpre, n_rows, nb, const_cast<int32_t*>(layout->blk_row));
+    } else {
+      hipLaunchKernelGGL(pt::pt_plan_kernel, dim3(1), dim3(1024), 0, st, rowptr, n_rows, nb, const_cast<int32_t*>(layout->blk_row));
+    }
+  }
   hipLaunchKernelGGL(pt::pt_build_kernel, dim3(nb), dim3(pt::THREADS), 0, st, rowptr, col, n_cols, col_base, symmetric ? 1 : 0, nb,
                      layout->blk_row, const_cast<int32_t*>(layout->blk_ntile), const_cast<int32_t*>(layout->blk_ndist), seg,
                      const_cast<uint16_t*>(layout->cdesc), const_cast<int32_t*>(layout->list_cols), codes, status);
