@@ -126,11 +126,16 @@ __global__ __launch_bounds__(256) void refine_kernel(
     }
   }
 
-  // rank of each candidate by (dist, idx); the entry with rank == knn is the bandwidth
+  // rank of each candidate by (dist, idx); the entry with rank == knn is the bandwidth.  The list is sorted by
+  // approximate d2, so the candidates that were gathered are a prefix of it: the rest sit at +inf behind every finite
+  // entry (their own rank is never used: their kernel value is 0 and the bandwidth entry, approximate rank <= knn,
+  // is finite), and only the prefix has to be compared against
+  const unsigned long long g0 = __ballot(dist[0] < INFINITY), g1 = __ballot(dist[1] < INFINITY);
+  const int n_fin = g1 ? 64 + (64 - __clzll((long long)g1)) : (g0 ? 64 - __clzll((long long)g0) : 0);
   int rk[2] = {0, 0};
-  const int ne = (n > 64) ? 2 : 1;
+  const int ne = (n_fin > 64) ? 2 : 1;
   for (int e2 = 0; e2 < ne; ++e2) {
-    const int lim = min(64, n - 64 * e2);
+    const int lim = min(64, n_fin - 64 * e2);
     for (int l2 = 0; l2 < lim; ++l2) {
       const double de = __shfl(dist[e2], l2, 64);
       const int ie = __shfl(idx[e2], l2, 64);

@@ -611,17 +611,26 @@ __global__ __launch_bounds__(1024) void pt_plan_kernel(const int64_t* __restrict
 constexpr int W_ENTRY = 361, W_FAR = 754, W_ROW = 2840;
 __global__ __launch_bounds__(256) void pt_row_weight_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                             int64_t n_rows, int64_t col_base, int win, int32_t* __restrict__ w) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const int64_t e0 = rowptr[i], e1 = rowptr[i + 1];
-  const int64_t self = col_base + i;
+  // 16 lanes per row: a row's entries (16-30 on a kNN graph) are one or two coalesced reads
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
   int far = 0;
-  for (int64_t e = e0; e < e1; ++e) {
-    const int64_t dlt = (int64_t)col[e] - self;
-    far += (dlt > win || dlt < -win) ? 1 : 0;
+  int64_t e0 = 0, e1 = 0;
+  if (i < n_rows) {
+    e0 = rowptr[i];
+    e1 = rowptr[i + 1];
+    const int64_t self = col_base + i;
+    for (int64_t e = e0 + sub; e < e1; e += 16) {
+      const int64_t dlt = (int64_t)col[e] - self;
+      far += (dlt > win || dlt < -win) ? 1 : 0;
+    }
   }
-  const int64_t v = (int64_t)W_ENTRY * (e1 - e0) + (int64_t)W_FAR * far + W_ROW;
-  w[i] = (int32_t)min(v, (int64_t)0x3fffffff);
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) far += __shfl_xor(far, off, 64);
+  if (i < n_rows && sub == 0) {
+    const int64_t v = (int64_t)W_ENTRY * (e1 - e0) + (int64_t)W_FAR * far + W_ROW;
+    w[i] = (int32_t)min(v, (int64_t)0x3fffffff);
+  }
 }
 __global__ __launch_bounds__(1024) void pt_plan_weighted_kernel(const int64_t* __restrict__ wpre, int64_t n_rows, int nb,
                                                                 int32_t* __restrict__ blk_row) {
@@ -1298,7 +1307,7 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
       int64_t* wpre = reinterpret_cast<int64_t*>(scratch);
       int32_t* w = reinterpret_cast<int32_t*>(scratch + off_w);
       const int win = (int)std::max<int64_t>(1, n_rows / nb / 2);
-      hipLaunchKernelGGL(pt::pt_row_weight_kernel, dim3((unsigned)ceil_div(n_rows, 256)), dim3(256), 0, st, rowptr, col, n_rows,
+      hipLaunchKernelGGL(pt::pt_row_weight_kernel, dim3((unsigned)ceil_div(n_rows * 16, 256)), dim3(256), 0, st, rowptr, col, n_rows,
                          col_base, win, w);
       const int rc = meld_exclusive_scan_i32_i64(w, wpre, n_rows, scratch + off_t, scan_bytes, stream);
       if (rc != MELD_OK) return rc;
