@@ -24,6 +24,16 @@ __all__ = ["MELD"]
 _FILTER_PARAMS = ("beta", "offset", "order", "solver", "chebyshev_order", "lap_type", "filter")
 
 
+_LABEL_STREAMS = {}
+
+
+def _label_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _LABEL_STREAMS:
+        _LABEL_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _LABEL_STREAMS[key]
+
+
 class MELD(GraphEstimator):
     """MELD operator for filtering signals over a graph.
 
@@ -205,6 +215,13 @@ class MELD(GraphEstimator):
         grouping is verified word by word against one representative row per group (a key collision
         falls back to the host path).  Returns (codes as an int64 device tensor, sorted uniques,
         label counts) or None when the dtype is not eligible."""
+        return MELD._factorize_device_end(MELD._factorize_device_begin(labels, device))
+
+    @staticmethod
+    def _factorize_device_begin(labels, device):
+        """The device half of ``_factorize_device``: everything up to the first value the host has to read, enqueued on
+        the current stream.  ``fit_transform`` runs it on a side stream while the candidate search occupies the main one
+        and reads the results (``_factorize_device_end``) after the graph is built."""
         lab = np.ascontiguousarray(labels)
         if lab.dtype.kind in "US" and lab.dtype.itemsize % 4 == 0 and lab.dtype.itemsize > 0:
             words = lab.view(np.int32).reshape(lab.shape[0], -1)
@@ -212,7 +229,6 @@ class MELD(GraphEstimator):
             words = lab.view(np.int32).reshape(lab.shape[0], -1)
         else:
             return None
-        n = lab.shape[0]
         t = torch.from_numpy(words).to(device)
         key = t[:, 0].to(torch.int64)
         for c in range(1, t.shape[1]):
@@ -222,7 +238,19 @@ class MELD(GraphEstimator):
         # the group's start (a scatter-min over N indices into p slots is an atomic pile-up: 21 ms at 1M, p = 2)
         by_code = torch.argsort(inv, stable=True)
         first = by_code[torch.cumsum(cnt, 0) - cnt]
-        if not bool((t == t[first][inv]).all().item()):
+        ok = (t == t[first][inv]).all()
+        done = torch.cuda.Event()
+        done.record()
+        return dict(lab=lab, inv=inv, cnt=cnt, first=first, ok=ok, done=done, device=device)
+
+    @staticmethod
+    def _factorize_device_end(h):
+        if h is None:
+            return None
+        h["done"].synchronize()
+        torch.cuda.current_stream().wait_event(h["done"])
+        lab, inv, cnt, first, device = h["lab"], h["inv"], h["cnt"], h["first"], h["device"]
+        if not bool(h["ok"].item()):
             return None  # two different labels share a key
         uniques = lab[first.cpu().numpy()]
         order = np.argsort(uniques, kind="stable")  # the p uniques, ordered as np.unique does
@@ -367,17 +395,45 @@ class MELD(GraphEstimator):
         # the labels are factorised first: on the device path that is a few small launches and two read-backs, which
         # cost a millisecond of host latency behind a finished graph build and nothing in front of it
         self._prefactored = None
+        pending, hook = {}, None
         try:
             raw = np.asarray(getattr(sample_labels, "values", sample_labels))
             if (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
                     and torch.cuda.is_available() and not isinstance(X, str):
-                fz = self._factorize_device(raw.reshape(-1), torch.device("cuda", torch.cuda.current_device()))
+                from . import graph as _graph
+
+                dev = torch.device("cuda", torch.cuda.current_device())
+                flat = raw.reshape(-1)
+
+                def hook():
+                    # runs inside the graph build, right after the candidate search has been launched: the copy of the
+                    # labels blocks a host that would otherwise wait for the search, and the launches share the GPU with it
+                    try:
+                        side = _label_stream(dev)
+                        with torch.cuda.stream(side):
+                            pending["h"] = self._factorize_device_begin(flat, dev)
+                    except Exception:  # (anything unusual about the labels is reported by transform's own checks)
+                        pending["h"] = None
+
+                _graph._WHILE_SEARCHING.append(hook)
+        except Exception:
+            hook = None
+        try:
+            self.fit(X, **kwargs)
+        finally:
+            if hook is not None:
+                from . import graph as _graph
+
+                if hook in _graph._WHILE_SEARCHING:  # (no search was launched: small N, a precomputed graph, ...)
+                    _graph._WHILE_SEARCHING.remove(hook)
+        try:
+            if pending.get("h") is not None:
+                try:
+                    fz = self._factorize_device_end(pending["h"])
+                except Exception:
+                    fz = None
                 if fz is not None:
                     self._prefactored = (sample_labels, fz)
-        except Exception:  # (anything unusual about the labels is reported by transform's own checks)
-            self._prefactored = None
-        self.fit(X, **kwargs)
-        try:
             return self.transform(sample_labels)
         finally:
             self._prefactored = None
