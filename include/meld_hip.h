@@ -432,6 +432,17 @@ int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, 
  * starting at the row with the smallest first coordinate: rank[g][i] = position of row i along the chain
  * (orders the centroids of the locality permutation so that consecutive groups are close in space). */
 int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream);
+/* Glue of the ordering levels, one launch each (meld_amd/reorder.py): stable argsort of 32-bit keys below 2^end_bit
+ * (order[i] = index of the i-th smallest key; keys_sorted alongside); starts[g] = first position of key g among the sorted
+ * keys, g = 0 .. n_groups; cents[(g f + c) d ..] = the cell at fraction (c + 1/2) / f of group g's sorted members;
+ * key[i] <- key[i] f + rank[key[i] f + child[i]] (position of the cell's child along its group's chain). */
+size_t meld_argsort_u32_temp_bytes(int64_t n);
+int meld_argsort_u32(const uint32_t* keys, int64_t n, int end_bit, int64_t* order, uint32_t* keys_sorted, void* temp,
+                     size_t temp_bytes, meld_stream_t stream);
+int meld_order_starts(const uint32_t* keys_sorted, int64_t n, int n_groups, int64_t* starts, meld_stream_t stream);
+int meld_order_pick_centroids(const double* X, int64_t N, int d, const int64_t* order, const int64_t* starts, int n_groups, int f,
+                              double* cents, meld_stream_t stream);
+int meld_order_update_keys(uint32_t* key, const int32_t* child, const int32_t* rank, int64_t n, int f, meld_stream_t stream);
 
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */

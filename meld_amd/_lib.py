@@ -107,6 +107,11 @@ SIGNATURES = {
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
+    "meld_argsort_u32_temp_bytes": (_sz, [_i64]),
+    "meld_argsort_u32": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "meld_order_starts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),
+    "meld_order_pick_centroids": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
+    "meld_order_update_keys": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
 }
 
 

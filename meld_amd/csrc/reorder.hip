@@ -8,6 +8,11 @@
 // kernel is its only device-side arithmetic: nearest of a small set of centroids for every cell.
 #include "common.hpp"
 
+#include <rocprim/rocprim.hpp>
+
+#include <cstdlib>
+#include <cstring>
+
 namespace meld {
 
 constexpr int AS_CT = 32;    // centroids per LDS tile
@@ -232,13 +237,220 @@ __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restric
   }
 }
 
+// The same assignment on the matrix pipe: d2(x, c) - |x|^2 = |c|^2 - 2 x.c, the products on v_mfma_f32_32x32x2_f32 (fp32
+// operands and accumulation; 157 TF/s against the ~13 TF/s the LDS-fed FMA loops above reach), |c|^2 as the start value of
+// the accumulators.  One wave = 32 points (rows) x up to 64 centroids (two column blocks) per pass, K two coordinates
+// at a time: lane (j, h) feeds point j's coordinate 2s + h on the A side and centroid j's on the B side.  The minimum
+// of a row is a butterfly over the 32 lanes of its half on keys (ordered value bits, low 6 bits replaced by the centroid
+// index): ties and near-ties (2^-18 relative) go to the lower index -- any assignment gives a valid ordering, it only has
+// to be the same on every run and every rank, which fixed-order fp32 arithmetic is.  Points are taken in `order`
+// (sorted by group) so that a workgroup meets one or two groups; it loads each group's centroids into LDS once and
+// its waves skip the chunks that hold no point of it.
+constexpr int AM_CHUNKS = 4;                   // chunks of 32 points per wave
+constexpr int AM_WG_PTS = 4 * AM_CHUNKS * 32;  // points per workgroup
+typedef float am_f32x16 __attribute__((ext_vector_type(16)));
+template <int NB>  // centroid blocks of 32: n_per_group <= 32 NB
+__global__ __launch_bounds__(256) void assign_nearest_mfma_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                                  const double* __restrict__ cents, int n_per_group,
+                                                                  const int* __restrict__ group,
+                                                                  const int64_t* __restrict__ order, int* __restrict__ out) {
+  // LDS (dynamic, sized for d): s_pi [4][32] int64 | cs [KP][32 NB] centroids, [k][n], zero beyond d / n_per_group |
+  // cn [32 NB] |c|^2 (+inf for the padding columns) | xs [4][32][KP + 1] per wave: the points of the chunk in flight, times -2
+  extern __shared__ __attribute__((aligned(16))) unsigned char am_lds[];
+  const int KP = (d + 1) & ~1, XS = KP + 1;
+  int64_t(*s_pi)[32] = reinterpret_cast<int64_t(*)[32]>(am_lds);
+  float(*cs)[32 * NB] = reinterpret_cast<float(*)[32 * NB]>(am_lds + 4 * 32 * 8);
+  float* cn = reinterpret_cast<float*>(am_lds + 4 * 32 * 8) + KP * 32 * NB;
+  float* xs = cn + 32 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * AM_WG_PTS;
+  const int n_here = (int)min((int64_t)AM_WG_PTS, N - p0);
+  int g_lo = 0, g_hi = 0;
+  if (group) {  // positions are sorted by group: the workgroup's groups are a range
+    g_lo = group[order ? order[p0] : p0];
+    g_hi = group[order ? order[p0 + n_here - 1] : p0 + n_here - 1];
+  }
+  // this lane's point in each of the wave's chunks
+  int64_t pi[AM_CHUNKS];
+  int pg[AM_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < AM_CHUNKS; ++c) {
+    const int rel = (w * AM_CHUNKS + c) * 32 + j;
+    pi[c] = rel < n_here ? (order ? order[p0 + rel] : p0 + rel) : -1;
+    pg[c] = (pi[c] >= 0 && group) ? group[pi[c]] : (pi[c] >= 0 ? 0 : -1);
+  }
+  for (int g = g_lo; g <= g_hi; ++g) {
+    __syncthreads();
+    const double* cb = cents + (int64_t)g * n_per_group * d;
+    for (int u = tid; u < KP * 32 * NB; u += 256) {
+      const int n = u / KP, k = u - n * KP;  // (consecutive threads read consecutive coordinates of a centroid)
+      cs[k][n] = (n < n_per_group && k < d) ? (float)cb[(int64_t)n * d + k] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < 32 * NB) {
+      float sq = 0.0f;
+      for (int k = 0; k < d; ++k) sq = fmaf(cs[k][tid], cs[k][tid], sq);
+      cn[tid] = tid < n_per_group ? sq : INFINITY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < AM_CHUNKS; ++c) {
+      if (!__any(pg[c] == g)) continue;
+      am_f32x16 acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float c2 = cn[nb * 32 + j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = c2;
+      }
+      // the chunk's 32 rows go through LDS: consecutive lanes read consecutive doubles (512 contiguous bytes per
+      // instruction, at most two rows), where one lane per row and coordinate touched 32 lines per instruction
+      // and the loads, not the products, set the pace (1M x 64 centroids: 0.33 ms, 0.14 without the loads; 0.24 this way)
+      float* xw = xs + (size_t)w * 32 * XS;
+      if (h == 0) s_pi[w][j] = pi[c];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        int row = lane / d, k = lane - row * d;  // element lane + 64 it of the 32 x d block
+        for (int it = 0; it < (32 * d + 63) / 64; ++it) {
+          if (row < 32) {
+            const int64_t pr = s_pi[w][row];
+            xw[row * XS + k] = pr >= 0 ? -2.0f * (float)X[pr * d + k] : 0.0f;
+          }
+          k += 64;
+          while (k >= d) {
+            k -= d;
+            ++row;
+          }
+        }
+        if ((d & 1) && lane < 32) xw[lane * XS + d] = 0.0f;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      for (int s2 = 0; s2 < KP / 2; ++s2) {
+        const int k = 2 * s2 + h;
+        const float a = xw[j * XS + k];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cs[k][nb * 32 + j], acc[nb], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next chunk overwrites the rows)
+      // row m = 8 (r / 4) + 4 h + r % 4 of the block is point m of the chunk; its minimum over the columns
+      unsigned mine = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        unsigned key = 0xffffffffu;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          unsigned u = __float_as_uint(acc[nb][r] + 0.0f);
+          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+          key = min(key, (u & ~63u) | (unsigned)(nb * 32 + j));
+        }
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) key = min(key, (unsigned)__shfl_xor((int)key, off, 64));
+        const int m = 8 * (r >> 2) + 4 * h + (r & 3);
+        if (m == j) mine = key;
+      }
+      // (point j's row sits in half (j >> 2) & 1)
+      if (((j >> 2) & 1) == h && pg[c] == g) out[pi[c]] = (int)(mine & 63u);
+    }
+  }
+}
+
+// Glue of the ordering levels (meld_amd/reorder.py), one launch each instead of a dozen tensor operations: the stage was
+// bound by the host issuing ~140 small launches (3.4 ms of CPU for 2.7 ms of GPU work at 1M cells).
+// starts[g] = first position of key g in the sorted keys, g = 0 .. n_groups (lower bound)
+__global__ __launch_bounds__(256) void order_starts_kernel(const uint32_t* __restrict__ keys_sorted, int64_t n, int n_groups,
+                                                           int64_t* __restrict__ starts) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n_groups) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys_sorted[mid] < (uint32_t)g) lo = mid + 1; else hi = mid;
+  }
+  starts[g] = lo;
+}
+// sub-centroids of every group: f evenly spaced members (in sorted order) of the group's cells
+__global__ __launch_bounds__(256) void order_pick_centroids_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                                   const int64_t* __restrict__ order,
+                                                                   const int64_t* __restrict__ starts, int n_groups, int f,
+                                                                   double* __restrict__ cents) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (int64_t)n_groups * f * d) return;
+  const int64_t gc = u / d;
+  const int k = (int)(u - gc * d);
+  const int g = (int)(gc / f), c = (int)(gc - (int64_t)g * f);
+  const int64_t s0 = starts[g], cnt = starts[g + 1] - s0;
+  const double frac = ((double)c + 0.5) / (double)f;
+  int64_t pick = s0 + (int64_t)(frac * (double)cnt);
+  pick = min(pick, s0 + max(cnt - 1, (int64_t)0));
+  pick = min(max(pick, (int64_t)0), N - 1);
+  cents[u] = X[order[pick] * d + k];
+}
+// key of the next level: position of the cell's child along its group's chain
+__global__ __launch_bounds__(256) void order_update_keys_kernel(uint32_t* __restrict__ key, const int32_t* __restrict__ child,
+                                                                const int32_t* __restrict__ rank, int64_t n, int f) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t base = key[i] * (uint32_t)f;
+  key[i] = base + (uint32_t)rank[base + (uint32_t)child[i]];
+}
+
 }  // namespace meld
 
 using namespace meld;
 
+extern "C" size_t meld_argsort_u32_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  int64_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, rocprim::make_counting_iterator<int64_t>(0), v, (size_t)n, 0u, 32u);
+  return bytes + 256;
+}
+extern "C" int meld_argsort_u32(const uint32_t* keys, int64_t n, int end_bit, int64_t* order, uint32_t* keys_sorted, void* temp,
+                                size_t temp_bytes, meld_stream_t stream) {
+  MELD_CHECK_ARG(keys && order && keys_sorted && temp && n > 0 && end_bit > 0 && end_bit <= 32, "meld_argsort_u32: bad arguments");
+  size_t bytes = temp_bytes;
+  MELD_HIP_CALL(rocprim::radix_sort_pairs(temp, bytes, keys, keys_sorted, rocprim::make_counting_iterator<int64_t>(0), order, (size_t)n,
+                                          0u, (unsigned)end_bit, S(stream)));
+  return MELD_OK;
+}
+extern "C" int meld_order_starts(const uint32_t* keys_sorted, int64_t n, int n_groups, int64_t* starts, meld_stream_t stream) {
+  MELD_CHECK_ARG(keys_sorted && starts && n > 0 && n_groups > 0, "meld_order_starts: bad arguments");
+  hipLaunchKernelGGL(order_starts_kernel, dim3((unsigned)ceil_div((int64_t)n_groups + 1, 256)), dim3(256), 0, S(stream), keys_sorted, n,
+                     n_groups, starts);
+  MELD_LAUNCH_CHECK("order_starts_kernel");
+  return MELD_OK;
+}
+extern "C" int meld_order_pick_centroids(const double* X, int64_t N, int d, const int64_t* order, const int64_t* starts, int n_groups,
+                                         int f, double* cents, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && order && starts && cents && N > 0 && d > 0 && n_groups > 0 && f > 0, "meld_order_pick_centroids: bad arguments");
+  hipLaunchKernelGGL(order_pick_centroids_kernel, dim3((unsigned)ceil_div((int64_t)n_groups * f * d, 256)), dim3(256), 0, S(stream), X, N,
+                     d, order, starts, n_groups, f, cents);
+  MELD_LAUNCH_CHECK("order_pick_centroids_kernel");
+  return MELD_OK;
+}
+extern "C" int meld_order_update_keys(uint32_t* key, const int32_t* child, const int32_t* rank, int64_t n, int f, meld_stream_t stream) {
+  MELD_CHECK_ARG(key && child && rank && n > 0 && f > 0, "meld_order_update_keys: bad arguments");
+  hipLaunchKernelGGL(order_update_keys_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, S(stream), key, child, rank, n, f);
+  MELD_LAUNCH_CHECK("order_update_keys_kernel");
+  return MELD_OK;
+}
+
 extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
                                    const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cents && out && N > 0 && d > 0 && n_per_group > 0, "meld_assign_nearest: bad arguments");
+  static const bool valu_only = getenv("MELD_ASSIGN") && !strcmp(getenv("MELD_ASSIGN"), "valu");  // (A/B: the FMA kernels)
+  if (!valu_only && d <= AS_DMAX && n_per_group <= 64 && (group == nullptr || order != nullptr)) {
+    const unsigned grid = (unsigned)ceil_div(N, (int64_t)AM_WG_PTS);
+    const int KP = (d + 1) & ~1, nbl = n_per_group <= 32 ? 1 : 2;
+    const size_t lds = 4 * 32 * 8 + sizeof(float) * ((size_t)KP * 32 * nbl + 32 * nbl + (size_t)4 * 32 * (KP + 1));
+    if (nbl == 1)
+      hipLaunchKernelGGL((assign_nearest_mfma_kernel<1>), dim3(grid), dim3(256), lds, S(stream), X, N, d, cents, n_per_group, group, order, out);
+    else
+      hipLaunchKernelGGL((assign_nearest_mfma_kernel<2>), dim3(grid), dim3(256), lds, S(stream), X, N, d, cents, n_per_group, group, order, out);
+    MELD_LAUNCH_CHECK("assign_nearest_mfma_kernel");
+    return MELD_OK;
+  }
   if (d <= AS_DMAX && n_per_group <= AT_CMAX && (group == nullptr || order != nullptr)) {
 #define MELD_ASSIGN_TILED(PERV)                                                                                         \
   hipLaunchKernelGGL((assign_nearest_tiled_kernel<PERV>), dim3((unsigned)ceil_div(N, AT_PTS)), dim3(256), 0, S(stream), X, \

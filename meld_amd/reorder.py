@@ -21,37 +21,21 @@ from ._lib import check, get_lib, ptr
 __all__ = ["locality_permutation"]
 
 
-def _argsort_bits(keys, n_bits):
-    """Stable argsort of non-negative int64 keys below 2**n_bits: the library's radix sort over just those bits
-    (a 14-bit key takes two passes; torch.argsort sorts all 64)."""
-    lib = get_lib()
-    n = int(keys.shape[0])
-    dev = keys.device
-    keys = keys.contiguous()
-    idx = torch.arange(n, dtype=torch.float64, device=dev)  # (exact up to 2**53)
-    k2, v2 = torch.empty_like(keys), torch.empty_like(idx)
-    tb = lib.meld_sort_temp_bytes(n)
-    tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
-    check(lib.meld_sort_pairs_u64_f64(ptr(keys), ptr(k2), ptr(idx), ptr(v2), n, int(max(1, n_bits)), ptr(tmp), tb,
-                                      torch.cuda.current_stream().cuda_stream), "meld_sort_pairs_u64_f64")
-    return v2.to(torch.int64)
+class _Sorter:
+    """Stable argsort of the 32-bit ordering keys (``meld_argsort_u32``: the index payload comes from a counting iterator,
+    the sorted keys are kept for the group boundaries); buffers allocated once per permutation."""
 
+    def __init__(self, n, dev):
+        self.lib, self.n = get_lib(), n
+        self.order = torch.empty(n, dtype=torch.int64, device=dev)
+        self.skeys = torch.empty(n, dtype=torch.int32, device=dev)
+        self.tb = self.lib.meld_argsort_u32_temp_bytes(n)
+        self.tmp = torch.empty(self.tb, dtype=torch.uint8, device=dev)
 
-def _chain_order_batched(P):
-    """Greedy nearest-neighbour chain over the rows of every P[b] (CUDA fp64 [B, m, d], m <= 64)
-    -> rank [B, m] int64: position of each row along its chain (one wave per group on the device)."""
-    B, m, d = P.shape
-    dev = P.device
-    if m <= 2:
-        return torch.arange(m, device=dev, dtype=torch.int64)[None, :].repeat(B, 1)
-    P = P.contiguous()
-    rank = torch.empty((B, m), dtype=torch.int32, device=dev)
-    check(get_lib().meld_chain_order(ptr(P), B, m, d, ptr(rank), torch.cuda.current_stream().cuda_stream), "meld_chain_order")
-    return rank.to(torch.int64)
-
-
-def _chain_order(P):
-    return _chain_order_batched(P[None])[0]
+    def __call__(self, key, n_groups, st):
+        bits = int(max(1, int(n_groups - 1).bit_length()))
+        check(self.lib.meld_argsort_u32(ptr(key), self.n, bits, ptr(self.order), ptr(self.skeys), ptr(self.tmp), self.tb, st), "meld_argsort_u32")
+        return self.order
 
 
 _SIDE = {}
@@ -62,33 +46,6 @@ def _side_stream(dev):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
-
-
-def _split_level(X, lib, st, group, n_groups, fanout):
-    """One refinement level: every group of cells gets `fanout` sub-centroids (evenly spaced
-    members), every cell its nearest one.  Returns (child id within group [N] int64, rank of each
-    child along its group's chain [n_groups, fanout])."""
-    N, d = int(X.shape[0]), int(X.shape[1])
-    dev = X.device
-    order = _argsort_bits(group, int(n_groups - 1).bit_length())
-    counts = torch.bincount(group, minlength=n_groups)
-    starts = torch.cumsum(counts, 0) - counts
-    frac = (torch.arange(fanout, device=dev, dtype=torch.float64) + 0.5) / fanout
-    pick = starts[:, None] + (frac[None, :] * counts[:, None].to(torch.float64)).to(torch.int64)
-    pick = torch.minimum(pick, (starts + torch.clamp(counts - 1, min=0))[:, None]).clamp_(0, N - 1)
-    cents = X.index_select(0, order[pick.reshape(-1)]).contiguous()  # [n_groups * fanout, d]
-    child = torch.empty(N, dtype=torch.int32, device=dev)
-    g32 = group.to(torch.int32)
-    # the chains over the sub-centroids (one wave per group, a latency-bound walk of <= 64 greedy steps: 0.14-0.27 ms)
-    # do not depend on the assignment of the cells: they run beside it on a second stream
-    main = torch.cuda.current_stream()
-    side = _side_stream(dev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        rank = _chain_order_batched(cents.reshape(n_groups, fanout, d))
-    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), fanout, ptr(g32), ptr(order), ptr(child), st), "meld_assign_nearest")
-    main.wait_stream(side)
-    return child.to(torch.int64), rank
 
 
 def locality_permutation(X, c1=None, fanouts=None, seed=0):
@@ -122,22 +79,37 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0):
         fanouts = min(shapes, key=lambda f: abs(math.log(c1 * f[0] * f[1] / max(N / 16.0, 1.0))))
     rng = np.random.default_rng(seed)
     idx1 = torch.from_numpy(np.sort(rng.choice(N, size=c1, replace=False))).to(dev)
-    cents1 = X.index_select(0, idx1).contiguous()
-    a1 = torch.empty(N, dtype=torch.int32, device=dev)
+    cents = X.index_select(0, idx1).contiguous()
+    i32 = dict(dtype=torch.int32, device=dev)
+    child = torch.empty(N, **i32)
+    key = torch.zeros(N, **i32)  # position of the cell's group along the chains of the levels so far (the group id of the next level)
     main, side = torch.cuda.current_stream(), _side_stream(dev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        rank1 = _chain_order(cents1)  # (one wave, 63 dependent steps: hidden behind the assignment)
-    check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents1), c1, None, None, ptr(a1), st), "meld_assign_nearest")
-    main.wait_stream(side)
-    key = rank1[a1.to(torch.int64)]  # order of the coarse cell of every point
-    group = a1.to(torch.int64)
-    n_groups = c1
-    for f in fanouts:
-        if N // (n_groups * f) < 4:
-            break
-        child, rank = _split_level(X, lib, st, group, n_groups, f)
-        key = key * f + rank[group, child]
-        group = group * f + child
+    sorter = _Sorter(N, dev)
+    # Every level: the chain over the group's centroids (one wave per group, a latency-bound walk of <= 64 greedy steps)
+    # does not depend on the assignment of the cells and runs beside it on a second stream; then
+    # key <- key * fanout + position of the cell's centroid along its group's chain.  Level 0 is one group of c1 random
+    # cells; each further level takes `fanout` evenly spaced members of every group (in sorted order) as sub-centroids.
+    # All of it is a handful of launches per level (meld_order_*): issued as tensor operations the stage was host-bound.
+    n_groups, f, order = 1, c1, None
+    for nxt in tuple(fanouts) + (None,):
+        rank = torch.empty(n_groups * f, **i32)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if f > 2:
+                check(lib.meld_chain_order(ptr(cents), n_groups, f, d, ptr(rank), side.cuda_stream), "meld_chain_order")
+            else:
+                rank.copy_(torch.arange(f, **i32).repeat(n_groups))
+        check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), f, ptr(key) if order is not None else None,
+                                      ptr(order) if order is not None else None, ptr(child), st), "meld_assign_nearest")
+        main.wait_stream(side)
+        check(lib.meld_order_update_keys(ptr(key), ptr(child), ptr(rank), N, f, st), "meld_order_update_keys")
         n_groups *= f
-    return _argsort_bits(key, int(n_groups - 1).bit_length())
+        order = sorter(key, n_groups, st)
+        if nxt is None or N // (n_groups * nxt) < 4:
+            break
+        f = nxt
+        starts = torch.empty(n_groups + 1, dtype=torch.int64, device=dev)
+        check(lib.meld_order_starts(ptr(sorter.skeys), N, n_groups, ptr(starts), st), "meld_order_starts")
+        cents = torch.empty(n_groups * f, d, dtype=torch.float64, device=dev)
+        check(lib.meld_order_pick_centroids(ptr(X), N, d, ptr(order), ptr(starts), n_groups, f, ptr(cents), st), "meld_order_pick_centroids")
+    return order

@@ -701,3 +701,38 @@ def test_partition_of_remote_entries_matches_numpy():
             assert set(zip(got_k[used].tolist(), got_v[used].tolist())) <= pairs
             if want.shape[0] <= cap:
                 assert len(set(zip(got_k[used].tolist(), got_v[used].tolist()))) == len(pairs)
+
+
+@pytest.mark.parametrize("n,d,npg,n_groups", [(20000, 50, 64, 1), (30011, 50, 32, 37), (5000, 7, 13, 300), (9000, 128, 64, 5)])
+def test_assign_nearest_on_the_matrix_pipe_matches_brute_force(n, d, npg, n_groups):
+    """meld_assign_nearest (|c|^2 - 2 x.c on the fp32 MFMA): every point gets its nearest centroid of its group; where it
+    differs from an fp64 brute force the two distances are a near-tie (fp32 products, keys without their low 6 bits)."""
+    from meld_amd._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    rng = np.random.default_rng(n + d)
+    X = rng.normal(size=(n, d)) * 3.0 + rng.normal(size=(1, d))
+    cents = rng.normal(size=(n_groups * npg, d)) * 3.0
+    Xd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(cents).cuda()
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    if n_groups == 1:
+        grp = np.zeros(n, dtype=np.int64)
+        check(lib.meld_assign_nearest(ptr(Xd), n, d, ptr(Cd), npg, None, None, ptr(out), st), "meld_assign_nearest")
+    else:
+        sizes = rng.multinomial(n - n_groups, np.ones(n_groups) / n_groups) + 1  # ragged groups, none empty
+        sizes[3] += sizes[4] - 1
+        sizes[4] = 1
+        grp = rng.permutation(np.repeat(np.arange(n_groups), sizes))
+        g32 = torch.from_numpy(grp.astype(np.int32)).cuda()
+        order = torch.from_numpy(np.argsort(grp, kind="stable")).cuda()
+        check(lib.meld_assign_nearest(ptr(Xd), n, d, ptr(Cd), npg, ptr(g32), ptr(order), ptr(out), st), "meld_assign_nearest")
+    got = out.cpu().numpy().astype(np.int64)
+    assert got.min() >= 0 and got.max() < npg
+    C = cents.reshape(n_groups, npg, d)[grp]                    # [n, npg, d]
+    d2 = ((X[:, None, :] - C) ** 2).sum(-1)
+    best = d2.argmin(1)
+    diff = np.nonzero(best != got)[0]
+    assert diff.shape[0] < 0.002 * n
+    scale = (X ** 2).sum(1) + (C ** 2).sum(-1).max(1)
+    assert np.all(d2[diff, got[diff]] - d2[diff, best[diff]] <= 2e-5 * scale[diff])
