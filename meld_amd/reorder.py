@@ -48,7 +48,7 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
-def locality_permutation(X, c1=None, fanouts=None, seed=0):
+def locality_permutation(X, c1=None, fanouts=None, seed=0, comm=None):
     """X: CUDA fp64 [N, d].  Returns perm (device int64 [N]) or None when N is too small to matter.
 
     Level 0: nearest of c1 (<= 64) random cells (coarse cells, ordered by a chain); each further
@@ -99,8 +99,30 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0):
                 check(lib.meld_chain_order(ptr(cents), n_groups, f, d, ptr(rank), side.cuda_stream), "meld_chain_order")
             else:
                 rank.copy_(torch.arange(f, **i32).repeat(n_groups))
-        check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), f, ptr(key) if order is not None else None,
-                                      ptr(order) if order is not None else None, ptr(child), st), "meld_assign_nearest")
+        if comm is None or comm.world == 1:
+            check(lib.meld_assign_nearest(ptr(X), N, d, ptr(cents), f, ptr(key) if order is not None else None,
+                                          ptr(order) if order is not None else None, ptr(child), st), "meld_assign_nearest")
+        else:
+            # row-sharded driver: the assignment -- the one pass over all cells of a level -- is split by position, every
+            # rank takes 1 / world of the cells (in the level's traversal order) and the children are all-gathered
+            # (4 B per cell); chains, sorts and picks are small and stay replicated, so every rank ends with the same keys
+            per = -(-N // comm.world)
+            p0 = min(comm.rank * per, N)
+            cnt = min(per, N - p0)
+            mine = torch.zeros(per, **i32)
+            if cnt > 0:
+                if order is None:
+                    check(lib.meld_assign_nearest(ptr(X[p0:]), cnt, d, ptr(cents), f, None, None, ptr(mine), st), "meld_assign_nearest")
+                else:
+                    sl = order[p0 : p0 + cnt]
+                    check(lib.meld_assign_nearest(ptr(X), cnt, d, ptr(cents), f, ptr(key), ptr(sl), ptr(child), st), "meld_assign_nearest")
+                    mine[:cnt] = child.index_select(0, sl)
+            everyone = torch.empty(per * comm.world, **i32)
+            comm.all_gather_rows(everyone, mine)
+            if order is None:
+                child.copy_(everyone[:N])
+            else:
+                child.index_copy_(0, order, everyone[:N])
         main.wait_stream(side)
         check(lib.meld_order_update_keys(ptr(key), ptr(child), ptr(rank), N, f, st), "meld_order_update_keys")
         n_groups *= f

@@ -53,10 +53,14 @@ def main(out_path, n, d, knn):
     op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X).cuda(), labels, comm=StagedComm())
     G = op.graph
+    # the ordering whose assignment passes were split over the ranks is the ordering one GPU computes alone
+    from meld_amd.reorder import locality_permutation
+
+    perm_equal = bool(torch.equal(G.perm, locality_permutation(op.X)))
     np.savez(
         out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, lmax=G.lmax, row_begin=G.row_begin, n_rows=G.n_rows,
         nnz_global=G.info["nnz_global"], iters=G.lmax_info["iterations"], device_resident=bool(G.lmax_info.get("device_resident", False)),
-        exchange=G.info["exchange"], all_reduces=G.lmax_info.get("all_reduces_per_iteration", 2),
+        exchange=G.info["exchange"], perm_equal=perm_equal, all_reduces=G.lmax_info.get("all_reduces_per_iteration", 2),
     )
     dist.destroy_process_group()
 

@@ -434,6 +434,7 @@ def test_two_ranks_on_one_gpu(tmp_path):
     assert bool(ranks[0]["device_resident"])  # the phase-wise Lanczos ran, not the host loop
     assert int(ranks[0]["all_reduces"]) == 1  # ... in its one-reduction form
     assert all(str(r["exchange"]) == "fixed" for r in ranks)  # meld_coo_partition_remote + one equal-split all-to-all
+    assert all(bool(r["perm_equal"]) for r in ranks)  # sharded assignment passes of the ordering: same permutation
     for r in ranks:
         assert abs(float(r["lmax"]) - single.graph.lmax) <= 1e-9 * single.graph.lmax
         assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
