@@ -329,14 +329,16 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // Query block of this workgroup.  Workgroups are dispatched in index order as slots free up, and with pruning their
   // work differs by up to 12x: block_order (optional) lists the query blocks by decreasing work, so that the longest
   // start first and the chip does not wait for a heavy block that was dispatched last (meld_knn16_block_work).
-  const int bx = a.block_order ? __builtin_amdgcn_readfirstlane(a.block_order[blockIdx.x]) : (int)blockIdx.x;
+  // (grid = slices x query blocks: the slices of a block are dispatched together, so "longest blocks first" holds across slices)
+  const int bx = a.block_order ? __builtin_amdgcn_readfirstlane(a.block_order[blockIdx.y]) : (int)blockIdx.y;
   const int q_base = bx * K16_BQ + wave * 64;  // first query of this wave
-  // reference slices (gridDim.y > 1): slice y scans tiles [tile_lo, tile_lo + n_scan) and writes its
-  // own candidate rows; meld_knn16_merge_slices combines them.  Used to spread a small query set
-  // (the second-stage re-search) over the whole chip.
-  const int tile_lo = (int)((long long)n_tiles * blockIdx.y / gridDim.y);
-  const int n_scan = (int)((long long)n_tiles * (blockIdx.y + 1) / gridDim.y) - tile_lo;
-  const int row_base = (int)(blockIdx.y * (gridDim.x * K16_BQ)) + q_base;  // first candidate row of this wave
+  // reference slices (gridDim.x > 1): slice y scans the tiles y, y + S, y + 2 S, ... (interleaved: with the cells in
+  // locality order the tiles a query block cannot rule out sit in a few runs, and contiguous slices would leave most of a
+  // heavy block's work in one of them) and writes its own candidate rows; meld_knn16_merge_slices combines them.  Used to
+  // spread few query blocks (the re-search, a row shard, a mid-sized data set) over the whole chip.
+  const int sl_n = (int)gridDim.x, sl_y = (int)blockIdx.x;
+  const int n_scan = (n_tiles - sl_y + sl_n - 1) / sl_n;
+  const int row_base = (int)(blockIdx.x * (gridDim.y * K16_BQ)) + q_base;  // first candidate row of this wave
   float* const wave_d2 = cand_d2 + (size_t)row_base * cap;                // (wave-uniform: SGPR pairs)
   int* const wave_idx = cand_idx + (size_t)row_base * cap;
 
@@ -380,7 +382,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // threshold of the workgroup cannot contribute a candidate and is skipped without being loaded.
   // search-error allowance in the scaled space: a skipped tile must fail `d2_approx < thr` for sure
   const float prune_margin = lb2 ? a.err_coef * a.norm2_max[0] * a.scale_info[0] * a.scale_info[0] : 0.0f;
-  const int t0 = (int)(((long long)a.tile_origin + (long long)bx * (K16_BQ / K16_TS)) % n_scan);
+  const int t0 = (int)((((long long)a.tile_origin + (long long)bx * (K16_BQ / K16_TS)) / sl_n) % n_scan);
   const __half* my_lb = lb2 ? lb2 + (size_t)(bx * K16_NWAVE + wave) * n_tiles : nullptr;
   // (A "convoy" order -- all resident workgroups sweeping the same tiles at the same time so that all but
   // the first find them in L2 -- was tried: the base loop gained 7 %, but the thresholds converge later and
@@ -397,7 +399,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     }
     int t = t0 + off;
     t = t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
-    return tile_lo + t;
+    return t * sl_n + sl_y;
   };
   // Pruning window (64 steps): lane i holds THIS WAVE's bound for step win_base + i (lb2 has one row per wave:
   // the wave's 64 queries against every tile).  my_live = steps of the window whose tile may still hold a
@@ -974,8 +976,11 @@ __global__ __launch_bounds__(64) void knn16_merge_slices_kernel(const int* __res
                                                                 int ksel, int cap, int n_slices,
                                                                 int* __restrict__ out_idx, float* __restrict__ out_d2,
                                                                 int* __restrict__ out_cnt) {
-  __shared__ float sd[K16_MERGE_MAX];
-  __shared__ int si[K16_MERGE_MAX];
+  // (dynamic LDS, n_slices * ksel entries: sized for the largest union it allowed five waves per CU -- 2.3 ms for 300k
+  // queries of two slices)
+  extern __shared__ __attribute__((aligned(16))) unsigned char merge_lds[];
+  float* sd = reinterpret_cast<float*>(merge_lds);
+  int* si = reinterpret_cast<int*>(merge_lds) + n_slices * ksel;
   const int lane = threadIdx.x;
   const int q = blockIdx.x;
   if (q >= q_count) return;
@@ -1997,15 +2002,16 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
                                double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
                                float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
-  MELD_CHECK_ARG(block_order == nullptr || n_slices == 1, "meld_knn16_topk: block_order excludes reference slices");
-  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX && (n_slices == 1 || lb2 == nullptr),
-                 "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d and excludes pruning", n_slices,
-                 K16_MERGE_MAX);
+  // (reference slices combine with pruning, the radius cut and a dispatch order: a slice's table row is the wave's row, its
+  // rows are cut at the radius ITS references imply -- looser than the global one, still valid -- and cand_thr then holds
+  // n_slices x q_pad thresholds of which the caller takes the minimum per query)
+  MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX, "meld_knn16_topk: n_slices=%d must satisfy n_slices * ksel <= %d",
+                 n_slices, K16_MERGE_MAX);
   MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   // radius cut (cand_thr != NULL): rows are cut at the kernel radius implied by their knn-th neighbour so far
-  MELD_CHECK_ARG(cand_thr == nullptr || (norm2_max != nullptr && knn >= 1 && knn < ksel && radius_factor >= 1.0 && n_slices == 1),
-                 "meld_knn16_topk: the radius cut needs norm2_max, 1 <= knn < ksel, radius_factor >= 1 and one slice");
+  MELD_CHECK_ARG(cand_thr == nullptr || (norm2_max != nullptr && knn >= 1 && knn < ksel && radius_factor >= 1.0),
+                 "meld_knn16_topk: the radius cut needs norm2_max, 1 <= knn < ksel, radius_factor >= 1");
   const int knn1 = cand_thr ? knn + 1 : 0;
   const float rf2 = cand_thr ? (float)(radius_factor * radius_factor * (1.0 + 1e-6)) : 0.0f;
   const float err_c = (float)meld_knn16_error_coef_const(nprod, d), err_l = (float)meld_knn16_error_coef_lin(nprod);
@@ -2015,7 +2021,8 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   const int KB = meld_knn16_kblocks(d);
   if (KB < 0) return KB;
   const int n_tiles = (int)ceil_div(n_ref, K16_TS);
-  const dim3 grid((unsigned)ceil_div(q_count, K16_BQ), (unsigned)n_slices);
+  const dim3 grid((unsigned)n_slices, (unsigned)ceil_div(q_count, K16_BQ));
+  MELD_CHECK_ARG(grid.y <= 65535u, "meld_knn16_topk: more than 65535 query blocks in one launch");
   MELD_CHECK_ARG(n_slices <= ceil_div(n_ref, K16_TS), "meld_knn16_topk: more slices than reference tiles");
   const int tile_origin = (int)((q_begin / K16_TS) % n_tiles);  // the scan starts at the queries' own position
   // profiling hooks (never set in production): MELD_KNN16_ABLATION=1 distances without selection,
@@ -2130,7 +2137,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     const int64_t n_rows = (int64_t)grid.x * K16_BQ * grid.y;
     const dim3 fgrid((unsigned)ceil_div(n_rows, 4));
     hipLaunchKernelGGL(knn16_finish_rows_kernel, fgrid, dim3(256), 0, S(stream), cand_d2, cand_idx, cand_cnt, Qn, scale_info, n_rows,
-                       (int64_t)grid.x * K16_BQ, cap, ksel);
+                       (int64_t)grid.y * K16_BQ, cap, ksel);
     MELD_LAUNCH_CHECK("knn16_finish_rows_kernel");
   }
   if (stats) {
@@ -2139,7 +2146,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     MELD_HIP_CALL(hipMemcpy(st, stats, sizeof(st), hipMemcpyDeviceToHost));
     fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu  tiles staged %llu (%.1f %% of workgroups x tiles)\n",
             st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3], st[4],
-            100.0 * (double)st[4] / ((double)grid.x * (double)grid.y * (double)n_tiles / (double)grid.y));
+            100.0 * (double)st[4] / ((double)grid.y * (double)n_tiles));
   }
   return MELD_OK;
 }
@@ -2190,7 +2197,7 @@ extern "C" int meld_knn16_merge_slices(const int32_t* s_idx, const float* s_d2, 
   if (cap < 0) return cap;
   MELD_CHECK_ARG(n_slices >= 1 && n_slices * ksel <= K16_MERGE_MAX, "meld_knn16_merge_slices: too many slices");
   const int q_pad = (int)(ceil_div(q_count, K16_BQ) * K16_BQ);
-  hipLaunchKernelGGL(knn16_merge_slices_kernel, dim3((unsigned)q_count), dim3(64), 0, S(stream), s_idx, s_d2,
+  hipLaunchKernelGGL(knn16_merge_slices_kernel, dim3((unsigned)q_count), dim3(64), (size_t)n_slices * ksel * 8, S(stream), s_idx, s_d2,
                      s_cnt, (int)q_count, q_pad, ksel, cap, n_slices, out_idx, out_d2, out_cnt);
   MELD_LAUNCH_CHECK("knn16_merge_slices_kernel");
   return MELD_OK;

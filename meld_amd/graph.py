@@ -563,8 +563,29 @@ class HipOps:
                     check(lib.meld_knn16_block_work(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), ptr(work), st), "meld_knn16_block_work")
                     block_order = torch.argsort(work, descending=True, stable=True).to(torch.int32)
                 tm.stop("bounds")
+            # Few query blocks (a row shard, a mid-sized data set): with pruning the work of a block varies 12-fold and a
+            # launch that fills the chip less than twice over ends when its heaviest block does (a 1/8 shard of 1M cells:
+            # 7-10 ms instead of 26 / 8).  The references are then cut into slices -- blocks x slices workgroups, each
+            # with its own candidate rows, merged afterwards -- so that the heavy blocks are shared out.
+            main_slices = 1
+            if will_prune and q_main == q_count and cand_thr is not None:
+                resident = lib.meld_knn16_resident_blocks(d, nprod)
+                if os.environ.get("MELD_KNN_MAIN_SLICES"):
+                    main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
+                elif resident > 0 and n_blocks < 2 * resident:
+                    main_slices = int(max(1, min(4, lib.meld_knn16_max_slices(ksel), -(-2 * resident // n_blocks), n_tiles // 64)))  # (more slices cost more in merging than they balance)
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
-                check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
+                if main_slices > 1:
+                    s_idx = torch.empty(main_slices * q_pad * cap, dtype=torch.int32, device=dev)
+                    s_d2 = torch.empty(main_slices * q_pad * cap, dtype=torch.float32, device=dev)
+                    s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
+                    s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
+                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
+                    check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_main, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
+                    cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
+                    del s_idx, s_d2, s_cnt, s_thr
+                else:
+                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
                 # until its results are refined: work that does not depend on the graph (fit_transform's label
                 # factorisation: a host-blocking copy + a few small launches on a side stream) is started here

@@ -21,10 +21,12 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
     ops = HipOps()
     for r in range(reps):
         mg.record_events(True)
-        keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, n, int(os.environ.get("KNN", "15")), 40, 1e-4, int(os.environ.get("KSEL", "64")))
+        q0, qc = int(os.environ.get("Q0", "0")), int(os.environ.get("QC", str(n)))  # (a row shard: queries [Q0, Q0 + QC) against all n cells)
+        keys, vals, bw, info = ops.directed_kernel_coo(Xd, q0, qc, int(os.environ.get("KNN", "15")), 40, 1e-4, int(os.environ.get("KSEL", "64")))
         torch.cuda.synchronize()
         ev = mg.event_times_ms()
         ms = ev["knn_topk"][0]
+        print({k: round(v[0], 2) for k, v in ev.items()})
         mg.record_events(False)
     kb = (50 + 3 + 15) // 16
     ideal = (n / 32.0) ** 2 * kb * 32 / 1024 / 2.4e9 * 1e3
