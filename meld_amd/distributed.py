@@ -85,17 +85,21 @@ class Comm:
         return rk, rv
 
 
-def exchange_capacity(rows_per_rank, ksel, world):
+def exchange_capacity(rows_per_rank, ksel, world, locality=False):
     """Slots per peer of the fixed-capacity exchange of transposed entries.  A rank emits at most rows_per_rank * ksel
-    directed entries (ksel candidates per row, typically a third of them survive the kernel threshold), spread over the
-    owners; twice the even share (never more than everything) -- with the cells in locality order most entries stay on
-    their own rank and never enter the exchange.  ``MELD_EXCHANGE_CAP`` overrides (the tests force the fallback with
-    it)."""
+    directed entries, in practice about a third of that (the candidates that survive the kernel threshold: ~20 per row at
+    knn = 15), each owed to the owner of its column.  With the cells in locality order most of them stay on their own rank
+    and never enter the exchange (a 1/8 shard of the 1M benchmark owes ~2 % of its entries to each neighbour): an eighth
+    of the even share of the bound is then plenty and keeps the buffer -- memset, all-to-all and the scatter's scan of it
+    -- small (32 MB instead of 256 MB per rank at 8 ranks); without an ordering the entries spread evenly and the capacity
+    is the even share of the bound.  An overflow is detected and falls back to the variable-length exchange.
+    ``MELD_EXCHANGE_CAP`` overrides (the tests force the fallback with it)."""
     env = os.environ.get("MELD_EXCHANGE_CAP")
     if env:
         return int(env)
     total = int(rows_per_rank) * int(ksel)
-    cap = min(total, 2 * total // max(world, 1) + 1024)
+    share = total // max(world, 1)
+    cap = min(total, (share // 8 if locality else share) + 1024)
     return ((cap + 255) // 256) * 256
 
 
@@ -134,7 +138,7 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
     direct_k, direct_v = keys[:M], vals[:M]  # rows owned by this rank
     trans_k, trans_v = keys[M:].contiguous(), vals[M:].contiguous()  # rows owned by anyone
     rows_here = max(n_loc, 1)
-    cap = exchange_capacity(R, ksel, comm.world)
+    cap = exchange_capacity(R, ksel, comm.world, locality=perm is not None)
 
     def assemble(fixed):
         if fixed:
