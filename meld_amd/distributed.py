@@ -89,17 +89,18 @@ def exchange_capacity(rows_per_rank, ksel, world, locality=False):
     """Slots per peer of the fixed-capacity exchange of transposed entries.  A rank emits at most rows_per_rank * ksel
     directed entries, in practice about a third of that (the candidates that survive the kernel threshold: ~20 per row at
     knn = 15), each owed to the owner of its column.  With the cells in locality order most of them stay on their own rank
-    and never enter the exchange (a 1/8 shard of the 1M benchmark owes ~2 % of its entries to each neighbour): an eighth
-    of the even share of the bound is then plenty and keeps the buffer -- memset, all-to-all and the scatter's scan of it
-    -- small (32 MB instead of 256 MB per rank at 8 ranks); without an ordering the entries spread evenly and the capacity
-    is the even share of the bound.  An overflow is detected and falls back to the variable-length exchange.
+    and never enter the exchange (measured with tools/shard_emulate.py: a 1/8 shard of the 1M benchmark emits 3.3 M
+    entries and owes 11 % of them to other ranks, at most 141 k = 4 % to any one): a quarter of the even share of the bound
+    (250 k at 8 ranks) covers that and keeps the buffer -- memset, all-to-all and the scatter's scan of it -- small (64 MB
+    instead of 256 MB per rank at 8 ranks); without an ordering the entries spread evenly and the capacity is the even
+    share of the bound.  An overflow is detected and falls back to the variable-length exchange.
     ``MELD_EXCHANGE_CAP`` overrides (the tests force the fallback with it)."""
     env = os.environ.get("MELD_EXCHANGE_CAP")
     if env:
         return int(env)
     total = int(rows_per_rank) * int(ksel)
     share = total // max(world, 1)
-    cap = min(total, (share // 8 if locality else share) + 1024)
+    cap = min(total, (share // 4 if locality else share) + 1024)
     return ((cap + 255) // 256) * 256
 
 

@@ -72,6 +72,14 @@ _ro.locality_permutation = lambda X, *a, comm=None, **k: _lp(X, *a, **k)
 _fold = _mf._lanczos_lmax_folded
 _mf._lanczos_lmax_folded = lambda G, ops, comm, u0, tol, max_iter, check_every: _fold(G, ops, comm, u0, tol, 35, check_every)
 
+from meld_amd.graph import HipOps as _HO
+_pr = _HO.partition_remote
+def _pr_print(self, keys, vals, R, world, rank, cap):
+    send, counts = _pr(self, keys, vals, R, world, rank, cap)
+    print("  entries owed to each rank", counts.tolist(), "of", int(keys.shape[0]), "capacity", cap)
+    return send, counts
+_HO.partition_remote = _pr_print
+
 X, labels = synthetic_cells(N, 50, seed=0)
 Xd = torch.from_numpy(X).cuda()
 for rep in range(4):
