@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/_profile_round.sh r03 <commit> [quick]'
 # bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3), fabric traffic (PMC) of the hot kernels,
 # PMC passes over the search and the recurrence kernels, the per-wave timeline of a recurrence step, and the full-oracle
-# parity runs at 1M and 500k.  Every file carries the commit; copy gpurun_out/prof_<tag>/* to profiles/.
+# parity runs at 1M and 500k, the VertexFrequencyCluster line at 1M and the per-rank compute of the sharded driver.  Every file carries the commit; copy gpurun_out/prof_<tag>/* to profiles/.
 tag=${1:-r03}; commit=${2:-unknown}; quick=${3:-}
 out=gpurun_out/prof_$tag; mkdir -p $out/pmc; export TMPDIR=/tmp
 stamp() { echo "# commit $commit, $(date -u +%Y-%m-%dT%H:%MZ), $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"; }
@@ -34,4 +34,10 @@ PY
 rm -rf gpurun_out/pmc_knn_$tag gpurun_out/pmc_spmm_$tag
 { stamp; python tools/save_graph.py 1000000 /tmp/g1m.pt > /dev/null; for p in 2 1; do echo "## p = $p"; python tools/spmm_stamps.py /tmp/g1m.pt $p 2>/dev/null; done; python tools/spmm_time.py /tmp/g1m.pt 2>/dev/null | grep "tiled p\|lanczos"; } > $out/recurrence_step_timeline.txt
 { stamp; for n in 1000000 500000; do echo "## N = $n"; python tools/parity_200k.py $n 2>&1 | grep -v amdgpu.ids; done; } > $out/full_oracle_parity.txt
+{ stamp; python bench.py --cells 1000000 --steps 2 --warmup 1 --cpu-sample 0 --no-host-input --vfc 2>/dev/null | python -c "
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1))"; } > $out/vfc_1M.txt
+{ stamp; echo "# per-rank compute of the sharded driver on ONE GPU (stand-in collectives, results wrong by construction): tools/shard_emulate.py"
+  for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done; } > $out/shard_emulation.txt
 ls -la $out $out/pmc
