@@ -70,7 +70,7 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
     is EXTRAPOLATED and labelled as such.  `value` is the measured rate of the largest sample."""
     from oracle import meld_oracle as mo
 
-    sizes = [50_000, 100_000, 200_000] if (full_protocol or sample_cells == 200_000) else [sample_cells // 4, sample_cells // 2, sample_cells]
+    sizes = [50_000, 100_000, 200_000] if full_protocol else [sample_cells // 4, sample_cells // 2, sample_cells]
     runs = []
     for n in sizes:
         X, labels = mo.synthetic_cells(n, n_dims=dims, seed=0)
@@ -102,12 +102,25 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
             "note": "EXTRAPOLATED from the three runs above with t ~ N^{:.2f}; not measured".format(expo),
         },
         "host_cores_available": os.cpu_count(),
+        "recorded_full_protocol": recorded_full_protocol(),
         "best_effort": {
             "value": n_big / t_best,
             "cores": os.cpu_count(),
             "note": "same {}-cell sample with sklearn brute-force kNN on all host cores (n_jobs=-1); {:.1f} s".format(n_big, t_best),
         },
     }
+
+
+def recorded_full_protocol():
+    """SURVEY 8d's own sample sizes (50k / 100k / 200k) take 27 minutes of host time -- the ball tree degrades sharply past
+    50k cells in 50 dimensions -- so they are timed once per round (`bench.py --cpu-full`, tools/_profile_round.sh) and the
+    record, with the commit it was taken at, rides along in every line; the default run times a quarter of those sizes."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_baseline_full.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def cpu_chebyshev_full_size(G, labels, beta, order):
@@ -165,10 +178,11 @@ def main():
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--beta", type=float, default=60)
     ap.add_argument("--order", type=int, default=30)
-    ap.add_argument("--cpu-sample", type=int, default=200000,
-                    help="largest CPU-baseline sample (0 = skip); also run at 1/2 and 1/4 of it.  Default: SURVEY 8d's "
-                         "50k / 100k / 200k protocol (about five minutes of host time); e.g. 40000 for a half-minute run")
-    ap.add_argument("--cpu-full", action="store_true", help="(kept for older command lines: the default is the full protocol now)")
+    ap.add_argument("--cpu-sample", type=int, default=50000,
+                    help="largest CPU-baseline sample (0 = skip); also run at 1/2 and 1/4 of it.  Default 50000: 12.5k / 25k / "
+                         "50k cells, about 45 s of host time (the line also carries the round's recorded run of SURVEY 8d's "
+                         "own 50k / 100k / 200k, which takes 27 minutes: --cpu-full)")
+    ap.add_argument("--cpu-full", action="store_true", help="time SURVEY 8d's 50k / 100k / 200k samples (27 minutes of host time)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the extra untimed-region passes with X on the host")
     ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
     ap.add_argument("--vfc", action="store_true", help="also time VertexFrequencyCluster (filter-bank method) on the benchmark graph "

@@ -269,6 +269,15 @@ int meld_csr_from_keys(const uint64_t* ukeys, int64_t nnz, int64_t row_begin, in
  * cap means the caller must fall back to a variable-length exchange. */
 int meld_coo_partition_remote(const uint64_t* keys, const double* vals, int64_t n, int64_t rows_per_rank, int world,
                               int self_rank, int64_t cap, int32_t* counts, int64_t* send, meld_stream_t stream);
+/* Single-GPU shortcut for meld_coo_emit + meld_coo_scatter_rows (all N rows local, q_begin = 0): the kept candidates of
+ * meld_knn_refine go straight into the row buckets -- a row's own entries into its first slots without an atomic, the
+ * transposed copies behind one -- instead of through 2 M (key, value) pairs.  cursor[N] holds on entry the number of own
+ * entries of every row (keep_cnt; for the rows of the exact sweep its count) and ends as meld_coo_scatter_rows leaves it;
+ * ksel <= meld_csr_bucket_slots(). */
+int meld_coo_emit_scatter(int64_t q_count, const int32_t* cand_idx, const double* cand_val, int ksel, int cap,
+                          const int32_t* keep_cnt, const int32_t* flag_rows, int32_t n_flag, const int64_t* fb_off,
+                          const int32_t* fb_col, const double* fb_val, int64_t fb_total, int32_t* cursor, int32_t* tcol,
+                          double* tval, meld_stream_t stream);
 int meld_csr_bucket_slots(void);
 int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
                           int32_t* cursor, int32_t* tcol, double* tval, meld_stream_t stream);

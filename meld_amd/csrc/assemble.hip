@@ -342,6 +342,73 @@ __global__ __launch_bounds__(256) void coo_partition_remote_kernel(const unsigne
   }
 }
 
+// Emit + scatter in one pass (single GPU, all rows local): the kept candidates of row q go straight into the row buckets --
+// its own entries into the first keep_cnt[q] slots of bucket q (no atomic: cursor[] starts at keep_cnt[]), the transposed
+// copy of each into the bucket of its column's row behind an atomic slot -- instead of being written as 2 M (key, value)
+// pairs (512 MB at 1M cells) that the scatter kernel reads back.  cursor ends as meld_coo_scatter_rows leaves it.
+__global__ __launch_bounds__(256) void coo_emit_scatter_rows_kernel(int64_t q_count, const int* __restrict__ cand_idx,
+                                                                    const double* __restrict__ cand_val, int ksel, int cap,
+                                                                    const int* __restrict__ keep_cnt, int* __restrict__ cursor,
+                                                                    int* __restrict__ tcol, double* __restrict__ tval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= q_count) return;
+  if (keep_cnt[q] == 0) return;  // flagged (its entries come from the exact sweep) or empty row
+  int written = 0;
+  for (int c0 = 0; c0 < ksel; c0 += 64) {
+    const int c = c0 + lane;
+    double v = 0.0;
+    int j = 0;
+    if (c < ksel) {
+      v = cand_val[(size_t)q * ksel + c];
+      j = cand_idx[(size_t)q * cap + c];
+    }
+    const bool keep = v > 0.0;
+    const unsigned long long b = __ballot(keep);
+    if (keep) {
+      const int pos = written + __popcll(b & ((1ull << lane) - 1ull));
+      const double hv = 0.5 * v;
+      tcol[q * CSR_BUCKET + pos] = j;  // (pos < keep_cnt[q] <= ksel <= CSR_BUCKET)
+      tval[q * CSR_BUCKET + pos] = hv;
+      const int slot = atomicAdd(cursor + j, 1);
+      if (slot < CSR_BUCKET) {  // (an overfull bucket shows in cursor[j]: the caller takes the sort-based path)
+        tcol[(int64_t)j * CSR_BUCKET + slot] = (int)q;
+        tval[(int64_t)j * CSR_BUCKET + slot] = hv;
+      }
+    }
+    written += __popcll(b);
+  }
+}
+// ... and the entries of the rows the exact sweep recomputed (thread per entry): fb_off[k] .. fb_off[k + 1] belong to row
+// flag_rows[k], whose cursor started at their count
+__global__ __launch_bounds__(256) void coo_emit_scatter_fallback_kernel(const int* __restrict__ flag_rows, int n_flag,
+                                                                        const int64_t* __restrict__ fb_off,
+                                                                        const int* __restrict__ fb_col,
+                                                                        const double* __restrict__ fb_val, int64_t fb_total,
+                                                                        int* __restrict__ cursor, int* __restrict__ tcol,
+                                                                        double* __restrict__ tval) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= fb_total) return;
+  int lo = 0, hi = n_flag - 1;  // row of entry e: last k with fb_off[k] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (fb_off[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  const int64_t q = flag_rows[lo];
+  const int64_t pos = e - fb_off[lo];
+  const int j = fb_col[e];
+  const double hv = 0.5 * fb_val[e];
+  if (pos < CSR_BUCKET) {
+    tcol[q * CSR_BUCKET + pos] = j;
+    tval[q * CSR_BUCKET + pos] = hv;
+  }
+  const int slot = atomicAdd(cursor + j, 1);
+  if (slot < CSR_BUCKET) {
+    tcol[(int64_t)j * CSR_BUCKET + slot] = (int)q;
+    tval[(int64_t)j * CSR_BUCKET + slot] = hv;
+  }
+}
+
 template <int SL>
 __device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], int lane) {
   constexpr int NE = 64 * SL;
@@ -515,6 +582,27 @@ extern "C" int meld_coo_partition_remote(const uint64_t* keys, const double* val
                      reinterpret_cast<const unsigned long long*>(keys), vals, n, rows_per_rank, world, self_rank, cap, counts,
                      reinterpret_cast<long long*>(send));
   MELD_LAUNCH_CHECK("coo_partition_remote_kernel");
+  return MELD_OK;
+}
+
+// cursor[n_rows] must hold, on entry, the number of OWN entries of every row (keep_cnt of complete rows, the sweep's count of
+// flagged rows); see coo_emit_scatter_rows_kernel.  Rows = all N cells (q_begin = 0): the transposed entries land in local buckets.
+extern "C" int meld_coo_emit_scatter(int64_t q_count, const int32_t* cand_idx, const double* cand_val, int ksel, int cap,
+                                     const int32_t* keep_cnt, const int32_t* flag_rows, int32_t n_flag, const int64_t* fb_off,
+                                     const int32_t* fb_col, const double* fb_val, int64_t fb_total, int32_t* cursor, int32_t* tcol,
+                                     double* tval, meld_stream_t stream) {
+  MELD_CHECK_ARG(cand_idx && cand_val && keep_cnt && cursor && tcol && tval && q_count > 0, "meld_coo_emit_scatter: bad arguments");
+  MELD_CHECK_ARG(cap >= ksel && ksel <= CSR_BUCKET, "meld_coo_emit_scatter: ksel=%d must fit a row bucket (%d) and the row stride cap=%d",
+                 ksel, CSR_BUCKET, cap);
+  hipLaunchKernelGGL(coo_emit_scatter_rows_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), q_count, cand_idx,
+                     cand_val, ksel, cap, keep_cnt, cursor, tcol, tval);
+  MELD_LAUNCH_CHECK("coo_emit_scatter_rows_kernel");
+  if (n_flag > 0 && fb_total > 0) {
+    MELD_CHECK_ARG(flag_rows && fb_off && fb_col && fb_val, "meld_coo_emit_scatter: missing fallback arrays");
+    hipLaunchKernelGGL(coo_emit_scatter_fallback_kernel, dim3((unsigned)ceil_div(fb_total, 256)), dim3(256), 0, S(stream), flag_rows,
+                       n_flag, fb_off, fb_col, fb_val, fb_total, cursor, tcol, tval);
+    MELD_LAUNCH_CHECK("coo_emit_scatter_fallback_kernel");
+  }
   return MELD_OK;
 }
 

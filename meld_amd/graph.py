@@ -415,7 +415,7 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
-    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None):
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -780,9 +780,29 @@ class HipOps:
         tm.stop("radius_exact")
 
         M = m_main + fb_total
-        keys = torch.empty(2 * M, dtype=torch.int64, device=dev)
-        vals = torch.empty(2 * M, dtype=torch.float64, device=dev)
-        if M > 0:
+        assembled = None
+        if assemble and M > 0 and q_begin == 0 and q_count == NR and not cross and os.environ.get("MELD_ASSEMBLE", "bucket") == "bucket":
+            # single GPU, every row local: the kept candidates go straight into the row buckets of the symmetrisation
+            # (meld_coo_emit_scatter) instead of through 2 M (key, value) pairs -- 512 MB written and read back at 1M cells
+            B = int(lib.meld_csr_bucket_slots())
+            if ksel <= B and q_count * B * 12 <= torch.cuda.mem_get_info(dev)[0] // 4:
+                cursor = keep_cnt.clone()
+                if n_flag_h > 0 and fb_total > 0:
+                    cursor[flag_rows[:n_flag_h].to(torch.int64)] = fb_cnt
+                tcol = torch.empty(q_count * B, dtype=torch.int32, device=dev)
+                tval = torch.empty(q_count * B, dtype=torch.float64, device=dev)
+                check(lib.meld_coo_emit_scatter(q_count, ptr(cand_idx), ptr(cand_val), ksel, cap, ptr(keep_cnt), ptr(flag_rows), n_flag_h,
+                                                ptr(fb_off), ptr(fb_col), ptr(fb_val), fb_total, ptr(cursor), ptr(tcol), ptr(tval), st),
+                      "meld_coo_emit_scatter")
+                tm.stop("coo_emit")
+                assembled = self._finish_buckets(cursor, tcol, tval, q_count)  # None: a bucket overflowed / a column thrice
+                tm.stop("symmetrize")
+                del cursor, tcol, tval
+        keys = vals = None
+        if assembled is None:
+            keys = torch.empty(2 * M, dtype=torch.int64, device=dev)
+            vals = torch.empty(2 * M, dtype=torch.float64, device=dev)
+        if M > 0 and assembled is None:
             check(
                 lib.meld_coo_emit(
                     q_begin, q_count, ptr(cand_idx), ptr(cand_val), ptr(cand_cnt), ksel, cap, ptr(keep_off), ptr(flag_rows),
@@ -799,6 +819,8 @@ class HipOps:
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
                     wave_tiles_done=int(tiles_done.item()) if tiles_done is not None else None)
+        if assembled is not None:
+            info["assembled"] = assembled  # (rowptr, col, val) of the symmetrised rows: the caller skips assemble_rows
         return keys, vals, bw, info
 
     # ---- A4: (K + K^T)/2 rows [row_begin, row_begin + n_rows) from unsorted COO ---------------------
@@ -826,6 +848,26 @@ class HipOps:
                                                  int(cap), ptr(counts), ptr(send), _stream()), "meld_coo_partition_remote")
         return send, counts
 
+    def _finish_buckets(self, cursor, tcol, tval, n_rows):
+        """Row buckets (meld_coo_scatter_rows / meld_coo_emit_scatter) -> CSR: every bucket sorted by column and its pairs
+        of equal columns summed inside one wave, then compacted.  None when a bucket overflowed or a column occurs more
+        than twice (the caller takes the sort-based path, whose summation order is defined)."""
+        lib, st, dev = self.lib, _stream(), cursor.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        ucnt = torch.empty(n_rows, **i32)
+        flags = torch.empty(1, **i32)
+        check(lib.meld_csr_rows_sort_merge(ptr(cursor), n_rows, ptr(tcol), ptr(tval), ptr(ucnt), ptr(flags), st), "meld_csr_rows_sort_merge")
+        rowptr = _scan_i32(lib, ucnt, st)
+        nnz, flag = (int(v) for v in torch.stack([rowptr[n_rows], flags[0].to(torch.int64)]).tolist())  # (one read-back)
+        if flag != 0:
+            return None
+        col = torch.empty(nnz, **i32)
+        val = torch.empty(nnz, dtype=torch.float64, device=dev)
+        if nnz > 0:
+            check(lib.meld_csr_compact_rows(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), st), "meld_csr_compact_rows")
+        self.last_assemble = "bucket"
+        return rowptr, col, val
+
     def assemble_rows(self, keys, vals, row_begin, n_rows, N, foreign=False):
         """Sum duplicate keys, build the CSR (sorted rows) of the local rows: by row buckets sorted inside one wave
         each (include/meld_hip.h, meld_coo_row_counts ...), or -- for the inputs that path refuses, and with
@@ -845,19 +887,10 @@ class HipOps:
             tcol = torch.empty(n_rows * B, **i32)
             tval = torch.empty(n_rows * B, dtype=torch.float64, device=dev)
             check(lib.meld_coo_scatter_rows(ptr(keys), ptr(vals), n, row_begin, n_rows, ptr(cursor), ptr(tcol), ptr(tval), st), "meld_coo_scatter_rows")
-            ucnt = torch.empty(n_rows, **i32)
-            flags = torch.empty(1, **i32)
-            check(lib.meld_csr_rows_sort_merge(ptr(cursor), n_rows, ptr(tcol), ptr(tval), ptr(ucnt), ptr(flags), st), "meld_csr_rows_sort_merge")
-            rowptr = _scan_i32(lib, ucnt, st)
-            nnz, flag = (int(v) for v in torch.stack([rowptr[n_rows], flags[0].to(torch.int64)]).tolist())  # (one read-back)
-            if flag == 0:
-                col = torch.empty(nnz, **i32)
-                val = torch.empty(nnz, dtype=torch.float64, device=dev)
-                if nnz > 0:
-                    check(lib.meld_csr_compact_rows(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), st), "meld_csr_compact_rows")
-                self.last_assemble = "bucket"
-                return rowptr, col, val
-            del cursor, ucnt, tcol, tval, rowptr
+            done = self._finish_buckets(cursor, tcol, tval, n_rows)
+            if done is not None:
+                return done
+            del cursor, tcol, tval
         self.last_assemble = "sort" if n > 0 else "empty"
         if foreign and n > 0:
             rows = keys >> 32  # (the sentinel ~0 is -1 as int64: its row is negative)
@@ -1131,11 +1164,14 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
             X = X.index_select(0, perm)
         tm.stop("reorder")
 
-    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback)
-    if keys.shape[0] == 0:
+    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True)
+    if info.get("nnz_directed", 0) == 0:
         raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
     tm.start()
-    rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
+    if info.get("assembled") is not None:  # (the kept candidates went straight into the row buckets)
+        rowptr, col, val = info.pop("assembled")
+    else:
+        rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
     del keys, vals
     tm.stop("symmetrize")
     ksum = ops.row_sums(rowptr, val, N, 1.0)

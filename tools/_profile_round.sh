@@ -7,7 +7,7 @@
 tag=${1:-r03}; commit=${2:-unknown}; quick=${3:-}
 out=gpurun_out/prof_$tag; mkdir -p $out/pmc; export TMPDIR=/tmp
 stamp() { echo "# commit $commit, $(date -u +%Y-%m-%dT%H:%MZ), $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"; }
-cpu="--cpu-sample 40000"; [ -z "$quick" ] && cpu=""
+cpu=""; [ "$quick" = "cpufull" ] && cpu="--cpu-full"   # (the 27-minute CPU protocol only when asked for)
 for n in 1000000 500000; do
   c=$cpu; [ $n != 1000000 ] && c="--cpu-sample 0"
   python bench.py --cells $n $c 2>$out/bench_$n.err > $out/bench_$n.json
