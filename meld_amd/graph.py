@@ -781,7 +781,8 @@ class HipOps:
 
         M = m_main + fb_total
         assembled = None
-        if assemble and M > 0 and q_begin == 0 and q_count == NR and not cross and os.environ.get("MELD_ASSEMBLE", "bucket") == "bucket":
+        if assemble and M > 0 and q_begin == 0 and q_count == NR and not cross and os.environ.get("MELD_ASSEMBLE", "bucket") == "bucket" \
+                and os.environ.get("MELD_ASSEMBLE_FUSED", "1") != "0":
             # single GPU, every row local: the kept candidates go straight into the row buckets of the symmetrisation
             # (meld_coo_emit_scatter) instead of through 2 M (key, value) pairs -- 512 MB written and read back at 1M cells
             B = int(lib.meld_csr_bucket_slots())

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from functools import partial
 
+import os
+
 import numpy as np
 import pandas as pd
 import torch
@@ -399,7 +401,8 @@ class MELD(GraphEstimator):
         try:
             raw = np.asarray(getattr(sample_labels, "values", sample_labels))
             if (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
-                    and torch.cuda.is_available() and not isinstance(X, str):
+                    and torch.cuda.is_available() and not isinstance(X, str) \
+                    and os.environ.get("MELD_LABEL_OVERLAP", "1") != "0":
                 from . import graph as _graph
 
                 dev = torch.device("cuda", torch.cuda.current_device())
