@@ -737,3 +737,42 @@ def test_assign_nearest_on_the_matrix_pipe_matches_brute_force(n, d, npg, n_grou
     assert diff.shape[0] < 0.002 * n
     scale = (X ** 2).sum(1) + (C ** 2).sum(-1).max(1)
     assert np.all(d2[diff, got[diff]] - d2[diff, best[diff]] <= 2e-5 * scale[diff])
+
+
+def test_ordering_glue_kernels_match_numpy():
+    """meld_argsort_u32 (stable, over the key bits only), meld_order_starts, meld_order_pick_centroids and
+    meld_order_update_keys against their NumPy definitions, groups of every size including empty ones."""
+    from meld_amd._lib import check, get_lib, ptr
+
+    lib = get_lib()
+    rng = np.random.default_rng(11)
+    n, d, n_groups, f = 70001, 9, 300, 7
+    key = rng.integers(0, n_groups - 5, n).astype(np.int32)  # (the last groups stay empty)
+    key[key == 17] = 18                                       # ... and one in the middle
+    X = rng.normal(size=(n, d))
+    st = torch.cuda.current_stream().cuda_stream
+    kd, Xd = torch.from_numpy(key).cuda(), torch.from_numpy(X).cuda()
+    order = torch.empty(n, dtype=torch.int64, device="cuda")
+    skeys = torch.empty(n, dtype=torch.int32, device="cuda")
+    tb = lib.meld_argsort_u32_temp_bytes(n)
+    tmp = torch.empty(tb, dtype=torch.uint8, device="cuda")
+    check(lib.meld_argsort_u32(ptr(kd), n, int(n_groups - 1).bit_length(), ptr(order), ptr(skeys), ptr(tmp), tb, st), "argsort")
+    want = np.argsort(key, kind="stable")
+    np.testing.assert_array_equal(order.cpu().numpy(), want)
+    np.testing.assert_array_equal(skeys.cpu().numpy(), key[want])
+    starts = torch.empty(n_groups + 1, dtype=torch.int64, device="cuda")
+    check(lib.meld_order_starts(ptr(skeys), n, n_groups, ptr(starts), st), "starts")
+    s_np = np.searchsorted(key[want], np.arange(n_groups + 1), side="left")
+    np.testing.assert_array_equal(starts.cpu().numpy(), s_np)
+    cents = torch.empty(n_groups * f, d, dtype=torch.float64, device="cuda")
+    check(lib.meld_order_pick_centroids(ptr(Xd), n, d, ptr(order), ptr(starts), n_groups, f, ptr(cents), st), "picks")
+    cnt = np.diff(s_np)
+    frac = (np.arange(f) + 0.5) / f
+    pick = s_np[:-1, None] + (frac[None, :] * cnt[:, None]).astype(np.int64)
+    pick = np.minimum(pick, (s_np[:-1] + np.maximum(cnt - 1, 0))[:, None]).clip(0, n - 1)
+    np.testing.assert_array_equal(cents.cpu().numpy(), X[want[pick.reshape(-1)]])
+    child = rng.integers(0, f, n).astype(np.int32)
+    rank = np.stack([rng.permutation(f) for _ in range(n_groups)]).astype(np.int32)
+    cd, rd = torch.from_numpy(child).cuda(), torch.from_numpy(rank.reshape(-1)).cuda()
+    check(lib.meld_order_update_keys(ptr(kd), ptr(cd), ptr(rd), n, f, st), "update")
+    np.testing.assert_array_equal(kd.cpu().numpy(), key * f + rank[key, child])
