@@ -197,9 +197,22 @@ __global__ __launch_bounds__(256) void assign_nearest_tiled_kernel(const double*
 // of row i along the chain.  (Was a host loop: the device -> host copy, the NumPy walk and the copy back
 // cost 4.6 ms at 1M cells with three levels.)
 __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restrict__ P, int m, int d,
-                                                         int* __restrict__ rank) {
+                                                         int* __restrict__ rank, int use_lds) {
+  // the group's rows are staged in LDS once (row stride d + 1 doubles): every step of the walk reads the current row
+  // (broadcast) and each lane its own -- from global memory that was 2 d dependent-latency loads per lane and step, 5 us per
+  // step and 0.3-0.4 ms per level of the ordering, all of it on the critical path of the level
+  extern __shared__ __attribute__((aligned(16))) double chain_lds[];
   const int lane = threadIdx.x;
-  const double* Pg = P + (size_t)blockIdx.x * m * d;
+  const double* Pg0 = P + (size_t)blockIdx.x * m * d;
+  const int ld = use_lds ? d + 1 : d;  // (rows too wide for the LDS a launch may ask for stay in global memory)
+  const double* Pr = use_lds ? chain_lds : Pg0;
+  if (use_lds) {
+    for (int u = lane; u < m * d; u += 64) {
+      const int r = u / d, k = u - r * d;
+      chain_lds[r * ld + k] = Pg0[u];
+    }
+    __syncthreads();
+  }
   int* rg = rank + (size_t)blockIdx.x * m;
   auto argmin = [&](double v) {  // lowest index among the minima
     int i = lane;
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restric
     return i;
   };
   bool used = lane >= m;
-  int cur = argmin(lane < m ? Pg[(size_t)lane * d] : INFINITY);
+  int cur = argmin(lane < m ? Pr[lane * ld] : INFINITY);
   if (lane == cur) {
     used = true;
     rg[lane] = 0;
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restric
     if (!used) {
       dist = 0.0;
       for (int k = 0; k < d; ++k) {
-        const double t = Pg[(size_t)lane * d + k] - Pg[(size_t)cur * d + k];
+        const double t = Pr[lane * ld + k] - Pr[cur * ld + k];
         dist = fma(t, t, dist);
       }
     }
@@ -493,7 +506,9 @@ extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const doub
 
 extern "C" int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream) {
   MELD_CHECK_ARG(P && rank && n_groups > 0 && m >= 1 && m <= 64 && d > 0, "meld_chain_order: bad arguments (1 <= m <= 64)");
-  hipLaunchKernelGGL(chain_order_kernel, dim3((unsigned)n_groups), dim3(64), 0, S(stream), P, m, d, rank);
+  const size_t chain_bytes = sizeof(double) * (size_t)m * (d + 1);
+  const int use_lds = chain_bytes <= 60 * 1024 ? 1 : 0;
+  hipLaunchKernelGGL(chain_order_kernel, dim3((unsigned)n_groups), dim3(64), use_lds ? chain_bytes : 0, S(stream), P, m, d, rank, use_lds);
   MELD_LAUNCH_CHECK("chain_order_kernel");
   return MELD_OK;
 }
