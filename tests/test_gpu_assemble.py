@@ -86,3 +86,19 @@ def test_long_rows_and_repeated_keys_take_the_sort_path(monkeypatch):
     rb, cb, vb = _assemble(keys3, vals3, 0, N, N, "bucket", monkeypatch)
     rs, cs, vs = _assemble(keys3, vals3, 0, N, N, "sort", monkeypatch)
     assert np.array_equal(rb, rs) and np.array_equal(cb, cs) and np.array_equal(vb, vs)
+
+
+@pytest.mark.parametrize("n,force", [(30000, False), (6000, True)])
+def test_candidates_straight_into_the_buckets_build_the_same_graph(n, force, monkeypatch):
+    """meld_coo_emit_scatter (single GPU: the kept candidates go into the row buckets without the COO detour) builds bit for
+    bit the CSR of the emit + scatter path -- also when every row comes from the exact sweep (force_fallback)."""
+    import meld_amd
+
+    rng = np.random.default_rng(5)
+    X = torch.from_numpy(rng.normal(size=(n, 12))).cuda()
+    monkeypatch.setenv("MELD_ASSEMBLE_FUSED", "1")
+    A = meld_amd.build_knn_graph(X, knn=9, force_fallback=force)
+    monkeypatch.setenv("MELD_ASSEMBLE_FUSED", "0")
+    B = meld_amd.build_knn_graph(X, knn=9, force_fallback=force)
+    assert torch.equal(A.rowptr, B.rowptr) and torch.equal(A.col, B.col) and torch.equal(A.val, B.val)
+    assert torch.equal(A.dw_dev, B.dw_dev)
