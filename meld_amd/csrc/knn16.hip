@@ -1156,7 +1156,12 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
   constexpr int NS = (HV + BT - 1) / BT;
   __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
-  __shared__ __attribute__((aligned(16))) float lds_sa[2][K16_TS], lds_sb[2][K16_TS];  // s_p^2, 2 s_p of the tile's cells
+  // SEEDED: the per-query terms ride on the matrix pipe too.  acc_pt - s_p^2 - 2 s_p rho_t = acc_pt + (s_p^2)(-1) + (s_p)(-2 rho_t):
+  // one more K block whose slots 0 and 1 hold (s_p^2, s_p) on the cell side and (-1, -2 rho_t) on the centroid side, i.e.
+  // one MFMA per accumulator on top of the plain distances instead of three VALU operations and two LDS reads per distance
+  // (the kernel was VALU-bound: ~220 vector instructions against 16 MFMAs per wave and tile).  fp16 products are exact in
+  // fp32; s_p^2, s_p and rho_t are rounded UP to fp16, which only keeps more tiles alive.
+  __shared__ __attribute__((aligned(16))) f16x8 lds_x[2][2 * K16_TS];  // per cell of the tile: (s_p^2, s_p, 0 ...); second half: zeros
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
   const int c_base = blockIdx.x * BT + wave * 64;
   f16x8 bhi[2][KB];
@@ -1168,6 +1173,16 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
     cn[g] = Cn[c_base + g * 32 + jq];
     cr[g] = Cr[c_base + g * 32 + jq];
+  }
+  f16x8 bx[2];  // centroid side of the extra K block: (-1, -2 rho_t, 0 ...) in the lower half-lanes
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bx[g][e] = (_Float16)0.0f;
+    if (h == 0) {
+      bx[g][0] = (_Float16)(-1.0f);
+      bx[g][1] = (_Float16)(-__half2float(__float2half_ru(2.0f * cr[g])));
+    }
   }
   const float err_abs = err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
   const int b_lo = (int)((long long)n_blocks * blockIdx.y / gridDim.y);
@@ -1205,8 +1220,14 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
       // the global one without the norms
       const float e_row = seed_nq >= 0.0f ? fminf((err_c * nmax_s + err_l * sqrtf(seed_nq * nmax_s)) * 1.001f, seed_margin) : seed_margin;
       const float sp = seed_v < 0.0f ? 0.0f : sqrtf(seed_v + e_row) * 1.0001f;
-      lds_sa[buf][tid] = sp * sp;
-      lds_sb[buf][tid] = seed_v < 0.0f || !(sp < INFINITY) ? 0.0f : 2.0f * sp;
+      f16x8 xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = (_Float16)0.0f;
+      xv[0] = (_Float16)__half2float(__float2half_ru(sp * sp));  // (+inf for a cell without a seed: acc - inf keeps the tile alive)
+      xv[1] = (seed_v < 0.0f || !(sp < INFINITY)) ? (_Float16)0.0f : (_Float16)__half2float(__float2half_ru(sp));
+      lds_x[buf][tid] = xv;
+      xv[0] = xv[1] = (_Float16)0.0f;
+      lds_x[buf][K16_TS + tid] = xv;
     }
   };
   if (n_steps <= 0) return;
@@ -1235,18 +1256,12 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
         m[0] = fminf(m[0], min16(c0));
         m[1] = fminf(m[1], min16(c1));
         if (SEEDED) {
-          // accumulator r of a lane = cell sub*32 + (r & 3) + 8 (r >> 2) + 4 h of the tile
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 sa = *reinterpret_cast<const float4*>(&lds_sa[buf][sub * 32 + 8 * r4 + 4 * h]);
-            const float4 sb = *reinterpret_cast<const float4*>(&lds_sb[buf][sub * 32 + 8 * r4 + 4 * h]);
-            const float a4[4] = {sa.x, sa.y, sa.z, sa.w}, b4[4] = {sb.x, sb.y, sb.z, sb.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              mb[0] = fminf(mb[0], fmaf(-b4[e], cr[0], c0[r4 * 4 + e] - a4[e]));
-              mb[1] = fminf(mb[1], fmaf(-b4[e], cr[1], c1[r4 * 4 + e] - a4[e]));
-            }
-          }
+          // (the extra block goes on top of the plain accumulators, in place: they are not needed afterwards)
+          const f16x8 ax = lds_x[buf][(h == 0 ? 0 : K16_TS) + sub * 32 + jq];  // (upper half-lanes: K slots 8 .. 15, all zero)
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax, bx[0], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ax, bx[1], c1, 0, 0, 0);
+          mb[0] = fminf(mb[0], min16(c0));
+          mb[1] = fminf(mb[1], min16(c1));
         }
       }
     }
