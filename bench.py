@@ -230,15 +230,21 @@ def main():
             return op, mdist.fit_transform_sharded(op, X, labels)
         return op, op.fit_transform(X, labels)
 
-    for _ in range(args.warmup):
-        one_step()
-    mgraph.record_events(True)
     # (as timeit does: no cyclic-GC pass of the interpreter inside the timed region -- with scipy / sklearn / pandas imported a
-    # generation-2 collection takes ~45 ms, and one landed in the 5th of 5 steps of a default run: 98.9 ms against 52.2-52.4)
+    # generation-2 collection takes ~45 ms, and one landed in the 5th of 5 steps of a default run: 98.9 ms against 52.2-52.4.
+    # Collected BEFORE the warm-up: the pass idles the GPU for ~0.1 s, and the first step after such a pause runs ~2 ms slower)
     import gc
 
     gc.collect()
     gc.disable()
+    op = dens = None
+    mgraph.record_events(True)  # (as in the timed loop: the first spans create the event pool)
+    for _ in range(args.warmup):
+        # (results held exactly as in the timed loop: the previous step's graph is alive while the next one is built, and a
+        # warm-up that dropped it at once left the allocator two steps short of its steady state -- +1.8 ms on the first
+        # two timed steps)
+        op, dens = one_step()
+    mgraph.record_events(True)
     barrier()
     t0 = time.perf_counter()
     step_ms = []
