@@ -227,7 +227,15 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
         X = pca_project(X, op.n_pca, seed=42 if op.random_state is None else int(op.random_state)).contiguous()
         op.data_nu = X
     op.X = X
-    op.graph = build_sharded_graph(
-        X, ops, comm, knn=op.knn, decay=op.decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
-    )
-    return op.transform(sample_labels)
+    # (the label factorisation of transform starts under this rank's candidate search, as on one GPU)
+    finish = op._prefactor_under_search(sample_labels, eligible=X.is_cuda) if hasattr(op, "_prefactor_under_search") else (lambda: None)
+    try:
+        op.graph = build_sharded_graph(
+            X, ops, comm, knn=op.knn, decay=op.decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
+        )
+    finally:
+        finish()
+    try:
+        return op.transform(sample_labels)
+    finally:
+        op._prefactored = None

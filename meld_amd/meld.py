@@ -394,15 +394,28 @@ class MELD(GraphEstimator):
     def fit_transform(self, X, sample_labels, **kwargs):
         """Builds the graph on ``X`` and estimates the density of each sample in
         ``sample_labels`` (reference ``meld/meld.py:252-274``)."""
-        # the labels are factorised first: on the device path that is a few small launches and two read-backs, which
-        # cost a millisecond of host latency behind a finished graph build and nothing in front of it
+        finish = self._prefactor_under_search(sample_labels, eligible=not isinstance(X, str))
+        try:
+            self.fit(X, **kwargs)
+        finally:
+            finish()
+        try:
+            return self.transform(sample_labels)
+        finally:
+            self._prefactored = None
+
+    def _prefactor_under_search(self, sample_labels, eligible=True):
+        """The label factorisation of ``transform`` (fixed-width labels of large inputs: a host-blocking copy, a sort, a few
+        gathers, two read-backs -- 1.2 ms at 1M cells) is independent of the graph: it is started by the graph build right
+        after the candidate search has been launched (``graph._WHILE_SEARCHING``), on a side stream, while the host would
+        otherwise wait for the search.  Returns ``finish()``: call it after the build; it reads the results and leaves them
+        in ``self._prefactored`` for the ``transform`` that follows (or leaves nothing, and ``transform`` factorises as usual)."""
         self._prefactored = None
         pending, hook = {}, None
         try:
             raw = np.asarray(getattr(sample_labels, "values", sample_labels))
-            if (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
-                    and torch.cuda.is_available() and not isinstance(X, str) \
-                    and os.environ.get("MELD_LABEL_OVERLAP", "1") != "0":
+            if eligible and (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
+                    and torch.cuda.is_available() and os.environ.get("MELD_LABEL_OVERLAP", "1") != "0":
                 from . import graph as _graph
 
                 dev = torch.device("cuda", torch.cuda.current_device())
@@ -421,15 +434,13 @@ class MELD(GraphEstimator):
                 _graph._WHILE_SEARCHING.append(hook)
         except Exception:
             hook = None
-        try:
-            self.fit(X, **kwargs)
-        finally:
+
+        def finish():
             if hook is not None:
                 from . import graph as _graph
 
                 if hook in _graph._WHILE_SEARCHING:  # (no search was launched: small N, a precomputed graph, ...)
                     _graph._WHILE_SEARCHING.remove(hook)
-        try:
             if pending.get("h") is not None:
                 try:
                     fz = self._factorize_device_end(pending["h"])
@@ -437,6 +448,5 @@ class MELD(GraphEstimator):
                     fz = None
                 if fz is not None:
                     self._prefactored = (sample_labels, fz)
-            return self.transform(sample_labels)
-        finally:
-            self._prefactored = None
+
+        return finish
