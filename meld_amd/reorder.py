@@ -1,12 +1,15 @@
 """Cache-locality permutation of the cells (no reference counterpart; see csrc/reorder.hip).
 
-``locality_permutation(X)`` returns ``perm`` (int64, device) with ``X_new = X[perm]``: cells are
-grouped by their nearest of C1 coarse centroids (random cells, fixed seed) and, inside a coarse
-cell, by their nearest of C2 sub-centroids; centroids are ordered by a greedy nearest-neighbour
-chain so that consecutive groups are close in space.  Leaves hold ~N / (C1*C2) cells (~250 at 1M),
-so a row block of the recurrence kernel gathers mostly from its own few KiB of the iterate.
-The graph, and therefore every result, is independent of the order (tests compare against the
-oracle in the original order); only memory locality changes.
+``locality_permutation(X)`` returns ``perm`` (int64, device) with ``X_new = X[perm]``: cells are grouped by their nearest of
+C1 coarse centroids (random cells, fixed seed), inside a coarse cell by their nearest of F1 sub-centroids, and once more by
+F2; the centroids of every group are ordered by a greedy nearest-neighbour chain, so that consecutive groups are close in
+space.  The fan-outs are chosen for leaves of ~16 cells ((64; 32, 32) at 1M cells): a 64-cell reference tile of the search is
+then four neighbouring leaves -- what the pruning bounds of the search pay for -- and a row block of the recurrence kernel
+gathers mostly from its own part of the iterate.  One 32-bit key per cell (the position of its group along the chains) is the
+group id of the next level; a level is six launches (``meld_assign_nearest`` on the matrix pipe, the chain beside it,
+``meld_order_update_keys``, ``meld_argsort_u32``, ``meld_order_starts``, ``meld_order_pick_centroids``).
+The graph, and therefore every result, is independent of the order (tests compare against the oracle in the original order);
+only memory locality and the cost of the search change.
 """
 from __future__ import annotations
 
