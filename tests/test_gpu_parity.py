@@ -405,8 +405,9 @@ def test_unweighted_knn_graph_decay_none(n, d, knn):
     assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
-def test_two_ranks_on_one_gpu(tmp_path):
-    """Both ranks of a 2-rank group run the real HIP kernels on this GPU (collectives staged through host
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_on_one_gpu(tmp_path, world):
+    """All ranks of a 2- (3-) rank group run the real HIP kernels on this GPU (collectives staged through host
     memory over gloo, see tests/dist_worker_gpu.py): every rank must return the single-GPU result."""
     import socket
     import subprocess
@@ -421,15 +422,16 @@ def test_two_ranks_on_one_gpu(tmp_path):
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "res")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn)]
     res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(2)]
+    ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
     ref = single.fit_transform(X, labels)
-    assert [int(r["row_begin"]) for r in ranks] == [0, -(-((n + 1) // 2) // 256) * 256]  # shards = whole search workgroups
+    per = -(-(-(-n // world)) // 256) * 256  # shards = whole search workgroups
+    assert [int(r["row_begin"]) for r in ranks] == [min(i * per, n) for i in range(world)]
     assert int(ranks[0]["nnz_global"]) == single.graph.nnz
     assert bool(ranks[0]["device_resident"])  # the phase-wise Lanczos ran, not the host loop
     assert int(ranks[0]["all_reduces"]) == 1  # ... in its one-reduction form
