@@ -117,6 +117,16 @@ int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, con
                       const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
                       const float* thr_seed, const float* q_norm2 /* optional: Qn of meld_knn16_prepare, per-row allowance */,
                       int nprod, void* temp, void* lb2, meld_stream_t stream);
+/* The same in two calls, for a row-sharded build: every rank computes the spheres of a range of tiles into its slots of a zeroed
+ * temp (three arrays, meld_knn16_sphere_layout: [rows][row_bytes] centres, [rows] fp32 |c|^2, [rows] fp32 radii), the ranks
+ * all-gather them, and the table is built from the complete arrays. */
+int meld_knn16_tile_spheres(const double* X, int64_t N, int d, const double* mean, const float* scale_info, void* temp,
+                            int64_t tile_begin, int64_t tile_count, meld_stream_t stream);
+int meld_knn16_sphere_layout(int64_t n_ref, int d, int64_t* rows, int64_t* row_bytes);
+int meld_knn16_bounds_from_spheres(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                      const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
+                      const float* thr_seed, const float* q_norm2 /* optional: Qn of meld_knn16_prepare, per-row allowance */,
+                      int nprod, void* temp, void* lb2, meld_stream_t stream);
 /* nprod selects the precision of the products: 3 = hi.hi + hi.lo + lo.hi (error bound
  * 2^-14 max|x~|^2), 1 = hi.hi only (a third of the MFMAs, bound 2^-9 |x~_q| max|x~|; rows the looser
  * bound cannot certify are searched again / go through meld_knn_radius_exact, so results are

@@ -49,6 +49,9 @@ SIGNATURES = {
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),
     "meld_knn16_bounds_temp_bytes": (_sz, [_i64, _i32, _i64]),
     "meld_knn16_bounds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+    "meld_knn16_bounds_from_spheres": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+    "meld_knn16_tile_spheres": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _ptr]),
+    "meld_knn16_sphere_layout": (_i32, [_i64, _i32, _ptr, _ptr]),
     "meld_knn16_topk": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _i32, _i32, _ptr, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_block_work": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_seed_thresholds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),

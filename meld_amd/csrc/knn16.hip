@@ -1026,11 +1026,12 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
                                                            const double* __restrict__ mean,
                                                            const float* __restrict__ scale_info, int KB,
                                                            _Float16* __restrict__ cent16, float* __restrict__ cent_n,
-                                                           float* __restrict__ cent_r) {
+                                                           float* __restrict__ cent_r, int tile0) {
   __shared__ float xs[K16_TS][K16_DMAX + 4];
   __shared__ float cs[K16_DMAX + 19];
   const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * K16_TS;
+  const int tile = tile0 + (int)blockIdx.x;  // (a row-sharded build computes the spheres of a range of tiles per rank)
+  const int64_t row0 = (int64_t)tile * K16_TS;
   const int cnt = (int)min((int64_t)K16_TS, N - row0);
   const float s = scale_info[0];
   for (int u = tid; u < K16_TS * d; u += 256) {
@@ -1104,8 +1105,8 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
     float n = 0.0f;
     for (int k = 0; k < d; ++k) n = fmaf(cs[k], cs[k], n);
     if (tid == 0) {
-      cent_r[blockIdx.x] = sqrtf(r2) * 1.0001f + 1e-30f;
-      cent_n[blockIdx.x] = n;
+      cent_r[tile] = sqrtf(r2) * 1.0001f + 1e-30f;
+      cent_n[tile] = n;
     }
   } else if (tid - 64 < KB * 2) {
     const int g = tid - 64;
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
       hi[e] = h16;
       lo[e] = l16;
     }
-    f16x8* qrow = reinterpret_cast<f16x8*>(cent16) + (size_t)blockIdx.x * ((size_t)KB * 4);
+    f16x8* qrow = reinterpret_cast<f16x8*>(cent16) + (size_t)tile * ((size_t)KB * 4);
     qrow[g * 2 + 0] = hi;
     qrow[g * 2 + 1] = lo;
   }
@@ -1794,10 +1795,41 @@ extern "C" size_t meld_knn16_bounds_temp_bytes(int64_t n_ref, int d, int64_t q_c
   return n_c * ((size_t)kb * 64 + 2 * sizeof(float)) + 256;
 }
 
-extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                                 const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
-                                 const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* lb2,
-                                 meld_stream_t stream) {
+// The tile spheres alone, for the tiles [tile_begin, tile_begin + tile_count) (centres as query-operand rows, |c|^2, radii ->
+// their slots of temp, which the caller has zeroed): they depend on the cells only, so the ranks of a row-sharded build
+// compute a share each and all-gather the three arrays (meld_knn16_sphere_layout) before meld_knn16_bounds_from_spheres.
+extern "C" int meld_knn16_tile_spheres(const double* X, int64_t N, int d, const double* mean, const float* scale_info, void* temp,
+                                       int64_t tile_begin, int64_t tile_count, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && scale_info && temp && N > 0 && tile_begin >= 0 && tile_count >= 0, "meld_knn16_tile_spheres: bad arguments");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int n_t = (int)ceil_div(N, K16_TS);
+  MELD_CHECK_ARG(tile_begin + tile_count <= n_t, "meld_knn16_tile_spheres: tile range beyond the %d tiles", n_t);
+  if (tile_count == 0) return MELD_OK;
+  const size_t n_c = (size_t)ceil_div(n_t, K16_BOUNDS_THREADS) * K16_BOUNDS_THREADS;
+  _Float16* c16 = reinterpret_cast<_Float16*>(temp);
+  float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
+  float* cr = cn + n_c;
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3((unsigned)tile_count), dim3(256), 0, S(stream), X, N, d, mean, scale_info, KB, c16, cn, cr,
+                     (int)tile_begin);
+  MELD_LAUNCH_CHECK("tile_spheres_kernel");
+  return MELD_OK;
+}
+// rows (= tiles, padded to whole workgroups of the table kernel) and bytes per row of the three arrays in temp:
+// [rows][row_bytes] centres, then [rows] fp32 |c|^2, then [rows] fp32 radii
+extern "C" int meld_knn16_sphere_layout(int64_t n_ref, int d, int64_t* rows, int64_t* row_bytes) {
+  MELD_CHECK_ARG(rows && row_bytes && n_ref > 0, "meld_knn16_sphere_layout: bad arguments");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  *rows = (int64_t)(ceil_div(ceil_div(n_ref, K16_TS), K16_BOUNDS_THREADS) * K16_BOUNDS_THREADS);
+  *row_bytes = (int64_t)KB * 64;
+  return MELD_OK;
+}
+
+static int k16_bounds_impl(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                           const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
+                           const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* lb2,
+                           meld_stream_t stream, bool spheres_ready) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_bounds: nprod must be 1 or 3");
   MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && temp && lb2 && N > 0 && q_count > 0 && q_begin >= 0 &&
                      q_begin + q_count <= N,
@@ -1811,8 +1843,10 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
   _Float16* c16 = reinterpret_cast<_Float16*>(temp);
   float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
   float* cr = cn + n_c;
-  MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
-  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr);
+  if (!spheres_ready) {
+    MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
+    hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+  }
   const int bt = KB <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2;
   const int gx = (int)(n_c / bt);
   const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
@@ -1857,6 +1891,18 @@ extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double
     MELD_LAUNCH_CHECK("knn16_bounds_symmetrize_kernel");
   }
   return MELD_OK;
+}
+extern "C" int meld_knn16_bounds(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                 const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
+                                 const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* lb2,
+                                 meld_stream_t stream) {
+  return k16_bounds_impl(X, N, d, mean, scale_info, norm2_max, Rt16, q_begin, q_count, thr_seed, q_norm2, nprod, temp, lb2, stream, false);
+}
+extern "C" int meld_knn16_bounds_from_spheres(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                              const float* norm2_max, const void* Rt16, int64_t q_begin, int64_t q_count,
+                                              const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* lb2,
+                                              meld_stream_t stream) {
+  return k16_bounds_impl(X, N, d, mean, scale_info, norm2_max, Rt16, q_begin, q_count, thr_seed, q_norm2, nprod, temp, lb2, stream, true);
 }
 
 // Tiles a search workgroup will stage at most: those some wave of it cannot rule out at its start thresholds (the

@@ -130,7 +130,11 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
     dev = X.device
 
     if n_loc > 0:
-        keys, vals, bw, info = ops.directed_kernel_coo(X, r0, n_loc, knn, decay, thresh, ksel)
+        # (collectives inside the build -- the shared tile spheres -- only when EVERY rank builds rows: a rank without rows
+        # never gets here; the test is the same on all ranks)
+        every_rank_has_rows = (comm.world - 1) * R < N
+        extra = {"comm": comm} if (getattr(ops, "shards_spheres", False) and every_rank_has_rows) else {}
+        keys, vals, bw, info = ops.directed_kernel_coo(X, r0, n_loc, knn, decay, thresh, ksel, **extra)
     else:
         keys = torch.empty(0, dtype=torch.int64, device=dev)
         vals = torch.empty(0, dtype=torch.float64, device=dev)

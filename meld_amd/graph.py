@@ -415,7 +415,7 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
-    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False):
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -554,9 +554,29 @@ class HipOps:
                 # its own start threshold, see meld_knn16_bounds)
                 tb = lib.meld_knn16_bounds_temp_bytes(N, d, q_count)
                 tmpb = torch.empty(tb, dtype=torch.uint8, device=dev)
+                spheres_shared = False
+                if comm is not None and getattr(comm, "world", 1) > 1:
+                    # row-sharded build: the spheres of the reference tiles are the same on every rank (0.7 ms at 1M cells):
+                    # every rank computes 1 / world of them and the three arrays are all-gathered (4 MB in all)
+                    import ctypes as C
+
+                    rows_c, row_b = C.c_int64(0), C.c_int64(0)
+                    check(lib.meld_knn16_sphere_layout(N, d, C.byref(rows_c), C.byref(row_b)), "meld_knn16_sphere_layout")
+                    rows_c, row_b = int(rows_c.value), int(row_b.value)
+                    if rows_c % comm.world == 0:
+                        per = rows_c // comm.world
+                        t0s = min(comm.rank * per, n_tiles)
+                        t1s = min(t0s + per, n_tiles)
+                        tmpb.zero_()
+                        check(lib.meld_knn16_tile_spheres(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(tmpb), t0s, max(t1s - t0s, 0), st), "meld_knn16_tile_spheres")
+                        parts = (tmpb[: rows_c * row_b], tmpb[rows_c * row_b : rows_c * (row_b + 4)], tmpb[rows_c * (row_b + 4) : rows_c * (row_b + 8)])
+                        for arr, width in zip(parts, (row_b, 4, 4)):
+                            mine = arr[comm.rank * per * width : (comm.rank + 1) * per * width].clone()
+                            comm.all_gather_rows(arr, mine)
+                        spheres_shared = True
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 seeded_bounds = seeds is not None and self.seeded_bounds
-                check(lib.meld_knn16_bounds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 if self.block_order and q_main == q_count and n_blocks > 1:
                     # longest query blocks first (the dispatch follows the block index): see meld_knn16_block_work
                     work = torch.empty(n_blocks, dtype=torch.int32, device=dev)
@@ -924,6 +944,7 @@ class HipOps:
         return self.lib.meld_spmm_dot_slots()
 
     # ---- panel-tiled copy of W for the recurrence (csrc/spmm_tiled.hip) -----------------------------
+    shards_spheres = True  # directed_kernel_coo(comm=...) splits the tile spheres of the pruning table over the ranks
     PT_MIN_ROWS = 65536  # below this the CSR-stream kernel is launch-bound anyway and the layout does not pay
 
     _pt_selfcheck = {"done": False, "ok": True}

@@ -63,12 +63,14 @@ if os.environ.get("TRACE"):  # name the stage a fault happens in: synchronise an
                  "lanczos_fold", "lanczos_axpy3", "cheby_step", "sort_pairs"):
         setattr(HipOps, name, traced(name, getattr(HipOps, name)))
 
-# two places where wrong data would change the WORK: the ordering (garbage children = no locality = no pruning) is computed
+# three places where wrong data would change the WORK: the ordering (garbage children = no locality = no pruning) is computed
 # unsharded (its assignment passes then cost 8/8 instead of 1/8 of 0.85 ms), and the lmax estimate (garbage vectors never
 # converge) is stopped after the 35 iterations the real graph needs
 from meld_amd import reorder as _ro, filter as _mf
 _lp = _ro.locality_permutation
 _ro.locality_permutation = lambda X, *a, comm=None, **k: _lp(X, *a, **k)
+from meld_amd.graph import HipOps as _HipOps
+_HipOps.shards_spheres = False  # (likewise: stand-in spheres of the other ranks' tiles would wreck the pruning; a real rank computes 1 / world of the 0.7 ms)
 _fold = _mf._lanczos_lmax_folded
 _mf._lanczos_lmax_folded = lambda G, ops, comm, u0, tol, max_iter, check_every: _fold(G, ops, comm, u0, tol, 35, check_every)
 
