@@ -6,8 +6,9 @@
 // W is static over the ~65 steps of a fit_transform (35 Lanczos + 29 Chebyshev), so it is re-laid out once
 // (round-3 layout):
 //
-//   * rows are cut into nb blocks of <= RMAX rows with balanced nonzero counts, ONE block per CU; the block's
-//     accumulators (one per row) live in LDS for the whole step;
+//   * rows are cut into nb blocks of <= RMAX rows with balanced estimated TIME (entries + far-reaching entries + rows,
+//     pt_row_weight_kernel; balanced nonzero counts when there is no scratch for the weights), ONE block per CU; the
+//     block's accumulators (one per row) live in LDS for the whole step;
 //   * IN part -- W is symmetric, and 40 % of a block's nonzeros (1M-cell benchmark graph, locality order) have
 //     their column inside the block's own row range.  Those are stored ONCE per pair (i < j): the block's own
 //     slice of the iterate is staged in LDS, a pair contributes v x_j to row i and v x_i to row j.  12 bytes
