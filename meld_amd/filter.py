@@ -67,6 +67,45 @@ def _stream():
 _PINNED = {}  # (shape, dtype) -> pinned host staging buffer of the last result copied back
 
 
+class _PinnedPool:
+    """Pinned result buffers handed to the caller WITHOUT a host copy.  The densities leave the device through pinned memory
+    (pageable copies run at a few GB/s) and used to be copied once more into a fresh array because the staging buffer is
+    reused by the next call (0.4 ms for 16 MB).  Now the caller's array IS the pinned buffer: a finalizer on that array --
+    which fires when the array and every view of it (the DataFrame's) are gone -- returns the buffer to the pool.  At most
+    ``MAX_OUT`` buffers of a shape are lent out at a time (pinning a new one costs milliseconds and pinned memory is a
+    shared resource); beyond that the result is copied as before."""
+
+    MAX_OUT = 4
+
+    def __init__(self):
+        self.free = {}  # key -> [tensor, ...]
+        self.out = {}   # key -> number lent out
+
+    def lend(self, r):
+        """r: device tensor -> numpy array with its values (device synchronised), or None when the pool is exhausted."""
+        import weakref
+
+        key = (tuple(r.shape), r.dtype)
+        free = self.free.setdefault(key, [])
+        if not free and self.out.get(key, 0) >= self.MAX_OUT:
+            return None
+        stage = free.pop() if free else torch.empty(r.shape, dtype=r.dtype, pin_memory=True)
+        stage.copy_(r, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        arr = stage.numpy()
+        self.out[key] = self.out.get(key, 0) + 1
+
+        def back(pool=self, key=key, stage=stage):
+            pool.out[key] = pool.out.get(key, 1) - 1
+            pool.free.setdefault(key, []).append(stage)
+
+        weakref.finalize(arr, back)
+        return arr
+
+
+_POOL = _PinnedPool()
+
+
 def spectral_kernel(name, beta, offset, order, lmax):
     """h(lambda) of reference ``meld/filter.py:42-53``."""
     lname = name.lower()
@@ -482,7 +521,10 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
             r_orig[perm] = r
             r = r_orig
         # D2H through a pinned staging buffer kept on the graph (pageable copies run at a few GB/s)
-        if r.is_cuda:
+        out = _POOL.lend(r) if (r.is_cuda and os.environ.get("MELD_PINNED_RESULT", "1") != "0") else None
+        if out is not None:
+            pass
+        elif r.is_cuda:
             stage = _PINNED.get((tuple(r.shape), r.dtype))  # (process-wide: a new graph per fit would pin 16 MB each time)
             if stage is None:
                 _PINNED.clear()

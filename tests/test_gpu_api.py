@@ -607,3 +607,30 @@ def test_one_reduction_lanczos_equals_the_device_resident_loop(n):
     t_fld, i_fld = mf._lanczos_lmax_folded(G, ops, None, u, 1e-3, 300, 5)
     assert i_fld["iterations"] == i_dev["iterations"] == i_pha["iterations"] and i_fld["all_reduces_per_iteration"] == 1
     assert abs(t_fld - t_dev) < 1e-10 * t_dev and abs(t_pha - t_dev) < 1e-10 * t_dev
+
+
+def test_results_lent_from_pinned_buffers_stay_valid_and_come_back():
+    """The densities are handed over in the pinned buffer they left the device through (no second host copy).  A result that
+    is still held must not be touched by later calls -- more results than the pool lends out are copied as before -- and a
+    released result returns its buffer to the pool."""
+    import gc
+
+    import torch
+
+    meld = _meld()
+    from meld_amd import filter as mf
+
+    rng = np.random.default_rng(12)
+    held = []
+    for i in range(mf._PinnedPool.MAX_OUT + 2):
+        X = rng.normal(size=(9000, 6))
+        labels = rng.integers(0, 2, 9000)
+        out = meld.MELD(knn=7, verbose=0).fit_transform(X, labels)
+        held.append((out, out.values.copy()))
+    for out, snap in held:
+        np.testing.assert_array_equal(out.values, snap)
+    key = ((9000, 2), torch.float64)
+    assert mf._POOL.out.get(key, 0) == mf._PinnedPool.MAX_OUT
+    del held, out
+    gc.collect()
+    assert mf._POOL.out.get(key, 0) == 0 and len(mf._POOL.free.get(key, [])) == mf._PinnedPool.MAX_OUT
