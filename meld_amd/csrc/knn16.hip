@@ -246,6 +246,20 @@ __device__ void knn16_rank_row(int n0, int n1, int half, int ksel, float out_sca
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Scan order of a query block: step s -> tile.  Own tiles first (t0 .. t0 + 3), then outwards on both sides of the own
+// position (two_sided): in the locality order both the next and the previous leaves are spatial neighbours, so the
+// thresholds tighten sooner than on a forward-only walk.  Offsets -B .. F-1 with F + B = n_scan: every tile once.
+// (Shared by the search kernel and by meld_knn16_step_lists, which must agree on it.)
+__device__ __forceinline__ int k16_scan_tile(int s, int t0, int n_scan, int two_sided) {
+  int off = s;
+  if (two_sided && s >= K16_BQ / K16_TS) {
+    const int j = s - K16_BQ / K16_TS;
+    off = (j & 1) ? -1 - (j >> 1) : K16_BQ / K16_TS + (j >> 1);
+  }
+  const int t = t0 + off;
+  return t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
+}
+
 // Kernel arguments of knn16_topk_kernel, one struct passed by value: its layout IS the kernel-argument
 // segment, which lets cold code re-read a field where it is needed instead of holding it in an SGPR for
 // the whole scan.
@@ -269,6 +283,10 @@ struct K16Args {
   float* cand_thr;
   unsigned long long* tiles_done;
   const int* block_order;
+  // LIST kernels: the steps of every query block, precomputed (meld_knn16_step_lists): entry = tile | live waves << 24
+  const unsigned* step_list;
+  const int* step_cnt;
+  long long list_stride;
 };
 #define K16_COLD(FIELD) \
   (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
@@ -283,9 +301,11 @@ __host__ __device__ constexpr int k16_waves(int KB, int ABL, int NPROD) {
   return (NPROD == 1 && KB <= 4 && ABL != 6) ? 3 : ((KB <= 5 || (NPROD == 1 && KB <= 8)) ? 2 : 1);
 }
 
-template <int KB, int ABL, int NPROD>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
+template <int KB, int ABL, int NPROD, bool LIST = false>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
                                       // only), 6 = product at two waves per SIMD where three are the default;
                                       // NPROD: split products (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
+                                      // LIST: the steps of a query block (tile + the waves that need it) come from a precomputed list
+                                      // (meld_knn16_step_lists) instead of the pruning table: no per-step masks, ballots or window logic
 __global__ __launch_bounds__(K16_THREADS)
 __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(const K16Args a) {
   // Arguments the scan loop needs stay in SGPRs; the cold ones (K16_COLD: compaction parameters, the outputs
@@ -296,7 +316,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const float* __restrict__ Qn = a.Qn;
   const _Float16* __restrict__ Rt16 = a.Rt16;
   const int n_tiles = a.n_tiles, ksel = a.ksel, cap = a.cap;
-  const __half* __restrict__ lb2 = a.lb2;
+  const __half* __restrict__ lb2 = LIST ? nullptr : a.lb2;
   const int batch_every = a.batch_every, two_sided = a.two_sided;
   int* __restrict__ cand_idx = a.cand_idx;
   float* __restrict__ cand_d2 = a.cand_d2;
@@ -336,8 +356,20 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // locality order the tiles a query block cannot rule out sit in a few runs, and contiguous slices would leave most of a
   // heavy block's work in one of them) and writes its own candidate rows; meld_knn16_merge_slices combines them.  Used to
   // spread few query blocks (the re-search, a row shard, a mid-sized data set) over the whole chip.
-  const int sl_n = (int)gridDim.x, sl_y = (int)blockIdx.x;
-  const int n_scan = (n_tiles - sl_y + sl_n - 1) / sl_n;
+  int sl_n_ = (int)gridDim.x;
+#ifndef K16_NO_SLN_PIN
+  // (opaque to the rematerialiser: otherwise gridDim.x is re-read from the dispatch packet -- a scalar load and its
+  // s_waitcnt lgkmcnt(0) -- in tile_of() of every iteration)
+  asm volatile("" : "+s"(sl_n_));
+#endif
+  const int sl_n = sl_n_, sl_y = (int)blockIdx.x;
+  // LIST: the block's steps = the entries of its list (tile | waves that cannot rule the tile out << 24), in scan order;
+  // read with scalar loads (constant address space), two steps ahead of their use
+  typedef const __attribute__((address_space(4))) unsigned* k16_list_ptr;
+  const k16_list_ptr my_list = LIST ? (k16_list_ptr)(uintptr_t)(a.step_list + (size_t)bx * (size_t)a.list_stride) : (k16_list_ptr)0;
+  const int n_scan = LIST ? __builtin_amdgcn_readfirstlane(a.step_cnt[bx]) : (n_tiles - sl_y + sl_n - 1) / sl_n;
+  auto list_entry = [&](int s_) __attribute__((always_inline)) { return s_ < n_scan ? my_list[s_] : 0u; };
+  auto entry_live = [&](unsigned e) __attribute__((always_inline)) { return ((e >> (24 + wave)) & 1u) != 0u; };
   const int row_base = (int)(blockIdx.x * (gridDim.y * K16_BQ)) + q_base;  // first candidate row of this wave
   float* const wave_d2 = cand_d2 + (size_t)row_base * cap;                // (wave-uniform: SGPR pairs)
   int* const wave_idx = cand_idx + (size_t)row_base * cap;
@@ -374,6 +406,17 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     wmax = w;
   }
   unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
+  // ... and where a wave's cycles go (s_memtime stamps at points where the LDS / scalar counter is drained anyway): MFMA segments
+  // of a live step, slow path, control tail up to the tile wait, the tile wait, the tile barrier; steps sat out
+  unsigned tm_seg = 0, tm_sel = 0, tm_tail = 0, tm_dma = 0, tm_bar = 0, tm_idle = 0, tm_mark = 0;
+  auto tm_now = [&]() __attribute__((always_inline)) { return ABL == 2 ? (unsigned)__builtin_readcyclecounter() : 0u; };
+  auto tm_lap = [&](unsigned& acc) __attribute__((always_inline)) {
+    if (ABL == 2) {
+      const unsigned n = tm_now();
+      acc += n - tm_mark;
+      tm_mark = n;
+    }
+  };
 
   // Tiles are visited starting at the workgroup's own position (its spatial neighbourhood when
   // the cells are in locality order) and wrapping around: step s -> tile (t0 + s) mod n_tiles.
@@ -388,19 +431,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // the first find them in L2 -- was tried: the base loop gained 7 %, but the thresholds converge later and
   // the net was +3 %; its progress counter was also a returning atomic in the loop, whose pending result made
   // the compiler guard the first ds_read of every iteration with s_waitcnt vmcnt(0).  Removed.)
-  auto tile_of = [&](int s) {
-    // own tiles first, then outwards on both sides of the own position (two_sided): in the locality
-    // order both the next and the previous leaves are spatial neighbours, so the thresholds tighten
-    // sooner than on a forward-only walk.  offsets -B .. F-1 with F + B = n_scan: every tile once.
-    int off = s;
-    if (two_sided && s >= K16_BQ / K16_TS) {
-      const int j = s - K16_BQ / K16_TS;
-      off = (j & 1) ? -1 - (j >> 1) : K16_BQ / K16_TS + (j >> 1);
-    }
-    int t = t0 + off;
-    t = t >= n_scan ? t - n_scan : (t < 0 ? t + n_scan : t);
-    return t * sl_n + sl_y;
-  };
+  // (LIST kernels never call it: their steps are list entries)
+  auto tile_of = [&](int s) { return k16_scan_tile(s, t0, n_scan, two_sided) * sl_n + sl_y; };
   // Pruning window (64 steps): lane i holds THIS WAVE's bound for step win_base + i (lb2 has one row per wave:
   // the wave's 64 queries against every tile).  my_live = steps of the window whose tile may still hold a
   // candidate for the wave (its bound <= the wave's largest threshold + the search-error allowance); the waves
@@ -493,7 +525,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 #define K16_STAGED_BUT_LAST() __builtin_amdgcn_s_waitcnt(0x0F70 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14))
   // tile barrier that leaves the vector-memory counter alone (LDS traffic of this wave done, then s_barrier)
 #define K16_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  K16_LOAD(__builtin_amdgcn_readfirstlane(tile_of(0)), 0u);
+  K16_LOAD(__builtin_amdgcn_readfirstlane(LIST ? (int)(list_entry(0) & 0xFFFFFFu) : tile_of(0)), 0u);
 
   // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
   // their loads past the first barrier and then has to guard their first use inside the loop with
@@ -589,6 +621,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   };
   auto refresh_wmax = [&]() __attribute__((always_inline)) {
     if (my_lb == nullptr) return;  // only the pruning test reads it
+#ifdef K16_NO_WMAX_REFRESH
+    return;  // (experiment: the live sets stay what the start thresholds make them)
+#endif
     float w = fmaxf(thrp[0] + wave_qn[jq], thrp[1] + wave_qn[32 + jq]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
@@ -691,13 +726,28 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     }
     float m0, m1;
     vote(c0, c1, m0, m1);
+#ifndef K16_NO_VOTE_PIN
+    // The minima are needed only when the block is `fresh`, and where that is not a constant (the first segment of a step)
+    // the compiler sinks the whole vote behind the branch on it -- out of the basic block of the MFMAs, i.e. the 8 MFMAs
+    // issue back to back and the ~20 VALU instructions of the vote afterwards, instead of two per MFMA slot.  An asm use
+    // pins them to this block.
+    if (issue) asm volatile("" : "+v"(m0), "+v"(m1));
+#endif
     const bool hit = m0 < thrp[0] || m1 < thrp[1];
     if (issue) pipeline_order();
     if (ABL == 1) {  // profiling ablation: distances + minimum, selection removed
       asm volatile("" ::"v"(m0), "v"(m1));
       return;
     }
-    if (fresh && __any(hit)) select(c0, c1, m0, m1, ref_base);
+    if (fresh && __any(hit)) {
+      unsigned t0s = tm_now();
+      select(c0, c1, m0, m1, ref_base);
+      if (ABL == 2) {
+        const unsigned d = tm_now() - t0s;
+        tm_sel += d;
+        tm_mark += d;  // (not counted as segment time)
+      }
+    }
   };
 
   // Which step follows `after`: the first one of the pruning window that some wave of the workgroup still
@@ -742,10 +792,20 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   int n_done = 0;         // tiles this wave has taken part in
   bool live_cur = true;   // does this wave take part in the current tile
   bool pend = false;      // accB holds a block that has not been voted on yet
+  unsigned e_pref = 0u;   // LIST: the entry of the step after s_next
   int t_cur = tile_of(0);
   bool live_next = true;
   int s_next = next_step(0, 0, &live_next);
   int t_next = s_next < n_scan ? tile_of(s_next) : t_cur;
+  if constexpr (LIST) {
+    const unsigned e0 = list_entry(0), e1 = list_entry(1);
+    e_pref = list_entry(2);
+    t_cur = (int)(e0 & 0xFFFFFFu);
+    live_cur = entry_live(e0);
+    s_next = 1;
+    t_next = s_next < n_scan ? (int)(e1 & 0xFFFFFFu) : t_cur;
+    live_next = entry_live(e1);
+  }
   // tiles of steps 0 and s_next requested; the first one has to be there
   if (s_next < n_scan && ABL != 9) {
     K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), (unsigned)TILE_LDS_BYTES);
@@ -759,11 +819,30 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   auto scan_step = [&]() __attribute__((always_inline)) {
     const int t = t_cur;
     const _Float16* tile_r = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(lds_ring) + rd_b);
+    const bool tm_live = live_cur;
+    unsigned e_far = 0u;  // LIST: the entry two steps past s_next, requested a whole iteration before it is needed
+    if constexpr (LIST) e_far = list_entry(s_next + 2);
+#ifdef K16_LIST_LOAD_TOP
+    // LIST: the step after next is known here, so its tile is requested before the MFMA segments (the buffer it goes to was
+    // read by the previous iteration and every wave has passed the barrier behind that)
+    int s_nn_top = 0, t_nn_top = 0;
+    if constexpr (LIST) {
+      s_nn_top = min(s_next + 1, n_scan);
+      t_nn_top = s_nn_top < n_scan ? (int)(e_pref & 0xFFFFFFu) : t_next;
+      if (s_nn_top < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane(t_nn_top), wr_b);
+    }
+#endif
     if (live_cur) {
+#ifdef K16_SETPRIO
+      __builtin_amdgcn_s_setprio(K16_SETPRIO);
+#endif
       // sub-tile 0 on the pipe while sub-tile 1 of the previous tile is voted on
       segment(tile_r, 0, accA0, accA1, accB0, accB1, refB, true, pend);
       // sub-tile 1 on the pipe while sub-tile 0 is voted on
       segment(tile_r, 1, accB0, accB1, accA0, accA1, t * K16_TS + 4 * h, true, true);
+#ifdef K16_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       refB = t * K16_TS + 32 + 4 * h;
       pend = true;
       ++n_done;
@@ -773,6 +852,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       pend = false;
     }
 
+    if (tm_live) tm_lap(tm_seg); else tm_lap(tm_idle);
     if (batch_every > 0 && (it & (batch_every - 1)) == batch_every - 1) {
       // (Placed here, in front of the staging store whose vmcnt(0) wait follows anyway: a cold region with
       // memory operations in front of a pipeline segment makes the compiler wait for ALL outstanding loads at
@@ -803,24 +883,40 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 
     // the step after s_next (masks published before the last barrier; the window may move on here)
     bool live_nn = true;
-    const int s_nn = s_next < n_scan ? next_step(s_next, par, &live_nn) : n_scan;
-    const int t_nn = s_nn < n_scan ? tile_of(s_nn) : t_next;
+    int s_nn, t_nn;
+    if constexpr (LIST) {
+      s_nn = min(s_next + 1, n_scan);
+      t_nn = s_nn < n_scan ? (int)(e_pref & 0xFFFFFFu) : t_next;
+      live_nn = entry_live(e_pref);
+      e_pref = e_far;
+    } else {
+      s_nn = s_next < n_scan ? next_step(s_next, par, &live_nn) : n_scan;
+      t_nn = s_nn < n_scan ? tile_of(s_nn) : t_next;
+    }
 
     // request the tile of the step after next (into the buffer the previous iteration read: every wave has passed
     // the barrier behind it), then wait for the tile of the next step, requested one iteration ago
     if (ABL != 9) {  // (8 / 9 = timing-only ablations: tiles from a 64-tile hot set / no tile loads)
       if (s_nn < n_scan) {
+#ifdef K16_LIST_LOAD_TOP
+        if constexpr (!LIST)
+#endif
         K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_nn & 63) : t_nn), wr_b);
+        tm_lap(tm_tail);
         K16_STAGED_BUT_LAST();
       } else {
+        tm_lap(tm_tail);
         K16_STAGED();
       }
+      tm_lap(tm_dma);
     }
     if (my_lb) {
       my_live = __ballot(win_lb <= wmax + prune_margin);
       if (lane == 0) lds_wlive[par ^ 1][wave] = my_live;
     }
+    tm_lap(tm_tail);
     if (ABL != 10 && (ABL != 4 || (s_cur & 1))) K16_TILE_BARRIER();  // (4 / 10 = timing-only ablations: MFMAs only, a barrier every other tile / none)
+    tm_lap(tm_bar);
     s_cur = s_next;
     t_cur = t_next;
     live_cur = live_next;
@@ -834,6 +930,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     nx_b = wr_b;
     wr_b = free_b;
   };
+  tm_mark = tm_now();
   while (s_cur < n_scan) scan_step();
   if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false, true);  // drain: sub-tile 1 of the last tile
   {
@@ -852,6 +949,13 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       atomicAdd(stats + 2, (unsigned long long)a);
       atomicAdd(stats + 3, (unsigned long long)st_sq);
       if (wave == 0) atomicAdd(stats + 4, (unsigned long long)it);
+      atomicAdd(stats + 5, (unsigned long long)tm_seg);
+      atomicAdd(stats + 6, (unsigned long long)tm_sel);
+      atomicAdd(stats + 7, (unsigned long long)tm_tail);
+      atomicAdd(stats + 8, (unsigned long long)tm_dma);
+      atomicAdd(stats + 9, (unsigned long long)tm_bar);
+      atomicAdd(stats + 10, (unsigned long long)tm_idle);
+      atomicAdd(stats + 11, (unsigned long long)it);
     }
   }
   // final: sort every row, convert back to input units, publish its length and its threshold (the row
@@ -1868,15 +1972,17 @@ static int k16_bounds_impl(const double* X, int64_t N, int d, const double* mean
       K16_BOUNDS_LAUNCH(KBV, false, (KBV <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2));                            \
     break;
   switch (KB) {
+    K16_BOUNDS_CASE(4)
+#ifndef K16_DEV_KB4
     K16_BOUNDS_CASE(1)
     K16_BOUNDS_CASE(2)
     K16_BOUNDS_CASE(3)
-    K16_BOUNDS_CASE(4)
     K16_BOUNDS_CASE(5)
     K16_BOUNDS_CASE(6)
     K16_BOUNDS_CASE(7)
     K16_BOUNDS_CASE(8)
     K16_BOUNDS_CASE(9)
+#endif
     default:
       set_err("meld_knn16_bounds: no kernel for %d K blocks", KB);
       return MELD_ERR_UNSUPPORTED;
@@ -1943,6 +2049,74 @@ extern "C" int meld_knn16_block_work(const void* lb2, const float* thr_seed, int
                      reinterpret_cast<const __half*>(lb2), thr_seed, n_tiles, (float)meld_knn16_error_coef(nprod, d), norm2_max,
                      scale_info, work);
   MELD_LAUNCH_CHECK("knn16_block_work_kernel");
+  return MELD_OK;
+}
+
+// Step lists of the first pass.  With the seeds the search starts at thresholds that are final for half the rows, and what
+// the waves learn during the scan removes only 1.5 % of the (wave, tile) blocks the START thresholds leave (measured at 1M
+// cells: 69.3 M wave-blocks with the per-step test against the current thresholds, 70.3 M with the start thresholds alone)
+// -- while testing, publishing and merging the per-wave masks every step is half of what a wave does between two tiles.
+// So the steps of a query block are fixed before the search: one workgroup per block walks the scan order, keeps the tiles
+// some wave of the block cannot rule out at its start thresholds (table entry <= the wave's largest seed + the search-error
+// allowance, as in knn16_block_work_kernel) and writes  tile | (waves that need it) << 24  in scan order; cnt[b] = the
+// block's steps (>= 1: step 0 is always listed).  The search kernel (LIST instantiation) just walks the list.
+__global__ __launch_bounds__(256) void knn16_step_list_kernel(const __half* __restrict__ lb2, const float* __restrict__ thr_seed,
+                                                              int n_tiles, float err_coef, const float* __restrict__ norm2_max,
+                                                              const float* __restrict__ scale_info, int tile_origin, int two_sided,
+                                                              unsigned* __restrict__ list, long long stride, int* __restrict__ cnt) {
+  __shared__ float wm[K16_NWAVE];
+  __shared__ int wtot[2][K16_NWAVE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x;
+  float sd = thr_seed ? thr_seed[(size_t)bx * K16_BQ + tid] : INFINITY;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sd = fmaxf(sd, __shfl_xor(sd, off, 64));
+  if (lane == 0) wm[wave] = sd + err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+  __syncthreads();
+  const float w0 = wm[0], w1 = wm[1], w2 = wm[2], w3 = wm[3];
+  const __half* row = lb2 + (size_t)bx * K16_NWAVE * n_tiles;
+  unsigned* out = list + (size_t)bx * (size_t)stride;
+  const int t0 = (int)(((long long)tile_origin + (long long)bx * (K16_BQ / K16_TS)) % n_tiles);
+  int base = 0, par = 0;
+  for (int s0 = 0; s0 < n_tiles; s0 += 256, par ^= 1) {
+    const int sidx = s0 + tid;
+    unsigned mask = 0u;
+    int t = 0;
+    if (sidx < n_tiles) {
+      t = k16_scan_tile(sidx, t0, n_tiles, two_sided);
+      mask = (__half2float(row[t]) <= w0 ? 1u : 0u) | (__half2float(row[(size_t)n_tiles + t]) <= w1 ? 2u : 0u) |
+             (__half2float(row[(size_t)2 * n_tiles + t]) <= w2 ? 4u : 0u) | (__half2float(row[(size_t)3 * n_tiles + t]) <= w3 ? 8u : 0u);
+    }
+    const bool keep = mask != 0u || sidx == 0;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wtot[par][wave] = __popcll(bal);
+    __syncthreads();  // (the two parities alternate: the next round's writes cannot overtake this round's reads)
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wtot[par][w];
+    if (keep) out[before + __popcll(bal & (((unsigned long long)1 << lane) - 1ull))] = (unsigned)t | (mask << 24);
+    base += wtot[par][0] + wtot[par][1] + wtot[par][2] + wtot[par][3];
+  }
+  if (tid == 0) cnt[bx] = base;
+}
+
+static int k16_two_sided() {  // scan order: own tiles, then alternately forwards / backwards (0 = forwards only; profiling hook)
+  const char* e = getenv("MELD_KNN16_TWO_SIDED");
+  return e ? (atoi(e) != 0) : 1;
+}
+
+extern "C" int meld_knn16_step_lists(const void* lb2, const float* thr_seed, int64_t n_ref, int d, int64_t q_count, int nprod,
+                                     const float* norm2_max, const float* scale_info, int64_t q_begin, uint32_t* list,
+                                     int64_t list_stride, int32_t* cnt, meld_stream_t stream) {
+  MELD_CHECK_ARG(lb2 && norm2_max && scale_info && list && cnt && n_ref > 0 && q_count > 0 && (nprod == 1 || nprod == 3) && q_begin >= 0,
+                 "meld_knn16_step_lists: bad arguments");
+  static_assert(K16_NWAVE == 4 && K16_BQ == 256, "knn16_step_list_kernel is written for 4 waves of 64 queries");
+  const int n_tiles = (int)ceil_div(n_ref, K16_TS);
+  MELD_CHECK_ARG(n_tiles < (1 << 24) && list_stride >= n_tiles, "meld_knn16_step_lists: list_stride must hold the %d tiles of a block", n_tiles);
+  const int tile_origin = (int)((q_begin / K16_TS) % n_tiles);
+  hipLaunchKernelGGL(knn16_step_list_kernel, dim3((unsigned)ceil_div(q_count, K16_BQ)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const __half*>(lb2), thr_seed, n_tiles, (float)meld_knn16_error_coef(nprod, d), norm2_max, scale_info,
+                     tile_origin, k16_two_sided(), list, (long long)list_stride, cnt);
+  MELD_LAUNCH_CHECK("knn16_step_list_kernel");
   return MELD_OK;
 }
 
@@ -2037,15 +2211,17 @@ extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn,
       K16_SEEDM_LAUNCH(KBV, 64);     \
     break;
   switch (KB) {
+    K16_SEEDM_CASE(4)
+#ifndef K16_DEV_KB4
     K16_SEEDM_CASE(1)
     K16_SEEDM_CASE(2)
     K16_SEEDM_CASE(3)
-    K16_SEEDM_CASE(4)
     K16_SEEDM_CASE(5)
     K16_SEEDM_CASE(6)
     K16_SEEDM_CASE(7)
     K16_SEEDM_CASE(8)
     K16_SEEDM_CASE(9)
+#endif
     default:
       set_err("meld_knn16_seed_thresholds_mfma: no kernel for %d K blocks", KB);
       return MELD_ERR_UNSUPPORTED;
@@ -2056,13 +2232,16 @@ extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn,
   return MELD_OK;
 }
 
-extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
-                               int64_t n_ref, int d,
-                               int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
-                               const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
-                               double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
-                               float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
+static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
+                         int64_t n_ref, int d,
+                         int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
+                         const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                         double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                         float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, const uint32_t* step_list,
+                         const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
+  MELD_CHECK_ARG(step_list == nullptr || (step_cnt != nullptr && nprod == 1 && n_slices == 1 && lb2 == nullptr && thr_init != nullptr),
+                 "meld_knn16_topk_listed: step lists go with the hi-only pass, one slice, start thresholds and no table");
   // (reference slices combine with pruning, the radius cut and a dispatch order: a slice's table row is the wave's row, its
   // rows are cut at the radius ITS references imply -- looser than the global one, still valid -- and cand_thr then holds
   // n_slices x q_pad thresholds of which the caller takes the minimum per query)
@@ -2103,8 +2282,7 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     MELD_CHECK_ARG(batch_every >= 0 && (batch_every & (batch_every - 1)) == 0, "MELD_KNN16_BATCH_EVERY must be a power of two");
   }
   if (const char* e = getenv("MELD_KNN16_BATCH_SLACK")) batch_slack = std::max(0, atoi(e));
-  int two_sided = 1;  // scan order: own tiles, then alternately forwards / backwards (0 = forwards only)
-  if (const char* e = getenv("MELD_KNN16_TWO_SIDED")) two_sided = atoi(e) != 0;
+  const int two_sided = k16_two_sided();
   if (getenv("MELD_KNN16_STATS")) {  // profiling hook: selection counters, printed after the launch
     static unsigned long long* counters[64] = {nullptr};  // (a racing first call leaks 256 B at worst)
     int dev = 0;
@@ -2142,15 +2320,46 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
   ka.cand_thr = cand_thr;
   ka.tiles_done = reinterpret_cast<unsigned long long*>(tiles_done);
   ka.block_order = block_order;
+  ka.step_list = step_list;
+  ka.step_cnt = step_cnt;
+  ka.list_stride = (long long)list_stride;
+#ifndef K16_PROFILING
+  MELD_CHECK_ARG(abl == 0, "MELD_KNN16_ABLATION needs a library built with -DK16_PROFILING");
+#endif
+#ifdef K16_PROFILING  // the timing-only ablations of the list-driven kernel (8: tiles from a 64-tile hot set, 9: no tile loads, 1: no selection)
+#define K16_DEV_LIST_ABL(KBV)                                                                                       \
+  if (abl == 9) hipLaunchKernelGGL((knn16_topk_kernel<KBV, 9, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+  else if (abl == 8) hipLaunchKernelGGL((knn16_topk_kernel<KBV, 8, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+  else if (abl == 1) hipLaunchKernelGGL((knn16_topk_kernel<KBV, 1, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+  else
+#else
+#define K16_DEV_LIST_ABL(KBV)
+#endif
 #define K16_LAUNCH2(KBV, ABLV, NP) \
   hipLaunchKernelGGL((knn16_topk_kernel<KBV, ABLV, NP>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka)
 #define K16_LAUNCH(KBV, ABLV)        \
   do {                               \
-    if (nprod == 1)                  \
+    if (step_list != nullptr) {      \
+      K16_DEV_LIST_ABL(KBV)          \
+      if (stats != nullptr)          \
+        hipLaunchKernelGGL((knn16_topk_kernel<KBV, 2, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+      else                           \
+        hipLaunchKernelGGL((knn16_topk_kernel<KBV, 0, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+    } else if (nprod == 1)           \
       K16_LAUNCH2(KBV, ABLV, 1);     \
     else                             \
       K16_LAUNCH2(KBV, ABLV, 3);     \
   } while (0)
+#ifndef K16_PROFILING  // product builds: the search and its counters (MELD_KNN16_STATS); the timing-only ablations of tools/knn_ablate.py are
+                       // compiled with -DK16_PROFILING (tools/build_variant.sh prof knn16.hip -DK16_PROFILING [-DK16_DEV_KB4 = d <= 61 only])
+#define K16_CASE(KBV)                  \
+  case KBV:                            \
+    if (stats != nullptr)              \
+      K16_LAUNCH(KBV, 2);              \
+    else                               \
+      K16_LAUNCH(KBV, 0);              \
+    break;
+#else
 #define K16_CASE(KBV)                  \
   case KBV:                            \
     if (abl == 1)                      \
@@ -2176,16 +2385,19 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     else                               \
       K16_LAUNCH(KBV, 0);              \
     break;
+#endif
   switch (KB) {
+    K16_CASE(4)
+#ifndef K16_DEV_KB4
     K16_CASE(1)
     K16_CASE(2)
     K16_CASE(3)
-    K16_CASE(4)
     K16_CASE(5)
     K16_CASE(6)
     K16_CASE(7)
     K16_CASE(8)
     K16_CASE(9)
+#endif
     default:
       set_err("meld_knn16_topk: KB=%d is not an instantiated size", KB);
       return MELD_ERR_UNSUPPORTED;
@@ -2202,14 +2414,45 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
     MELD_LAUNCH_CHECK("knn16_finish_rows_kernel");
   }
   if (stats) {
-    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     MELD_HIP_CALL(hipStreamSynchronize(S(stream)));
     MELD_HIP_CALL(hipMemcpy(st, stats, sizeof(st), hipMemcpyDeviceToHost));
     fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu  tiles staged %llu (%.1f %% of workgroups x tiles)\n",
             st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3], st[4],
             100.0 * (double)st[4] / ((double)grid.y * (double)n_tiles));
+    {
+      const double tot = (double)(st[5] + st[6] + st[7] + st[8] + st[9] + st[10]);
+      fprintf(stderr, "[knn16 stats] wave cycles (s_memtime units, summed over waves; %% of the scan loop): MFMA segments of live steps %.1f  slow path %.1f  "
+                      "control tail %.1f  tile wait %.1f  barrier %.1f  steps sat out %.1f   -- per wave and staged tile: %.0f units; live wave-steps %.1f %%\n",
+              100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot,
+              tot / (double)st[11], st[11] ? 50.0 * (double)st[0] / (double)st[11] : 0.0);
+    }
   }
   return MELD_OK;
+}
+
+extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
+                               int64_t n_ref, int d,
+                               int64_t q_count, int ksel, int nprod, int n_slices, const void* lb2,
+                               const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                               double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
+                               float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
+  return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, nprod, n_slices, lb2, norm2_max, q_begin, thr_init, knn,
+                       radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, nullptr, nullptr, 0, stream);
+}
+
+// The hi-only first pass over precomputed step lists (meld_knn16_step_lists) instead of the pruning table: same rows,
+// counts and thresholds as meld_knn16_topk(nprod = 1, n_slices = 1, lb2, thr_init) up to the 1.5 % of blocks the per-step
+// test against the CURRENT thresholds would have skipped (they hold no candidate: the lists are a superset).
+extern "C" int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
+                                      int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
+                                      int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                                      double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
+                                      uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
+  MELD_CHECK_ARG(step_list && step_cnt && list_stride > 0, "meld_knn16_topk_listed: null step lists");
+  return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, 1, nullptr, norm2_max, q_begin, thr_init, knn,
+                       radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, step_list, step_cnt, list_stride,
+                       stream);
 }
 
 // Workgroups of the search kernel that are resident on the device at once (occupancy x CUs): the
@@ -2229,15 +2472,17 @@ extern "C" int meld_knn16_resident_blocks(int d, int nprod) {
     }                                                                                                             \
     break;
   switch (KB) {
+    K16_OCC(4)
+#ifndef K16_DEV_KB4
     K16_OCC(1)
     K16_OCC(2)
     K16_OCC(3)
-    K16_OCC(4)
     K16_OCC(5)
     K16_OCC(6)
     K16_OCC(7)
     K16_OCC(8)
     K16_OCC(9)
+#endif
     default:
       return MELD_ERR_UNSUPPORTED;
   }

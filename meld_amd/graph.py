@@ -402,6 +402,8 @@ class HipOps:
         self.seeded_bounds = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
         # pruned search: query blocks dispatched by decreasing work (meld_knn16_block_work)
         self.block_order = os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0"
+        # the first pass walks precomputed step lists (meld_knn16_step_lists) instead of testing the pruning table step by step
+        self.step_lists = os.environ.get("MELD_KNN_STEP_LISTS", "1") != "0"
         # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
         # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
         # waves and the sliced launch costs more than the idle tail, so it is off
@@ -441,7 +443,7 @@ class HipOps:
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
-        used_prune = used_seed = used_seeded_bounds = used_block_order = False
+        used_prune = used_seed = used_seeded_bounds = used_block_order = used_step_lists = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if cross and search != "f16x3":
@@ -523,7 +525,7 @@ class HipOps:
                 # publishes each row's final threshold for refine's completeness test
                 cand_thr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
-            lb2 = block_order = None
+            lb2 = block_order = step_list = step_cnt = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
             # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
@@ -577,10 +579,23 @@ class HipOps:
                 lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 seeded_bounds = seeds is not None and self.seeded_bounds
                 check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
-                if self.block_order and q_main == q_count and n_blocks > 1:
+                # (few query blocks -- a row shard, a mid-sized data set -- are searched in reference slices, which the lists do not do)
+                resident_all = lib.meld_knn16_resident_blocks(d, nprod)
+                if self.step_lists and seeds is not None and q_main == q_count and cand_thr is not None and nprod == 1 \
+                        and not os.environ.get("MELD_KNN_MAIN_SLICES") and not (resident_all > 0 and n_blocks < 2 * resident_all):
+                    # the tiles a block can rule out at its start thresholds, written down once (the count is the block's work)
+                    step_list = torch.empty(n_blocks * n_tiles, dtype=torch.int32, device=dev)
+                    step_cnt = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+                    check(lib.meld_knn16_step_lists(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), 0 if cross else q_begin,
+                                                    ptr(step_list), n_tiles, ptr(step_cnt), st), "meld_knn16_step_lists")
+                    work = step_cnt
+                elif self.block_order and q_main == q_count and n_blocks > 1:
                     # longest query blocks first (the dispatch follows the block index): see meld_knn16_block_work
                     work = torch.empty(n_blocks, dtype=torch.int32, device=dev)
                     check(lib.meld_knn16_block_work(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), ptr(work), st), "meld_knn16_block_work")
+                else:
+                    work = None
+                if self.block_order and work is not None and n_blocks > 1:
                     block_order = torch.argsort(work, descending=True, stable=True).to(torch.int32)
                 tm.stop("bounds")
             # Few query blocks (a row shard, a mid-sized data set): with pruning the work of a block varies 12-fold and a
@@ -588,7 +603,7 @@ class HipOps:
             # 7-10 ms instead of 26 / 8).  The references are then cut into slices -- blocks x slices workgroups, each
             # with its own candidate rows, merged afterwards -- so that the heavy blocks are shared out.
             main_slices = 1
-            if will_prune and q_main == q_count and cand_thr is not None:
+            if will_prune and q_main == q_count and cand_thr is not None and step_list is None:
                 resident = lib.meld_knn16_resident_blocks(d, nprod)
                 if os.environ.get("MELD_KNN_MAIN_SLICES"):
                     main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
@@ -604,6 +619,8 @@ class HipOps:
                     check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_main, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
+                elif step_list is not None:
+                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk_listed")
                 else:
                     check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
@@ -624,7 +641,8 @@ class HipOps:
             used_prune, used_seed = lb2 is not None, seeds is not None
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             used_block_order = block_order is not None
-            del lb2
+            used_step_lists = step_list is not None
+            del lb2, step_list, step_cnt
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
         else:
@@ -835,7 +853,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), split_tail=bool(self.split_tail),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), split_tail=bool(self.split_tail),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)

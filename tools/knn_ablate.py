@@ -39,11 +39,23 @@ if os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0":
     check(lib.meld_knn16_block_work(ptr(lb2), ptr(mseed), N, d, N, 1, ptr(nmax), ptr(sinfo), ptr(work), st))
     ORDER = torch.argsort(work, descending=True, stable=True).to(torch.int32)
 
+LISTS = None
+if os.environ.get("MELD_KNN_STEP_LISTS", "1") != "0":  # the list-driven first pass (meld_knn16_step_lists / _topk_listed), as in the product
+    sl = torch.empty((q_pad // BQ) * n_tiles, dtype=torch.int32, device="cuda"); sc = torch.empty(q_pad // BQ, dtype=torch.int32, device="cuda")
+    check(lib.meld_knn16_step_lists(ptr(lb2), ptr(mseed), N, d, N, 1, ptr(nmax), ptr(sinfo), 0, ptr(sl), n_tiles, ptr(sc), st))
+    LISTS = (sl, sc)
+    if ORDER is not None:
+        ORDER = torch.argsort(sc, descending=True, stable=True).to(torch.int32)
+
 def run(seed, label):
     done.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, ptr(seed) if seed is not None else None,
+    if LISTS is not None:
+        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, ptr(LISTS[0]), ptr(LISTS[1]), n_tiles, ptr(nmax), 0, ptr(seed),
+                                         knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), ptr(ORDER) if ORDER is not None else None, st))
+    else:
+      check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, ptr(seed) if seed is not None else None,
                               knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), ptr(ORDER) if ORDER is not None else None, st))
     e1.record(); torch.cuda.synchronize()
     print("%-44s %.2f ms   blocks computed %.3f" % (label, e0.elapsed_time(e1), float(done) / ((q_pad // 64) * n_tiles)))
@@ -55,7 +67,8 @@ if abl is None:
     torch.save(seed.cpu(), "/tmp/knn_seed.pt")
     run(seed, "product, thresholds seeded with the final ones")
     print("seed / final threshold: median %.2f, p90 %.2f" % (float((mseed[:N] / seed[:N]).median()), float(torch.quantile((mseed[:N] / seed[:N])[:200000], 0.9))))
-    for a, name in (("5", "appends without their stores"), ("7", "no final ranking"), ("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("4", "MFMAs only, a barrier every other tile"), ("10", "MFMAs only, no barrier"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
+    abls = (("1", "no selection (MFMA + vote + control + staging)"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")) if LISTS is not None else None
+    for a, name in abls or (("5", "appends without their stores"), ("7", "no final ranking"), ("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("4", "MFMAs only, a barrier every other tile"), ("10", "MFMAs only, no barrier"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
         subprocess.run([sys.executable, __file__, str(n)], env=env)
 else:
