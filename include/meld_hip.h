@@ -440,6 +440,15 @@ int meld_pt_build(const int64_t* rowptr, const int32_t* col, const double* val, 
 int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
                        const double* x_full, int64_t x_row_offset, const double* z, double* y, double* r,
                        double alpha, double beta, double gamma, double coef, double* dots, meld_stream_t stream);
+/* Steps 2 .. n_coef - 1 of the Chebyshev recurrence in one call (single GPU, no collective between the steps):
+ *   T_k = alpha2 L T_{k-1} + beta2 T_{k-1} - T_{k-2},   r += coeffs[k] T_k      [UPSTREAM pygsp cheby_op, /root/reference/meld/filter.py:59]
+ * t_prev2 / t_prev1: [n_rows, p] buffers holding T_0 / T_1 on entry, used as ping-pong buffers; r: holds c_0/2 T_0 + c_1 T_1 on
+ * entry, the filtered signal on return; coeffs: n_coef doubles on the HOST.  The accumulator is read and written every other step
+ * only (a step adds c_k T_k + c_{k-1} T_{k-1} at once), which removes 16 of the 80 vector bytes per row and step at p = 2.
+ * *last (optional) = 1 if t_prev1 holds the last T, 0 if t_prev2 does. */
+int meld_pt_cheby_run(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
+                      double* t_prev2, double* t_prev1, double* r, const double* coeffs, int n_coef, double alpha2, double beta2,
+                      int* last, meld_stream_t stream);
 /* meld_lanczos_steps / meld_lanczos_spmv on the layout (same contracts). */
 int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                           double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,

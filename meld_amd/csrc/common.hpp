@@ -57,6 +57,6 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // one recurrence step on the panel-tiled layout (spmm_tiled.hip); coef_dev: device-resident Lanczos scalars
 int pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double* dw, int p, const double* x_full,
             int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
-            double coef, double* dots, const double* coef_dev, hipStream_t st);
+            double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x = 0.0);
 
 }  // namespace meld

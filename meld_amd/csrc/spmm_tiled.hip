@@ -93,6 +93,7 @@ struct StepArgs {
   const double* coef_dev;
   int64_t x_row_offset;
   double alpha, beta, gamma, coef;
+  double coef_x;  // r += coef * y + coef_x * x (own rows): lets a recurrence touch r every other step (meld_pt_cheby_run)
   int nb;
   int ld, colofs;
   unsigned long long* stamps;  // development: [nb][16][8] wall-clock stamps of every wave (meld_pt_debug_stamps), or NULL
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void 
   if (b >= a.nb) return;  // padding workgroup (whole workgroup leaves: no barrier is left hanging)
 
   double alpha = a.alpha, gamma = a.gamma;
-  const double beta = a.beta, coef = a.coef;
+  const double beta = a.beta, coef = a.coef, coef_x = a.coef_x;
   if (a.coef_dev != nullptr) {  // device-resident Lanczos: scalars written by the previous iteration
     alpha = a.coef_dev[3];
     gamma = a.coef_dev[4];
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void 
       for (int c = 0; c < P; ++c) {
         const double lx = dwi[q] * xl[q].v[c] - ap.v[c];  // (L x)_i
         yv.v[c] = alpha * lx + beta * xl[q].v[c] + gamma * zl[q].v[c];
-        rl_[q].v[c] += coef * yv.v[c];
+        rl_[q].v[c] += coef * yv.v[c] + coef_x * xl[q].v[c];
         d_yx += yv.v[c] * xl[q].v[c];
         d_yy += yv.v[c] * yv.v[c];
       }
@@ -1374,13 +1375,13 @@ static int pt_step_cols(pt::StepArgs a, int p, hipStream_t st, bool f32) {
 // internal entry (also used by the Lanczos drivers in spmm.hip)
 int meld::pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double* dw, int p, const double* x_full,
                   int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
-                  double coef, double* dots, const double* coef_dev, hipStream_t st) {
+                  double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x) {
   if (L->nb == 0) return MELD_OK;
   pt::StepArgs a;
   a.blk_row = L->blk_row; a.blk_ntile = L->blk_ntile; a.blk_ndist = L->blk_ndist; a.seg = L->seg;
   a.list_cols = L->list_cols; a.pval = L->pval; a.pidx = L->pidx; a.cdesc = L->cdesc; a.rowptr = rowptr; a.dw = dw; a.x_full = x_full;
   a.z = z; a.y = y; a.r = r; a.dots = dots; a.coef_dev = coef_dev; a.x_row_offset = x_row_offset; a.alpha = alpha;
-  a.beta = beta; a.gamma = gamma; a.coef = coef; a.nb = L->nb; a.ld = p; a.colofs = 0;
+  a.beta = beta; a.gamma = gamma; a.coef = coef; a.coef_x = coef_x; a.nb = L->nb; a.ld = p; a.colofs = 0;
   a.ablate = g_pt_ablate;
   a.stamps = g_pt_stamps;
   a.pval32 = L->pval32;
@@ -1401,6 +1402,49 @@ extern "C" int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t*
   if (n_rows == 0) return MELD_OK;
   const int rc = pt_step(layout, rowptr, dw, p, x_full, x_row_offset, z, y, r, alpha, beta, gamma, coef, dots, nullptr, st);
   if (rc != MELD_OK) return rc;
+  MELD_LAUNCH_CHECK("pt_step_kernel");
+  return MELD_OK;
+}
+
+// Steps k = 2 .. n_coef - 1 of the Chebyshev recurrence in one call (single GPU: x_row_offset = 0, no collective between
+// the steps):  T_k = alpha2 L T_{k-1} + beta2 T_{k-1} - T_{k-2},  r += c_k T_k  [UPSTREAM pygsp cheby_op, reference
+// meld/filter.py:59].  t_prev2 / t_prev1 hold T_0 / T_1 on entry and are used as the two ping-pong buffers (T_k
+// overwrites T_{k-2}); r already holds c_0 / 2 T_0 + c_1 T_1.  The accumulator is touched every OTHER step only: a step
+// that holds T_k in its result and T_{k-1} in its own rows of the iterate adds c_k T_k + c_{k-1} T_{k-1} at once, the
+// step before it neither reads nor writes r -- 32 of the 80 bytes of vector traffic per row and step pair at p = 2.
+// coeffs: n_coef doubles on the HOST.  *last = 0 / 1: the buffer (t_prev2 / t_prev1) that holds T of the last order.
+extern "C" int meld_pt_cheby_run(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
+                                 double* t_prev2, double* t_prev1, double* r, const double* coeffs, int n_coef, double alpha2,
+                                 double beta2, int* last, meld_stream_t stream) {
+  MELD_CHECK_ARG(layout && layout->blk_row && layout->blk_ntile && layout->blk_ndist && layout->seg && layout->list_cols &&
+                     layout->pval && layout->pidx && rowptr && dw && t_prev2 && t_prev1 && r && coeffs && n_rows >= 0 && p >= 1 &&
+                     n_coef >= 2,
+                 "meld_pt_cheby_run: bad arguments");
+  hipStream_t st = S(stream);
+  double* t_old = t_prev2;
+  double* t_cur = t_prev1;
+  int which = 1;  // t_cur is t_prev1
+  if (n_rows > 0) {
+    int k = 2;
+    if ((n_coef - 2) % 2 == 1) {  // an odd number of steps: the first one alone
+      const int rc = pt_step(layout, rowptr, dw, p, t_cur, 0, t_old, t_old, r, alpha2, beta2, -1.0, coeffs[k], nullptr, nullptr, st, 0.0);
+      if (rc != MELD_OK) return rc;
+      std::swap(t_old, t_cur);
+      which ^= 1;
+      ++k;
+    }
+    for (; k + 1 < n_coef; k += 2) {
+      // T_k: no accumulator traffic
+      int rc = pt_step(layout, rowptr, dw, p, t_cur, 0, t_old, t_old, nullptr, alpha2, beta2, -1.0, 0.0, nullptr, nullptr, st, 0.0);
+      if (rc != MELD_OK) return rc;
+      std::swap(t_old, t_cur);
+      // T_{k+1}, and r += c_{k+1} T_{k+1} + c_k T_k (T_k = this step's own rows of the iterate)
+      rc = pt_step(layout, rowptr, dw, p, t_cur, 0, t_old, t_old, r, alpha2, beta2, -1.0, coeffs[k + 1], nullptr, nullptr, st, coeffs[k]);
+      if (rc != MELD_OK) return rc;
+      std::swap(t_old, t_cur);
+    }
+  }
+  if (last) *last = which;
   MELD_LAUNCH_CHECK("pt_step_kernel");
   return MELD_OK;
 }

@@ -178,6 +178,9 @@ def chebyshev_apply(G, signal, coeffs, lmax):
     if comm is not None:
         comm.all_gather_rows(t_cur, _local(G, t_cur))
     with _EventSpan("cheby_steps", steps=int(c.shape[0] - 2), N=G.N, p=p, nnz=G.nnz):
+        if comm is None and c.shape[0] > 2 and hasattr(ops, "cheby_run") and os.environ.get("MELD_CHEBY_RUN", "1") != "0" \
+                and ops.cheby_run(G, p, t_old, t_cur, r, c, 2.0 / a1, -2.0 * a2 / a1):
+            return r  # (one call for all the steps; r is read and written every other step only)
         for k in range(2, c.shape[0]):
             # T_k overwrites the local rows of T_{k-2} (z and y alias; read-before-write per element)
             loc = _local(G, t_old)

@@ -1081,6 +1081,22 @@ class HipOps:
             "meld_cheby_step",
         )
 
+    def cheby_run(self, G, p, t_prev2, t_prev1, r, coeffs, alpha2, beta2):
+        """Steps 2 .. len(coeffs) - 1 of the Chebyshev recurrence in one call (``meld_pt_cheby_run``: single GPU, tiled layout;
+        the accumulator is touched every other step).  Returns False when the graph has no tiled layout (the caller steps)."""
+        pt = self.pt_layout(G)
+        if pt is None or getattr(G, "comm", None) is not None or G.row_begin != 0:
+            return False
+        import ctypes as C
+
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        check(
+            self.lib.meld_pt_cheby_run(C.byref(pt["struct"]), ptr(G.rowptr), ptr(G.dw_dev), G.n_rows, p, ptr(t_prev2), ptr(t_prev1), ptr(r),
+                                       c.ctypes.data_as(C.c_void_p), int(c.shape[0]), float(alpha2), float(beta2), None, _stream()),
+            "meld_pt_cheby_run",
+        )
+        return True
+
     def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch):
         """Iterations [it_begin, it_begin + n_iter) of the device-resident Lanczos recurrence
         (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors."""

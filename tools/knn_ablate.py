@@ -71,6 +71,8 @@ if abl is None:
     for a, name in abls or (("5", "appends without their stores"), ("7", "no final ranking"), ("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("4", "MFMAs only, a barrier every other tile"), ("10", "MFMAs only, no barrier"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
         subprocess.run([sys.executable, __file__, str(n)], env=env)
+elif abl == "99":
+    pass  # (set-up only: tools/sim_wg_schedule.py, tools/list_stats.py import this module for it)
 else:
     seed = torch.load("/tmp/knn_seed.pt").cuda()
     run(seed, "ablation %s" % abl); run(seed, "ablation %s" % abl)
