@@ -29,7 +29,7 @@ import torch.distributed as dist
 
 from .graph import DeviceGraph, resolve_graph_params
 
-__all__ = ["Comm", "shard_range", "build_sharded_graph", "fit_transform_sharded"]
+__all__ = ["Comm", "shard_range", "build_sharded_graph", "shard_of_graph", "fit_transform_sharded"]
 
 
 class Comm:
@@ -197,6 +197,43 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
     return G
 
 
+def shard_of_graph(Gf, ops, comm):
+    """This rank's row shard of a graph EVERY rank holds in full (built redundantly or adopted): the recurrences -- lmax,
+    Chebyshev, the filter-bank VertexFrequencyCluster -- then run row-sharded exactly as on a graph from
+    ``build_sharded_graph``.  For the graph kinds the sharded builder does not build itself (the MNN graph of ``sample_idx``,
+    a graph built elsewhere): the build is replicated, the filter is sharded."""
+    N = int(Gf.N)
+    R, r0, n_loc = shard_range(N, comm.world, comm.rank)
+    dev = Gf.val.device
+    if n_loc > 0:
+        e0, e1 = int(Gf.rowptr[r0]), int(Gf.rowptr[r0 + n_loc])
+        rowptr = (Gf.rowptr[r0 : r0 + n_loc + 1] - e0).contiguous()
+        col, val = Gf.col[e0:e1].contiguous(), Gf.val[e0:e1].contiguous()
+        dw = Gf.dw_dev[r0 : r0 + n_loc].contiguous()
+    else:  # (a rank beyond the last row: it still takes part in every collective)
+        rowptr = torch.zeros(2, dtype=torch.int64, device=dev)
+        col = torch.empty(0, dtype=torch.int32, device=dev)
+        val = torch.empty(0, dtype=torch.float64, device=dev)
+        dw = torch.zeros(1, dtype=torch.float64, device=dev)
+    ksum_all = torch.ones(R * comm.world, dtype=torch.float64, device=dev)
+    if Gf.ksum is not None:
+        ksum_all[:N] = Gf.ksum[:N]
+    info = dict(Gf.info)
+    info.update(nnz=int(col.shape[0]), nnz_global=int(Gf.nnz), rows_per_rank=R, row_begin=r0, rows_local=n_loc, world=comm.world,
+                build="replicated on every rank, rows sharded for the recurrences")
+    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum_all, anisotropy=Gf.anisotropy, row_begin=r0, n_total=N, info=info)
+    G.n_rows = n_loc
+    G.rows_pad = R
+    G.n_pad = R * comm.world
+    G.comm = comm
+    G.ops = ops
+    G.bandwidth = getattr(Gf, "bandwidth", None)
+    G.perm = Gf.perm
+    if getattr(Gf, "_lmax", None) is not None:
+        G.lmax = Gf._lmax
+    return G
+
+
 def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     """``op.fit_transform(X, sample_labels)`` with the cells row-sharded over the process group.
     ``op`` is a ``meld_amd.MELD``; every rank passes the same ``X`` / labels and receives the same
@@ -210,11 +247,12 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     if not isinstance(X, torch.Tensor):
         X = torch.from_numpy(np.ascontiguousarray(np.asarray(getattr(X, "values", X)), dtype=np.float64))
     X = X.to(device=ops.device, dtype=torch.float64).contiguous()
-    if op.thresh == 0 or op.decay is None:  # (n_landmark: accepted, the filter never uses the landmark operator)
-        raise NotImplementedError("the sharded builder supports the sparse alpha-decay kNN graph only")
-    unsupported = sorted(k for k in op.kwargs if k not in ("ksel",))
-    if unsupported:  # e.g. sample_idx (MNN graph): single-GPU only
+    if op.thresh == 0:  # (n_landmark: accepted, the filter never uses the landmark operator)
+        raise NotImplementedError("the sharded driver supports sparse graphs only (thresh > 0)")
+    unsupported = sorted(k for k in op.kwargs if k not in ("ksel", "sample_idx"))
+    if unsupported:
         raise NotImplementedError("graph options {} are not implemented by the row-sharded builder".format(unsupported))
+    decay = float("inf") if op.decay is None else op.decay  # None: graphtools' unweighted kNN graph = a 0 / 1 kernel
     # the same front end as the single-GPU path (MELD._build_graph): reject NaN / infinity, and build the
     # graph on the PCA scores when n_pca < min(X.shape) (graphtools' Data._reduce_data; the reference's
     # default n_pca=100 triggers it on wide data).  Every rank holds all of X and computes the same
@@ -234,9 +272,18 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     # (the label factorisation of transform starts under this rank's candidate search, as on one GPU)
     finish = op._prefactor_under_search(sample_labels, eligible=X.is_cuda) if hasattr(op, "_prefactor_under_search") else (lambda: None)
     try:
-        op.graph = build_sharded_graph(
-            X, ops, comm, knn=op.knn, decay=op.decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
-        )
+        if op.kwargs.get("sample_idx") is not None:
+            # MNN graph (reference test/test_meld.py:31-40 forwards sample_idx to graphtools): its blocks between samples do not
+            # follow the row shards, so every rank builds it whole -- the single-GPU builder -- and keeps its rows
+            from .mnn import build_mnn_graph
+
+            full = build_mnn_graph(X, op.kwargs["sample_idx"], knn=op.knn, decay=decay, thresh=op.thresh, anisotropy=op.anisotropy,
+                                   ksel=op.kwargs.get("ksel"))
+            op.graph = shard_of_graph(full, ops, comm)
+        else:
+            op.graph = build_sharded_graph(
+                X, ops, comm, knn=op.knn, decay=decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
+            )
     finally:
         finish()
     try:

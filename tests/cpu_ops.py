@@ -22,7 +22,8 @@ class CpuOps:
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False):
         Xn = X.numpy()
         if self._Kd is None:  # every rank can afford the whole directed kernel at test sizes
-            self._Kd, self._info = mo.knn_kernel(Xn, knn=knn, decay=decay, thresh=thresh, algorithm="brute", return_intermediates=True)
+            self._Kd, self._info = mo.knn_kernel(Xn, knn=knn, decay=None if np.isinf(decay) else decay, thresh=thresh, algorithm="brute",
+                                                 return_intermediates=True)  # (decay = inf: graphtools' unweighted kNN graph, decay=None)
         K = self._Kd[q_begin : q_begin + q_count].tocoo()
         rows = K.row.astype(np.int64) + q_begin
         cols = K.col.astype(np.int64)

@@ -21,8 +21,27 @@ def main(out_path, n, d, knn, n_labels, n_pca=0):
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     if n_labels == 3:
         labels = np.random.default_rng(1).choice(["A", "B", "C"], size=n)
-    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None)
-    dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
+    mode = os.environ.get("MELD_TEST_MODE", "")
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None, decay=None if mode == "unweighted" else 40)
+    if mode == "replicated":
+        # a graph every rank holds in full (here: the oracle's, uploaded like a graph built elsewhere), rows sharded for the
+        # recurrences only (meld_amd.distributed.shard_of_graph)
+        from meld_amd.graph import DeviceGraph
+
+        Go = mo.build_graph(X, knn=knn, algorithm="brute")
+        W = Go.W.tocsr()
+        W.sort_indices()
+        full = DeviceGraph(torch.from_numpy(W.indptr.astype(np.int64)), torch.from_numpy(W.indices.astype(np.int32)),
+                           torch.from_numpy(W.data.astype(np.float64)), torch.from_numpy(np.asarray(Go.dw, dtype=np.float64)), anisotropy=1.0)
+        comm = mdist.Comm()
+        op.graph = mdist.shard_of_graph(full, CpuOps(), comm)
+        op.X = torch.from_numpy(X)
+        dens = op.transform(labels)
+        G = op.graph
+        G.info.setdefault("exchange", "none")
+        G.info.setdefault("exchange_overflow", 0)
+    else:
+        dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
     G = op.graph
     # the same estimate with two all-reduces per iteration (the unfolded phases): every collective again, on every rank
     os.environ["MELD_LANCZOS_FOLD"] = "0"

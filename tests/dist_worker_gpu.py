@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out_path, n, d, knn):
+def main(out_path, n, d, knn, mode=""):
     dist.init_process_group("gloo")
     import meld_amd
     from meld_amd import distributed as mdist
@@ -50,9 +50,25 @@ def main(out_path, n, d, knn):
 
     torch.cuda.set_device(0)
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
-    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
+    kw = {}
+    if mode == "mnn":  # sample_idx: the MNN graph, built whole on every rank, rows sharded for the recurrences
+        kw["sample_idx"] = np.random.default_rng(3).choice(["s0", "s1"], size=n)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0, decay=None if mode == "unweighted" else 40, **kw)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X).cuda(), labels, comm=StagedComm())
     G = op.graph
+    extra = {}
+    if mode == "vfc":
+        # BASELINE configs[4] on the sharded driver with the HIP kernels on every rank: the filter-bank
+        # VertexFrequencyCluster fitted on this rank's shard (iterate all-gathered per SpMM, Gram matrices all-reduced)
+        vfc = meld_amd.VertexFrequencyCluster(method="filterbank", n_probes=24, n_bands=6, window_sizes=np.array([1, 2, 4, 8]),
+                                              chebyshev_order=48, random_state=3, n_clusters=3)
+        vfc.fit(G)
+        extra = dict(spec=vfc._fb_spectrogram.cpu().numpy(), ritz=vfc._fb["ritz"].cpu().numpy(), norm2=vfc._fb["window_norm2"].cpu().numpy())
+    if mode in ("mnn", "unweighted", "vfc"):
+        np.savez(out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, lmax=G.lmax, row_begin=G.row_begin, n_rows=G.n_rows,
+                 nnz_global=G.info["nnz_global"], **extra)
+        dist.destroy_process_group()
+        return
     # the ordering whose assignment passes were split over the ranks is the ordering one GPU computes alone
     from meld_amd.reorder import locality_permutation
 
@@ -66,4 +82,4 @@ def main(out_path, n, d, knn):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "")

@@ -99,6 +99,27 @@ def test_exchange_overflow_falls_back_to_the_variable_length_exchange(tmp_path):
         assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("mode", ["unweighted", "replicated"])
+def test_sharded_breadth_unweighted_graph_and_replicated_build(mode, tmp_path):
+    """(a) decay=None (graphtools' unweighted kNN graph, forwarded at reference meld/meld.py:106,118) on the row-sharded
+    builder; (b) a graph every rank holds in full -- the route of the MNN graph (sample_idx) and of graphs built elsewhere --
+    sharded for the recurrences only (shard_of_graph).  3 ranks, ragged tail; graph and densities against the oracle."""
+    n, d, knn, world = 700, 8, 7, 3
+    ranks = _run(world, tmp_path, n, d, knn, 2, extra_env=dict(MELD_TEST_MODE=mode))
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    G = mo.build_graph(X, knn=knn, algorithm="brute", decay=None if mode == "unweighted" else 40)
+    W = sparse.vstack([
+        sparse.csr_matrix((r["val"], r["col"], r["rowptr"][: int(r["n_rows"]) + 1]), shape=(int(r["n_rows"]), n)) for r in ranks
+    ]).tocsr()
+    assert W.nnz == G.W.nnz == int(ranks[0]["nnz_global"]) and abs(W - G.W).max() < 1e-13
+    samples, ind = mo.sample_indicators(labels)
+    ref = mo.meld_filter(ind, G, beta=40, chebyshev_order=25, lmax=float(ranks[0]["lmax"]))
+    for r in ranks:
+        assert float(r["lmax"]) == float(ranks[0]["lmax"])
+        assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < 1e-11
+        np.testing.assert_array_equal(r["dens"], ranks[0]["dens"])
+
+
 def test_shard_range_covers_everything():
     from meld_amd.distributed import shard_range
 

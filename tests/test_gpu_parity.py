@@ -442,6 +442,50 @@ def test_two_ranks_on_one_gpu(tmp_path, world):
         assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
 
 
+@pytest.mark.parametrize("mode", ["vfc", "mnn", "unweighted"])
+def test_two_ranks_on_one_gpu_vfc_and_graph_options(tmp_path, mode):
+    """The sharded driver beyond the plain kNN graph, with the real HIP kernels on both ranks of a 2-rank group (collectives
+    staged through host memory, tests/dist_worker_gpu.py): the filter-bank VertexFrequencyCluster (BASELINE configs[4]),
+    sample_idx (MNN graph: built whole on every rank, rows sharded for the recurrences) and decay=None (unweighted kNN
+    graph) -- every rank must return what one GPU computes alone."""
+    import socket
+    import subprocess
+
+    import meld_amd
+
+    mo = _oracle()
+    n, d, knn, world = 20011, 16, 9, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn), mode]
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    kw = dict(sample_idx=np.random.default_rng(3).choice(["s0", "s1"], size=n)) if mode == "mnn" else {}
+    single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0, decay=None if mode == "unweighted" else 40, **kw)
+    ref = single.fit_transform(X, labels)
+    assert int(ranks[0]["nnz_global"]) == single.graph.nnz
+    for r in ranks:
+        assert abs(float(r["lmax"]) - single.graph.lmax) <= 1e-9 * single.graph.lmax
+        assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
+    if mode == "vfc":
+        vfc = meld_amd.VertexFrequencyCluster(method="filterbank", n_probes=24, n_bands=6, window_sizes=np.array([1, 2, 4, 8]),
+                                              chebyshev_order=48, random_state=3, n_clusters=3)
+        vfc.fit(single.graph)
+        spec = vfc._fb_spectrogram.cpu().numpy()
+        assert spec.shape == (n, 24 + 6) and np.isfinite(spec).all()
+        for r in ranks:
+            np.testing.assert_array_equal(r["spec"], ranks[0]["spec"])  # every rank ends with the whole spectrogram
+            assert np.abs(r["ritz"] - vfc._fb["ritz"].cpu().numpy()).max() < 1e-7 * single.graph.lmax
+            assert np.abs(r["spec"] - spec).max() < 1e-6
+
+
 def test_locality_reordering_does_not_change_results():
     """The permutation is a memory-layout decision only: identical graph and densities (to
     rounding: summation order inside a row changes) with and without it."""
