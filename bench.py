@@ -102,6 +102,10 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
             "note": "EXTRAPOLATED from the three runs above with t ~ N^{:.2f}; not measured".format(expo),
         },
         "host_cores_available": os.cpu_count(),
+        "measured_full_size": measured_full_size(n_target),
+        "speedup_basis": "a quoted GPU / CPU ratio at the benchmark size uses `measured_full_size` (all host cores, brute force: the "
+        "fastest CPU configuration measured) when present; `extrapolated` (1 core, ball tree: the reference stack's defaults) is a "
+        "fit over three small samples with the exponent printed beside it and is never the basis of a headline ratio",
         "recorded_full_protocol": recorded_full_protocol(),
         "best_effort": {
             "value": n_big / t_best,
@@ -109,6 +113,18 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
             "note": "same {}-cell sample with sklearn brute-force kNN on all host cores (n_jobs=-1); {:.1f} s".format(n_big, t_best),
         },
     }
+
+
+def measured_full_size(n_cells):
+    """The one MEASURED CPU number at the benchmark size: the whole oracle (brute-force kNN on all host cores) run by the round's
+    evidence script (tools/parity_200k.py under tools/_profile_round.sh, 160 s at 1M cells -- too long for a default bench run),
+    recorded with its commit in profiles/r04_cpu_full_size.json."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_cpu_full_size.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(str(int(n_cells)))
+    except Exception:
+        return None
 
 
 def recorded_full_protocol():
@@ -426,6 +442,8 @@ def main():
                 "algorithmic": "{} B per SpMM (12*nnz + 4(N+1) + 8N + 40*N*p, p = {}: the matrix bytes counted once)".format(byts, R),
                 "ms_per_spmm": 1e3 * t_sp, "spmms": len(ev2["vfc_spmm"]), "traffic": None,
             }
+    out["value_definition"] = ("X resident in HBM when the timed region starts (the bench contract: inputs resident, the PCIe-inclusive "
+                               "rate is reported beside it as `value_host_input` and is SURVEY 8d's host-visible figure)")
     if host_ms:
         # SURVEY 8d's metric counts the H2D copy of X: this is the figure to compare with it (`value` starts X-resident)
         out["value_host_input"] = N / (1e-3 * float(np.median(host_ms)))

@@ -61,7 +61,17 @@ class Benchmarker(object):
         from .meld import MELD
 
         kwargs.pop("use_pygsp", None)
-        builder = MELD(n_pca=n_pca, random_state=self.seed, anisotropy=kwargs.pop("anisotropy", 0), **kwargs)
+        # graphtools accepts more graph keywords than the device builder implements: those are rejected here, by name,
+        # instead of being stored and silently ignored (the graph would differ from the reference's for the same call)
+        known = {"knn", "decay", "thresh", "ksel", "sample_idx", "n_landmark", "verbose", "distance"}
+        unknown = sorted(k for k in kwargs if k not in known | {"anisotropy"})
+        if unknown:
+            raise NotImplementedError("graph options {} are not implemented by the MI355X graph builder".format(unknown))
+        seed = self.seed
+        if seed is not None and not isinstance(seed, (int, np.integer)):
+            # (graphtools also takes a RandomState; the device PCA is seeded by an integer)
+            raise TypeError("Benchmarker.seed must be an integer or None to seed the graph's PCA, got {!r}".format(type(seed).__name__))
+        builder = MELD(n_pca=n_pca, random_state=seed, anisotropy=kwargs.pop("anisotropy", 0), **kwargs)
         self.graph = builder.fit(data).graph
         return self.graph
 

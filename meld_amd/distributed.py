@@ -270,7 +270,7 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
         op.data_nu = X
     op.X = X
     # (the label factorisation of transform starts under this rank's candidate search, as on one GPU)
-    finish = op._prefactor_under_search(sample_labels, eligible=X.is_cuda) if hasattr(op, "_prefactor_under_search") else (lambda: None)
+    finish = op._prefactor_under_search(sample_labels, eligible=X.is_cuda) if hasattr(op, "_prefactor_under_search") else (lambda publish=True: None)
     try:
         if op.kwargs.get("sample_idx") is not None:
             # MNN graph (reference test/test_meld.py:31-40 forwards sample_idx to graphtools): its blocks between samples do not
@@ -284,8 +284,11 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
             op.graph = build_sharded_graph(
                 X, ops, comm, knn=op.knn, decay=decay, thresh=op.thresh, anisotropy=op.anisotropy, ksel=op.kwargs.get("ksel")
             )
-    finally:
-        finish()
+    except BaseException:
+        finish(publish=False)
+        op._prefactored = None
+        raise
+    finish()
     try:
         return op.transform(sample_labels)
     finally:

@@ -76,10 +76,27 @@ class _PinnedPool:
     shared resource); beyond that the result is copied as before."""
 
     MAX_OUT = 4
+    MAX_FREE_BYTES = 256 << 20  # page-locked memory parked in the pool (not lent out) at most
 
     def __init__(self):
         self.free = {}  # key -> [tensor, ...]
         self.out = {}   # key -> number lent out
+        self.last_path = None  # "pinned" / "copy": which way the last result went (observable: tests, diagnostics)
+
+    def _free_bytes(self):
+        return sum(t.numel() * t.element_size() for lst in self.free.values() for t in lst)
+
+    def _evict(self, keep_key):
+        """Page-locked memory is not swappable: buffers of shapes other than the one in use are dropped first (a process that
+        runs differently sized inputs -- subsampling sweeps, parameter searches -- would otherwise keep MAX_OUT buffers of
+        every shape it ever saw), then surplus buffers of this shape, until the parked total is under MAX_FREE_BYTES."""
+        for key in [k for k in self.free if k != keep_key]:
+            if self._free_bytes() <= self.MAX_FREE_BYTES:
+                return
+            self.free.pop(key, None)
+        lst = self.free.get(keep_key, [])
+        while len(lst) > 1 and self._free_bytes() > self.MAX_FREE_BYTES:
+            lst.pop()
 
     def lend(self, r):
         """r: device tensor -> numpy array with its values (device synchronised), or None when the pool is exhausted."""
@@ -88,7 +105,11 @@ class _PinnedPool:
         key = (tuple(r.shape), r.dtype)
         free = self.free.setdefault(key, [])
         if not free and self.out.get(key, 0) >= self.MAX_OUT:
+            self.last_path = "copy"
             return None
+        if not free:
+            self._evict(key)  # (about to pin a new buffer: make room first)
+        self.last_path = "pinned"
         stage = free.pop() if free else torch.empty(r.shape, dtype=r.dtype, pin_memory=True)
         stage.copy_(r, non_blocking=True)
         torch.cuda.current_stream().synchronize()
@@ -98,6 +119,7 @@ class _PinnedPool:
         def back(pool=self, key=key, stage=stage):
             pool.out[key] = pool.out.get(key, 1) - 1
             pool.free.setdefault(key, []).append(stage)
+            pool._evict(key)
 
         weakref.finalize(arr, back)
         return arr

@@ -89,7 +89,43 @@ class _Timer:
             self._t0 = time.perf_counter()
 
 
-_WHILE_SEARCHING = []  # callables run once by the next directed_kernel_coo right after it has launched the candidate search
+class _HookList(list):
+    """Callables run once by the next directed_kernel_coo OF THIS THREAD right after it has launched the candidate search
+    (fit_transform's label factorisation).  Per thread: two builds running concurrently must not run each other's hooks."""
+
+
+class _PerThreadHooks:
+    def __init__(self):
+        import threading
+
+        self._tls = threading.local()
+
+    def _lst(self):
+        lst = getattr(self._tls, "hooks", None)
+        if lst is None:
+            lst = self._tls.hooks = _HookList()
+        return lst
+
+    def append(self, h):
+        self._lst().append(h)
+
+    def remove(self, h):
+        self._lst().remove(h)
+
+    def pop(self):
+        return self._lst().pop()
+
+    def __contains__(self, h):
+        return h in self._lst()
+
+    def __bool__(self):
+        return bool(self._lst())
+
+    def __len__(self):
+        return len(self._lst())
+
+
+_WHILE_SEARCHING = _PerThreadHooks()
 
 
 class DeviceGraph:
@@ -761,7 +797,10 @@ class HipOps:
         # ksel = 64, 0.63 s; none at ksel = 128, 32 ms).  Same graph either way.
         if (n_flag_h > max(1024, q_count // 100) and ksel < 128 and search == "f16x3" and not force_fallback
                 and os.environ.get("MELD_KNN_RETRY", "1") != "0"):
-            out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs)
+            # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
+            # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
+            out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
+                                           assemble=assemble)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out

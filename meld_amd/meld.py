@@ -250,8 +250,14 @@ class MELD(GraphEstimator):
         if h is None:
             return None
         h["done"].synchronize()
-        torch.cuda.current_stream().wait_event(h["done"])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(h["done"])
         lab, inv, cnt, first, device = h["lab"], h["inv"], h["cnt"], h["first"], h["device"]
+        for t in (inv, cnt, first, h["ok"]):
+            # allocated from the side stream's pool, consumed from here on by the current stream: without this the caching
+            # allocator may hand their blocks to the next side-stream hook while kernels of this stream still read them
+            if t.is_cuda:
+                t.record_stream(cur)
         if not bool(h["ok"].item()):
             return None  # two different labels share a key
         uniques = lab[first.cpu().numpy()]
@@ -396,10 +402,12 @@ class MELD(GraphEstimator):
         ``sample_labels`` (reference ``meld/meld.py:252-274``)."""
         finish = self._prefactor_under_search(sample_labels, eligible=not isinstance(X, str))
         try:
-            self.fit(X, **kwargs)
-        finally:
+            try:
+                self.fit(X, **kwargs)
+            except BaseException:
+                finish(publish=False)  # (the hook is withdrawn, its device work dropped: a failed fit leaves no factorisation behind)
+                raise
             finish()
-        try:
             return self.transform(sample_labels)
         finally:
             self._prefactored = None
@@ -435,12 +443,15 @@ class MELD(GraphEstimator):
         except Exception:
             hook = None
 
-        def finish():
+        def finish(publish=True):
             if hook is not None:
                 from . import graph as _graph
 
                 if hook in _graph._WHILE_SEARCHING:  # (no search was launched: small N, a precomputed graph, ...)
                     _graph._WHILE_SEARCHING.remove(hook)
+            if not publish:
+                pending.pop("h", None)
+                return
             if pending.get("h") is not None:
                 try:
                     fz = self._factorize_device_end(pending["h"])

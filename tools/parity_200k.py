@@ -11,7 +11,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 X, labels = mo.synthetic_cells(N, n_dims=50, seed=0)
 t0 = time.perf_counter()
 samples, dens, G = mo.fit_transform(X, labels, knn=15, beta=60, chebyshev_order=30, return_graph=True, algorithm="brute", n_jobs=-1)
-print("oracle: %.1f s" % (time.perf_counter() - t0))
+t_oracle = time.perf_counter() - t0
+print("oracle: %.1f s" % t_oracle)
 op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, lmax=G.lmax, verbose=0)
 out = op.fit_transform(X, labels)
 A, B = sparse.csr_matrix(op.graph.W), sparse.csr_matrix(G.W)
@@ -20,3 +21,16 @@ print("nnz equal:", A.nnz == B.nnz, " pattern equal:", np.array_equal(A.indices,
 print("max rel weight diff: %.3e" % (np.abs(A.data - B.data).max() / np.abs(B.data).max()))
 print("max rel density diff: %.3e" % (np.abs(out.values - dens).max() / np.abs(dens).max()))
 print("blocks computed: %.3f, rows re-searched %d, swept %d" % (op.graph.info["wave_tiles_done"] / ((N / 64) ** 2), op.graph.info["n_researched_rows"], op.graph.info["n_flagged_rows"]))
+if os.environ.get("MELD_CPU_FULL_JSON"):  # the MEASURED CPU number at this size for bench.py's cpu_baseline.measured_full_size
+    import json
+    path = os.environ["MELD_CPU_FULL_JSON"]
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        rec = {}
+    rec[str(N)] = {"cells": N, "seconds": t_oracle, "cells_per_s": N / t_oracle, "cores": os.cpu_count(), "kind": "port",
+                   "what": "whole oracle fit_transform (sklearn brute-force kNN on all host cores, n_jobs=-1, + scipy Chebyshev), measured at full size",
+                   "commit": os.environ.get("MELD_COMMIT", "unknown"),
+                   "pattern_equal": bool(A.nnz == B.nnz and np.array_equal(A.indices, B.indices) and np.array_equal(A.indptr, B.indptr)),
+                   "max_rel_density_diff": float(np.abs(out.values - dens).max() / np.abs(dens).max())}
+    json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
