@@ -31,6 +31,24 @@ json.dump(d, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 PY
 { stamp; bash tools/pmc_knn.sh gpurun_out/pmc_knn_$tag 1000000 2>&1 | grep -v "^pass"; } > $out/pmc/knn16_pmc_summary.txt
 { stamp; bash tools/pmc_spmm.sh gpurun_out/pmc_spmm_$tag 1000000 0 2>&1 | grep -v "^pass\|^saved"; } > $out/pmc/spmm_pmc_summary.txt
+# the search kernel's L2 counters ride in traffic.json too (hit / miss / fabric reads / L1->L2 read latency per launch)
+python - $out/pmc/knn16_pmc_summary.txt $out/pmc/traffic.json $commit <<'PY'
+import json, sys
+vals = {}
+for line in open(sys.argv[1]):
+    f = line.split()
+    if len(f) >= 4 and f[1] == "nprod1" and f[2] in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_VALU"):
+        vals[f[2]] = float(f[3])
+d = json.load(open(sys.argv[2]))
+if vals:
+    rec = dict(vals, commit=sys.argv[3], note="tools/pmc_knn.sh: per launch of the first-pass search kernel at 1M x 50")
+    if vals.get("TCC_HIT_sum") is not None and vals.get("TCC_MISS_sum"):
+        rec["tcc_hit_rate"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
+    if vals.get("TCP_TCC_READ_REQ_sum"):
+        rec["tcp_tcc_read_latency_cycles_mean"] = vals.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / vals["TCP_TCC_READ_REQ_sum"]
+    d["knn16_topk_l2@1000000x50"] = rec
+json.dump(d, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
 rm -rf gpurun_out/pmc_knn_$tag gpurun_out/pmc_spmm_$tag
 { stamp; python tools/save_graph.py 1000000 /tmp/g1m.pt > /dev/null; for p in 2 1; do echo "## p = $p"; python tools/spmm_stamps.py /tmp/g1m.pt $p 2>/dev/null; done; python tools/spmm_time.py /tmp/g1m.pt 2>/dev/null | grep "tiled p\|lanczos"; } > $out/recurrence_step_timeline.txt
 { stamp; for n in 1000000 500000; do echo "## N = $n"; MELD_COMMIT=$commit MELD_CPU_FULL_JSON=$out/cpu_full_size.json python tools/parity_200k.py $n 2>&1 | grep -v amdgpu.ids; done; } > $out/full_oracle_parity.txt

@@ -25,7 +25,7 @@ for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "knn16_topk" in k:
-            key = ("nprod1" if ("ELi1EE" in k or ", 1>" in k) else "nprod3", r["Counter_Name"])
+            key = ("nprod1" if any(t in k for t in ("ELi1EE", "ELi1ELb", ", 1>", ", 1, true>", ", 1, false>")) else "nprod3", r["Counter_Name"])
             acc[key] += float(r["Counter_Value"]); n[key] += 1
     for key in sorted(acc):
         print(f.split("/")[-3] if "/" in f else f, key[0], key[1], "%.6g" % (acc[key] / n[key]), "(per dispatch, %d dispatches)" % n[key])
