@@ -67,6 +67,19 @@ if abl is None:
     torch.save(seed.cpu(), "/tmp/knn_seed.pt")
     run(seed, "product, thresholds seeded with the final ones")
     print("seed / final threshold: median %.2f, p90 %.2f" % (float((mseed[:N] / seed[:N]).median()), float(torch.quantile((mseed[:N] / seed[:N])[:200000], 0.9))))
+    if LISTS is not None:
+        # what perfect seeds would be worth: table (per-query test) and lists rebuilt from the FINAL thresholds
+        check(lib.meld_knn16_bounds(ptr(Xd), N, d, ptr(mean), ptr(sinfo), ptr(nmax), ptr(Rt), 0, N, ptr(seed), ptr(Qn), 1, ptr(tmpb), ptr(lb2), st))
+        check(lib.meld_knn16_step_lists(ptr(lb2), ptr(seed), N, d, N, 1, ptr(nmax), ptr(sinfo), 0, ptr(LISTS[0]), n_tiles, ptr(LISTS[1]), st))
+        if ORDER is not None:
+            ORDER = torch.argsort(LISTS[1], descending=True, stable=True).to(torch.int32)
+        run(seed, "table + lists + thresholds from the final ones"); run(seed, "table + lists + thresholds from the final ones")
+        wm = seed[: (N // 64) * 64].view(-1, 64)
+        fm = (cthr[: (N // 64) * 64] * float(sinfo[0]) ** 2).view(-1, 64)
+        print("per wave: max seed / max final threshold: median %.2f p90 %.2f;  (product seeds) max seed / max final: median %.2f p90 %.2f" % (
+            float((wm.max(1).values / fm.max(1).values).median()), float(torch.quantile(wm.max(1).values / fm.max(1).values, 0.9)),
+            float((mseed[: (N // 64) * 64].view(-1, 64).max(1).values / fm.max(1).values).median()),
+            float(torch.quantile(mseed[: (N // 64) * 64].view(-1, 64).max(1).values / fm.max(1).values, 0.9))))
     abls = (("1", "no selection (MFMA + vote + control + staging)"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")) if LISTS is not None else None
     for a, name in abls or (("5", "appends without their stores"), ("7", "no final ranking"), ("1", "no selection (MFMA + vote + control + staging)"), ("3", "MFMAs only (no vote)"), ("4", "MFMAs only, a barrier every other tile"), ("10", "MFMAs only, no barrier"), ("8", "MFMAs only, tiles from an L2-hot set"), ("9", "MFMAs only, no tile loads")):
         env = dict(os.environ, MELD_KNN16_ABLATION=a)
