@@ -190,6 +190,14 @@ int meld_knn16_block_work(const void* lb2, const float* thr_seed, int64_t n_ref,
 int meld_knn16_step_lists(const void* lb2, const float* thr_seed, int64_t n_ref, int d, int64_t q_count, int nprod,
                           const float* norm2_max, const float* scale_info, int64_t q_begin, uint32_t* list,
                           int64_t list_stride, int32_t* cnt, meld_stream_t stream);
+/* The same lists straight from the cells when the queries are all the cells (one GPU): tile spheres, bounds, symmetrisation and list
+ * building in one call, with the bounds kept as two bits per (wave, tile) instead of the fp16 table (lb2 is never written).
+ * temp: meld_knn16_bounds_temp_bytes(n_ref, d, n_ref) bytes; scratch: meld_knn16_list_scratch_bytes(n_ref) bytes;
+ * thr_seed / q_norm2: the start thresholds and |q|^2 of the search (both required). */
+size_t meld_knn16_list_scratch_bytes(int64_t n_ref);
+int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, const double* mean, const float* scale_info, const float* norm2_max,
+                                 const void* Rt16, const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* scratch,
+                                 uint32_t* list, int64_t list_stride, int32_t* cnt, meld_stream_t stream);
 int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
                            int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt, int64_t list_stride,
                            const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,

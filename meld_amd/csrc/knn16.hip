@@ -1246,7 +1246,13 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
 // min_p [ acc_pt - s_p^2 - 2 s_p rho_t ] + |c_t|^2 - rho_t^2 > err (two VALU operations per distance on the
 // accumulators the first test needs anyway).  Such a tile gets +inf in the table -- the search kernel needs
 // no change -- and at 1M x 50 the blocks computed fall from 35 % to 25 % (tools/sim_prune_rules.py).
-template <int KB, bool SEEDED, int BT>  // BT threads = BT centroids per workgroup
+// BITS (with SEEDED, queries = all the cells): instead of the fp16 table the kernel writes what the step lists need of it, two bits per
+// (wave w, tile t):  A[w][t] = the bound is within reach of wave w's largest start threshold and the per-query test does not rule
+// the tile out;  B[w][t] = the bound is within reach of WAVE t's largest start threshold.  The symmetrised table entry of (w, t)
+// is max(bound(w, t), bound(t, w)), so (w, t) is listed iff A[w][t] and B[t][w]: a bit-matrix transpose and an AND
+// (knn16_bits_transpose_and_kernel) replace the table's 488 MB at 1M cells, the 64 x 64-entry symmetrisation pass over it and the
+// list builder's pass over it.  wthr[w] = largest seed of wave w + the search-error allowance (-inf: no cells).
+template <int KB, bool SEEDED, int BT, bool BITS = false>  // BT threads = BT centroids per workgroup
 __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
                                                                 const float* __restrict__ Cr,
                                                                 const _Float16* __restrict__ Rt16, int n_tiles,
@@ -1256,7 +1262,9 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
                                                                 const float* __restrict__ thr_seed, int64_t n_seed,
                                                                 float seed_err_coef, int mark_sign,
                                                                 const float* __restrict__ q_norm2, float err_c, float err_l,
-                                                                __half* __restrict__ lb2) {
+                                                                __half* __restrict__ lb2, const float* __restrict__ wthr = nullptr,
+                                                                unsigned long long* __restrict__ bits_a = nullptr,
+                                                                unsigned long long* __restrict__ bits_b = nullptr, int wpr = 0) {
   constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
   constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
   constexpr int NS = (HV + BT - 1) / BT;
@@ -1278,6 +1286,12 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
     cn[g] = Cn[c_base + g * 32 + jq];
     cr[g] = Cr[c_base + g * 32 + jq];
+  }
+  float wcol[2] = {-INFINITY, -INFINITY};  // BITS: start threshold (+ allowance) of the wave whose cells are this centroid's tile
+  if (BITS) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      if (c_base + g * 32 + jq < n_tiles) wcol[g] = wthr[c_base + g * 32 + jq];
   }
   f16x8 bx[2];  // centroid side of the extra K block: (-1, -2 rho_t, 0 ...) in the lower half-lanes
 #pragma unroll
@@ -1372,6 +1386,8 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     }
     if ((step % TPB) == TPB - 1) {
       const int b = b_lo + step / TPB;
+      const float wrow = BITS ? wthr[b] : 0.0f;
+      bool bit_a[2] = {false, false}, bit_b[2] = {false, false};
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const float v = fminf(m[g], __shfl_xor(m[g], 32, 64)) + cn[g];  // min_p |p - c|^2, approximate
@@ -1379,17 +1395,33 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
         const int c = c_base + g * 32 + jq;
         // (fp16, rounded towards zero: a smaller bound only prunes less)
         __half out = __float2half_rz(dist > 0.0f ? fminf(dist * dist, 60000.0f) : 0.0f);
+        const float outv = __half2float(out);  // (the value the table would hold: the tests below are the table-driven ones)
+        bool dead = false;
         if (SEEDED) {
           const float vb = fminf(mb[g], __shfl_xor(mb[g], 32, 64)) + cn[g] - cr[g] * cr[g];
           if (vb > 1.01f * err_abs + 1e-6f * (cn[g] + cr[g] * cr[g])) {  // dead for every query of the wave
             // (+inf; or, when the table is symmetrised afterwards, the bound with its sign bit set: the bound itself is
             // still wanted for the transposed entry)
             out = mark_sign ? __ushort_as_half((unsigned short)(__half_as_ushort(out) | 0x8000u)) : __ushort_as_half((unsigned short)0x7C00);
+            dead = true;
           }
           mb[g] = INFINITY;
         }
-        if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = out;
+        if (BITS) {
+          bit_a[g] = h == 0 && c < n_tiles && !dead && outv <= wrow;
+          bit_b[g] = h == 0 && c < n_tiles && outv <= wcol[g];
+        } else {
+          if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = out;
+        }
         m[g] = INFINITY;
+      }
+      if (BITS) {  // lanes 0 .. 31 hold the centroids c_base .. c_base + 31 (g = 0) and c_base + 32 .. c_base + 63 (g = 1)
+        const unsigned long long a0 = __ballot(bit_a[0]), a1 = __ballot(bit_a[1]);
+        const unsigned long long b0 = __ballot(bit_b[0]), b1 = __ballot(bit_b[1]);
+        if (lane == 0 && c_base < wpr * 64) {
+          bits_a[(size_t)b * wpr + (c_base >> 6)] = (a0 & 0xffffffffull) | (a1 << 32);
+          bits_b[(size_t)b * wpr + (c_base >> 6)] = (b0 & 0xffffffffull) | (b1 << 32);
+        }
       }
     }
     if (step + 1 < n_steps) store(buf ^ 1);
@@ -2099,6 +2131,74 @@ __global__ __launch_bounds__(256) void knn16_step_list_kernel(const __half* __re
   if (tid == 0) cnt[bx] = base;
 }
 
+// wthr[w] = largest start threshold of wave w (its 64 queries) + the search-error allowance, -inf for a wave without cells
+__global__ __launch_bounds__(256) void knn16_wave_thresholds_kernel(const float* __restrict__ thr_seed, int64_t n_seed, int n_rows,
+                                                                    float err_coef, const float* __restrict__ norm2_max,
+                                                                    const float* __restrict__ scale_info, float* __restrict__ wthr) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_rows) return;
+  const int64_t q = (int64_t)w * 64 + lane;
+  float sd = q < n_seed ? thr_seed[q] : -INFINITY;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sd = fmaxf(sd, __shfl_xor(sd, off, 64));
+  if (lane == 0) wthr[w] = sd + err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+}
+
+// live[w][.] = A[w][.] & transpose(B)[w][.]: one wave per 64 x 64 bit tile (lane l loads word R of row 64 C + l of B; bit j of
+// the 64 loaded words, gathered by a ballot, is the transposed word of row 64 R + j, columns 64 C ...)
+__global__ __launch_bounds__(256) void knn16_bits_transpose_and_kernel(const unsigned long long* __restrict__ bits_a,
+                                                                       const unsigned long long* __restrict__ bits_b, int n_rows, int wpr,
+                                                                       unsigned long long* __restrict__ live) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int R = tile / wpr, C = tile % wpr;  // output rows 64 R ..., output word C
+  if (R >= (n_rows + 63) / 64) return;
+  const int src_row = C * 64 + lane;
+  const unsigned long long x = (src_row < n_rows && R < wpr) ? bits_b[(size_t)src_row * wpr + R] : 0ull;
+  unsigned long long mine = 0ull;
+#pragma unroll 8
+  for (int j = 0; j < 64; ++j) {
+    const unsigned long long t = __ballot((x >> j) & 1ull);
+    if (lane == j) mine = t;
+  }
+  const int out_row = R * 64 + lane;
+  if (out_row < n_rows) live[(size_t)out_row * wpr + C] = mine & bits_a[(size_t)out_row * wpr + C];
+}
+
+// knn16_step_list_kernel on the bit form of the table (live[w][t]: wave w cannot rule tile t out)
+__global__ __launch_bounds__(256) void knn16_step_list_bits_kernel(const unsigned long long* __restrict__ live, int wpr, int n_tiles,
+                                                                   int tile_origin, int two_sided, unsigned* __restrict__ list,
+                                                                   long long stride, int* __restrict__ cnt) {
+  __shared__ int wtot[2][K16_NWAVE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x;
+  const unsigned long long* row = live + (size_t)bx * K16_NWAVE * wpr;
+  unsigned* out = list + (size_t)bx * (size_t)stride;
+  const int t0 = (int)(((long long)tile_origin + (long long)bx * (K16_BQ / K16_TS)) % n_tiles);
+  int base = 0, par = 0;
+  for (int s0 = 0; s0 < n_tiles; s0 += 256, par ^= 1) {
+    const int sidx = s0 + tid;
+    unsigned mask = 0u;
+    int t = 0;
+    if (sidx < n_tiles) {
+      t = k16_scan_tile(sidx, t0, n_tiles, two_sided);
+      const int wd = t >> 6, bt = t & 63;
+#pragma unroll
+      for (int w = 0; w < K16_NWAVE; ++w) mask |= (unsigned)((row[(size_t)w * wpr + wd] >> bt) & 1ull) << w;
+    }
+    const bool keep = mask != 0u || sidx == 0;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wtot[par][wave] = __popcll(bal);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wtot[par][w];
+    if (keep) out[before + __popcll(bal & (((unsigned long long)1 << lane) - 1ull))] = (unsigned)t | (mask << 24);
+    base += wtot[par][0] + wtot[par][1] + wtot[par][2] + wtot[par][3];
+  }
+  if (tid == 0) cnt[bx] = base;
+}
+
 static int k16_two_sided() {  // scan order: own tiles, then alternately forwards / backwards (0 = forwards only; profiling hook)
   const char* e = getenv("MELD_KNN16_TWO_SIDED");
   return e ? (atoi(e) != 0) : 1;
@@ -2117,6 +2217,83 @@ extern "C" int meld_knn16_step_lists(const void* lb2, const float* thr_seed, int
                      reinterpret_cast<const __half*>(lb2), thr_seed, n_tiles, (float)meld_knn16_error_coef(nprod, d), norm2_max, scale_info,
                      tile_origin, k16_two_sided(), list, (long long)list_stride, cnt);
   MELD_LAUNCH_CHECK("knn16_step_list_kernel");
+  return MELD_OK;
+}
+
+// Step lists straight from the cells (queries = all the cells, start thresholds known): tile spheres, the cells x centroids
+// bounds in their bit form (knn16_tile_bounds_kernel<..., BITS>), transpose-and-AND, lists -- the fp16 table of meld_knn16_bounds
+// (2 B per (wave, tile): 488 MB at 1M cells), its symmetrisation pass and the list builder's pass over it never exist.
+// Same lists as meld_knn16_bounds + meld_knn16_step_lists (tests/test_gpu_parity.py compares them entry by entry).
+extern "C" size_t meld_knn16_list_scratch_bytes(int64_t n_ref) {
+  const size_t n_q = (size_t)ceil_div(n_ref, K16_BQ) * K16_NWAVE, wpr = (size_t)ceil_div(ceil_div(n_ref, K16_TS), 64);
+  return ((n_q * sizeof(float) + 255) / 256) * 256 + 3 * n_q * wpr * sizeof(unsigned long long);
+}
+
+extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                            const float* norm2_max, const void* Rt16, const float* thr_seed, const float* q_norm2,
+                                            int nprod, void* temp, void* scratch, uint32_t* list, int64_t list_stride, int32_t* cnt,
+                                            meld_stream_t stream) {
+  MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_step_lists_direct: nprod must be 1 or 3");
+  MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && thr_seed && q_norm2 && temp && scratch && list && cnt && N > 0,
+                 "meld_knn16_step_lists_direct: bad arguments");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int n_t = (int)ceil_div(N, K16_TS), n_q = (int)ceil_div(N, K16_BQ) * K16_NWAVE;
+  MELD_CHECK_ARG(n_t < (1 << 24) && list_stride >= n_t, "meld_knn16_step_lists_direct: list_stride must hold the %d tiles of a block", n_t);
+  const int wpr = (int)ceil_div(n_t, 64);
+  const size_t n_c = (size_t)ceil_div(n_t, K16_BOUNDS_THREADS) * K16_BOUNDS_THREADS;
+  hipStream_t st = S(stream);
+  _Float16* c16 = reinterpret_cast<_Float16*>(temp);
+  float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
+  float* cr = cn + n_c;
+  float* wthr = reinterpret_cast<float*>(scratch);
+  unsigned long long* bits_a = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + (((size_t)n_q * sizeof(float) + 255) / 256) * 256);
+  unsigned long long* bits_b = bits_a + (size_t)n_q * wpr;
+  unsigned long long* live = bits_b + (size_t)n_q * wpr;
+  MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+  const float es = (float)meld_knn16_error_coef(nprod, d);
+  hipLaunchKernelGGL(knn16_wave_thresholds_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, st, thr_seed, N, n_q, es, norm2_max,
+                     scale_info, wthr);
+  // (rows of waves that no workgroup of the bounds kernel reaches, and the words behind the last tile, must read as zero)
+  MELD_HIP_CALL(hipMemsetAsync(bits_a, 0, 2 * (size_t)n_q * wpr * sizeof(unsigned long long), st));
+  const int bt = KB <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2;
+  const int gx = (int)(n_c / bt);
+  const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
+  const float ec = (float)meld_knn16_error_coef(1, d);
+#define K16_BITS_LAUNCH(KBV, BTV)                                                                                          \
+  hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true, BTV, true>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr,        \
+                     reinterpret_cast<const _Float16*>(Rt16), n_t, 0, n_q, ec, norm2_max, scale_info, thr_seed, N, es, 1, q_norm2, \
+                     (float)meld_knn16_error_coef_const(nprod, d), (float)meld_knn16_error_coef_lin(nprod), (__half*)nullptr, wthr,  \
+                     bits_a, bits_b, wpr)
+#define K16_BITS_CASE(KBV) \
+  case KBV:                \
+    K16_BITS_LAUNCH(KBV, (KBV <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2)); \
+    break;
+  switch (KB) {
+    K16_BITS_CASE(4)
+#ifndef K16_DEV_KB4
+    K16_BITS_CASE(1)
+    K16_BITS_CASE(2)
+    K16_BITS_CASE(3)
+    K16_BITS_CASE(5)
+    K16_BITS_CASE(6)
+    K16_BITS_CASE(7)
+    K16_BITS_CASE(8)
+    K16_BITS_CASE(9)
+#endif
+    default:
+      set_err("meld_knn16_step_lists_direct: no kernel for %d K blocks", KB);
+      return MELD_ERR_UNSUPPORTED;
+  }
+#undef K16_BITS_CASE
+#undef K16_BITS_LAUNCH
+  MELD_LAUNCH_CHECK("knn16_tile_bounds_kernel(bits)");
+  const int64_t n_tiles64 = (int64_t)ceil_div(n_q, 64) * wpr;
+  hipLaunchKernelGGL(knn16_bits_transpose_and_kernel, dim3((unsigned)ceil_div(n_tiles64, 4)), dim3(256), 0, st, bits_a, bits_b, n_q, wpr, live);
+  hipLaunchKernelGGL(knn16_step_list_bits_kernel, dim3((unsigned)ceil_div(N, K16_BQ)), dim3(256), 0, st, live, wpr, n_t, 0, k16_two_sided(), list,
+                     (long long)list_stride, cnt);
+  MELD_LAUNCH_CHECK("knn16_step_list_bits_kernel");
   return MELD_OK;
 }
 

@@ -612,13 +612,29 @@ class HipOps:
                             mine = arr[comm.rank * per * width : (comm.rank + 1) * per * width].clone()
                             comm.all_gather_rows(arr, mine)
                         spheres_shared = True
-                lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
                 seeded_bounds = seeds is not None and self.seeded_bounds
-                check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 # (few query blocks -- a row shard, a mid-sized data set -- are searched in reference slices, which the lists do not do)
                 resident_all = lib.meld_knn16_resident_blocks(d, nprod)
-                if self.step_lists and seeds is not None and q_main == q_count and cand_thr is not None and nprod == 1 \
-                        and not os.environ.get("MELD_KNN_MAIN_SLICES") and not (resident_all > 0 and n_blocks < 2 * resident_all):
+                want_lists = self.step_lists and seeds is not None and q_main == q_count and cand_thr is not None and nprod == 1 \
+                    and not os.environ.get("MELD_KNN_MAIN_SLICES") and not (resident_all > 0 and n_blocks < 2 * resident_all)
+                direct = want_lists and seeded_bounds and not spheres_shared and q_begin == 0 and q_count == N and not cross \
+                    and os.environ.get("MELD_KNN_LIST_DIRECT", "1") != "0" and not os.environ.get("MELD_KNN_SYMMETRIC_BOUNDS_OFF")
+                if direct:
+                    # queries = all the cells: the lists come straight from the cells (bounds as two bits per (wave, tile); the fp16
+                    # table, its symmetrisation pass and the list builder's pass over it never exist)
+                    step_list = torch.empty(n_blocks * n_tiles, dtype=torch.int32, device=dev)
+                    step_cnt = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+                    scratch = torch.empty(lib.meld_knn16_list_scratch_bytes(N), dtype=torch.uint8, device=dev)
+                    check(lib.meld_knn16_step_lists_direct(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), ptr(seeds), ptr(Qn), nprod,
+                                                           ptr(tmpb), ptr(scratch), ptr(step_list), n_tiles, ptr(step_cnt), st), "meld_knn16_step_lists_direct")
+                    del scratch
+                    work = step_cnt
+                else:
+                    lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
+                    check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                if direct:
+                    pass
+                elif want_lists:
                     # the tiles a block can rule out at its start thresholds, written down once (the count is the block's work)
                     step_list = torch.empty(n_blocks * n_tiles, dtype=torch.int32, device=dev)
                     step_cnt = torch.empty(n_blocks, dtype=torch.int32, device=dev)
@@ -674,7 +690,7 @@ class HipOps:
                     check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), NR, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), 0 if cross else q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), None, st), "meld_knn16_topk(tail)")
                     check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
                     del t_idx, t_d2, t_cnt
-            used_prune, used_seed = lb2 is not None, seeds is not None
+            used_prune, used_seed = lb2 is not None or step_list is not None, seeds is not None
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             used_block_order = block_order is not None
             used_step_lists = step_list is not None

@@ -822,3 +822,29 @@ def test_ordering_glue_kernels_match_numpy():
     cd, rd = torch.from_numpy(child).cuda(), torch.from_numpy(rank.reshape(-1)).cuda()
     check(lib.meld_order_update_keys(ptr(kd), ptr(cd), ptr(rd), n, f, st), "update")
     np.testing.assert_array_equal(kd.cpu().numpy(), key * f + rank[key, child])
+
+
+def test_direct_step_lists_equal_the_table_driven_ones():
+    """meld_knn16_step_lists_direct (bounds kept as two bits per (wave, tile), transposed and ANDed) must write the lists
+    meld_knn16_bounds + meld_knn16_step_lists write from the symmetrised fp16 table: same counts, same entries; and the graph
+    built on them is the graph of the table-driven search."""
+    mo = _oracle()
+    import meld_amd
+
+    X, _ = mo.synthetic_cells(400000, n_dims=50, seed=5)  # (enough query blocks for the list-driven pass: 2 x the resident workgroups)
+    Xd = torch.from_numpy(X).cuda()
+    graphs = {}
+    for direct in ("1", "0"):
+        os.environ["MELD_KNN_LIST_DIRECT"] = direct
+        try:
+            graphs[direct] = meld_amd.build_knn_graph(Xd, knn=15)
+        finally:
+            os.environ.pop("MELD_KNN_LIST_DIRECT", None)
+        assert graphs[direct].info["step_lists"]
+    A, B = graphs["1"], graphs["0"]
+    assert torch.equal(A.rowptr, B.rowptr) and torch.equal(A.col, B.col) and torch.equal(A.val, B.val)
+    # the same (wave, tile) blocks were computed -- except by the padding waves of the last query block (128 padding queries here),
+    # which the direct lists leave out of every step and the table keeps at whatever their padding seeds say
+    n_tiles = -(-400000 // 64)
+    pad_waves = (-(-400000 // 256) * 256 - 400000) // 64
+    assert 0 <= B.info["wave_tiles_done"] - A.info["wave_tiles_done"] <= pad_waves * n_tiles
