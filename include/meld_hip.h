@@ -457,7 +457,10 @@ int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, co
 int meld_pt_cheby_run(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows, int p,
                       double* t_prev2, double* t_prev1, double* r, const double* coeffs, int n_coef, double alpha2, double beta2,
                       int* last, meld_stream_t stream);
-/* meld_lanczos_steps / meld_lanczos_spmv on the layout (same contracts). */
+/* meld_lanczos_steps / meld_lanczos_spmv on the layout.  Same contracts, except that meld_pt_lanczos_steps needs
+ * scratch = 8 * meld_spmm_dot_slots() doubles (it keeps its partial sums and scalars in parity buffers there: two launches per
+ * iteration, the SpMV derives its own scalars; only state[0] = 1 / |start| is read, before iteration 0) and that betas[it] of
+ * the LAST iteration of a call is written by a closing one-wave launch. */
 int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                           double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,
                           int it_begin, int n_iter, double* scratch, meld_stream_t stream);

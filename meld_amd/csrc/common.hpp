@@ -54,9 +54,21 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Device-resident Lanczos on the tiled layout without a scalar kernel between the iterations: the SpMV of iteration k derives its
+// own scalars from the partial sums the axpy of iteration k - 1 left (beta_{k-1} = sqrt(sum nrm2_prev), s_k = 1 / beta_{k-1},
+// y = s_k L u_k - beta_{k-1} s_{k-1} u_{k-1}); block 0 records beta_{k-1} and s_k and clears the slots the next axpy adds into.
+struct PtLanczos {
+  const double* nrm2_prev;   // DOT_SLOTS partial sums of |w_{k-1}|^2 (k = 0: |u_0|^2 in slot 0)
+  double* nrm2_zero;         // DOT_SLOTS slots to clear
+  const double* state_prev;  // [0] = s_{k-1} (k = 0: 0)
+  double* state_cur;         // [0] <- s_k
+  double* betas;             // betas[it - 1] <- beta_{k-1} (it > 0)
+  int it;
+};
+
 // one recurrence step on the panel-tiled layout (spmm_tiled.hip); coef_dev: device-resident Lanczos scalars
 int pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double* dw, int p, const double* x_full,
             int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
-            double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x = 0.0);
+            double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x = 0.0, const PtLanczos* lz = nullptr);
 
 }  // namespace meld

@@ -272,6 +272,56 @@ __global__ __launch_bounds__(256) void lanczos_axpy_fused_kernel(double* __restr
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(&nrm2[blockIdx.x % DOT_SLOTS], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
+// Device-resident loop on the tiled layout (meld_pt_lanczos_steps): no scalar kernel between the iterations.  The SpMV derives
+// s_k and beta_{k-1} itself (PtLanczos, common.hpp); this is the axpy of lanczos_axpy_fused_kernel with the parity buffers of
+// that scheme: it reads s_k from state_cur, <y, u> from dots_cur, adds |w|^2 into nrm2_cur (cleared by the SpMV before it) and
+// clears dots_next, the slots the NEXT SpMV adds into.
+__global__ __launch_bounds__(256) void lanczos_axpy_pp_kernel(const double* __restrict__ state_cur, const double* __restrict__ dots_cur,
+                                                              double* __restrict__ nrm2_cur, double* __restrict__ dots_next,
+                                                              double* __restrict__ alphas, int it, const double* __restrict__ x,
+                                                              double* __restrict__ y, int64_t n) {
+  __shared__ double s_a;
+  __shared__ double s_part[4];
+  if (threadIdx.x < 64) {
+    const double v = wave_sum(dots_cur[threadIdx.x]);
+    if (threadIdx.x == 0) {
+      const double s_cur = state_cur[0];
+      const double alpha = v * s_cur;
+      s_a = -alpha * s_cur;
+      if (blockIdx.x == 0) alphas[it] = alpha;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 2 * DOT_SLOTS) dots_next[threadIdx.x - 64] = 0.0;
+  __syncthreads();
+  const double a = s_a;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = a * x[i] + y[i];
+    y[i] = v;
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&nrm2_cur[blockIdx.x % DOT_SLOTS], s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+// first call of a run (it_begin == 0): the parity buffers as iteration 0 expects them -- |u_0|^2 = 1 / state[0]^2 in slot 0 of the
+// "previous" sums, s_{-1} = 0, every accumulator clear
+__global__ __launch_bounds__(256) void lanczos_pp_init_kernel(const double* __restrict__ state, double* __restrict__ pp) {
+  // pp: dots[2][2 DOT_SLOTS] | nrm2[2][DOT_SLOTS] | st[2][8]
+  const int t = threadIdx.x;
+  for (int i = t; i < 6 * DOT_SLOTS + 16; i += 256) pp[i] = 0.0;
+  __syncthreads();
+  if (t == 0) {
+    const double inv = state[0];
+    pp[4 * DOT_SLOTS + DOT_SLOTS] = 1.0 / (inv * inv);  // nrm2[1][0]: what "iteration -1" left
+  }
+}
+// end of a batch: beta of the last iteration (the next SpMV would have recorded it)
+__global__ __launch_bounds__(64) void lanczos_pp_last_beta_kernel(const double* __restrict__ nrm2_last, double* __restrict__ betas, int it_last) {
+  const double v = wave_sum(nrm2_last[threadIdx.x]);
+  if (threadIdx.x == 0) betas[it_last] = sqrt(v);
+}
 __global__ __launch_bounds__(64) void lanczos_beta_kernel(double* __restrict__ state, const double* __restrict__ nrm2,
                                                           double* __restrict__ dots, double* __restrict__ betas, int it,
                                                           double* __restrict__ nrm2_clear) {
@@ -458,23 +508,35 @@ extern "C" int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64
                  "meld_pt_lanczos_steps: bad arguments");
   hipStream_t st = S(stream);
   double* V[3] = {v0, v1, v2};
-  double* dots = scratch;
-  double* nrm2 = scratch + 2 * DOT_SLOTS;
+  // Two launches per iteration: the SpMV (which derives its scalars from the previous axpy's partial sums and records beta of the
+  // previous iteration, PtLanczos in common.hpp) and the axpy.  (The one-wave beta kernel that used to sit between them cost a
+  // launch and its gaps, ~7 us of ~90 per iteration; folding it into the axpy behind a last-workgroup ticket had cost more than
+  // it saved -- a device-scope release per workgroup.)  Parity buffers in scratch (8 DOT_SLOTS doubles):
+  //   dots[2][2 DOT_SLOTS] | nrm2[2][DOT_SLOTS] | st[2][8];  iteration k adds <y, u> into dots[k & 1] and |w|^2 into nrm2[k & 1].
+  double* dots_pp = scratch;
+  double* nrm2_pp = scratch + 4 * DOT_SLOTS;
+  double* st_pp = scratch + 6 * DOT_SLOTS;
+  if (it_begin == 0) hipLaunchKernelGGL(lanczos_pp_init_kernel, dim3(1), dim3(256), 0, st, state, scratch);
   const unsigned grid_ax = (unsigned)std::min<int64_t>(2048, ceil_div(n_rows, 256));
   for (int it = it_begin; it < it_begin + n_iter; ++it) {
     double* u_prev = V[it % 3];
     double* u = V[(it + 1) % 3];
     double* y = V[(it + 2) % 3];
-    const int rc = pt_step(layout, rowptr, dw, 1, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots, state, st);
+    const int cur = it & 1, prv = cur ^ 1;
+    PtLanczos lz{nrm2_pp + prv * DOT_SLOTS, nrm2_pp + cur * DOT_SLOTS, st_pp + prv * 8, st_pp + cur * 8, betas, it};
+    const int rc = pt_step(layout, rowptr, dw, 1, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots_pp + cur * 2 * DOT_SLOTS, nullptr, st, 0.0, &lz);
     if (rc != MELD_OK) return rc;
-    // (the beta step stays a one-wave launch of its own: folded into the axpy behind a last-workgroup ticket it needs a
-    // __threadfence per workgroup, which on this part writes the L2 back -- measured 4.9 vs 3.6 ms per estimate)
-    hipLaunchKernelGGL(lanczos_axpy_fused_kernel, dim3(grid_ax), dim3(256), 0, st, state, dots, nrm2, alphas, it, u, y, n_rows);
-    hipLaunchKernelGGL(lanczos_beta_kernel, dim3(1), dim3(64), 0, st, state, nrm2, dots, betas, it, nrm2);
+    hipLaunchKernelGGL(lanczos_axpy_pp_kernel, dim3(grid_ax), dim3(256), 0, st, st_pp + cur * 8, dots_pp + cur * 2 * DOT_SLOTS,
+                       nrm2_pp + cur * DOT_SLOTS, dots_pp + prv * 2 * DOT_SLOTS, alphas, it, u, y, n_rows);
+  }
+  if (n_iter > 0) {
+    const int last = it_begin + n_iter - 1;
+    hipLaunchKernelGGL(lanczos_pp_last_beta_kernel, dim3(1), dim3(64), 0, st, nrm2_pp + (last & 1) * DOT_SLOTS, betas, last);
   }
   MELD_LAUNCH_CHECK("meld_pt_lanczos_steps");
   return MELD_OK;
 }
+
 extern "C" int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                                     const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
                                     const double* state, double* dots, meld_stream_t stream) {

@@ -91,6 +91,7 @@ struct StepArgs {
   double* r;
   double* dots;
   const double* coef_dev;
+  PtLanczos lz;  // (lz.nrm2_prev != NULL: the scalars are derived in the kernel, see common.hpp)
   int64_t x_row_offset;
   double alpha, beta, gamma, coef;
   double coef_x;  // r += coef * y + coef_x * x (own rows): lets a recurrence touch r every other step (meld_pt_cheby_run)
@@ -515,6 +516,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void 
   constexpr int NR = (RMAX + THREADS - 1) / THREADS;
   V<P> xl[NR], zl[NR], rl_[NR];
   double dwi[NR];
+  const bool lz_on = a.lz.nrm2_prev != nullptr;  // (uniform)
+  const double lz_part = lz_on ? a.lz.nrm2_prev[lane & (DOT_SLOTS - 1)] : 0.0;  // requested here, summed behind the barrier
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
     const int rl = min(tid + q * THREADS, max(nrows - 1, 0));
@@ -523,13 +526,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void 
     dwi[q] = a.dw[row];
 #pragma unroll
     for (int c = 0; c < P; ++c) zl[q].v[c] = rl_[q].v[c] = 0.0;
-    if (gamma != 0.0) zl[q] = ldg<P>(zs, row, a.ld, a.colofs);
+    if (gamma != 0.0 || lz_on) zl[q] = ldg<P>(zs, row, a.ld, a.colofs);
     if (a.r != nullptr) rl_[q] = ldg<P>(a.r, row, a.ld, a.colofs);
   }
   stamp(5);
   PT_WAIT_LDS();
   __builtin_amdgcn_s_barrier();  // every accumulator is final
   stamp(6);
+  if (lz_on) {  // every wave derives the iteration's scalars from the same 64 partial sums (same order, same value)
+    const double beta_prev = sqrt(wave_sum(lz_part));
+    const double s_prev = a.lz.state_prev[0];
+    alpha = 1.0 / beta_prev;
+    gamma = -beta_prev * s_prev;
+    if (b == 0 && tid == 0) {
+      a.lz.state_cur[0] = alpha;
+      if (a.lz.it > 0) a.lz.betas[a.lz.it - 1] = beta_prev;
+    }
+    if (b == 0 && tid >= 64 && tid < 64 + DOT_SLOTS) a.lz.nrm2_zero[tid - 64] = 0.0;
+  }
   double d_yx = 0.0, d_yy = 0.0;
 #pragma unroll
   for (int q = 0; q < NR; ++q) {
@@ -1375,7 +1389,7 @@ static int pt_step_cols(pt::StepArgs a, int p, hipStream_t st, bool f32) {
 // internal entry (also used by the Lanczos drivers in spmm.hip)
 int meld::pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double* dw, int p, const double* x_full,
                   int64_t x_row_offset, const double* z, double* y, double* r, double alpha, double beta, double gamma,
-                  double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x) {
+                  double coef, double* dots, const double* coef_dev, hipStream_t st, double coef_x, const PtLanczos* lz) {
   if (L->nb == 0) return MELD_OK;
   pt::StepArgs a;
   a.blk_row = L->blk_row; a.blk_ntile = L->blk_ntile; a.blk_ndist = L->blk_ndist; a.seg = L->seg;
@@ -1385,8 +1399,9 @@ int meld::pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double
   a.ablate = g_pt_ablate;
   a.stamps = g_pt_stamps;
   a.pval32 = L->pval32;
+  if (lz != nullptr) a.lz = *lz; else a.lz = PtLanczos{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   // the fp32 copy of the values serves the lmax estimate only (p = 1 with device-resident Lanczos scalars)
-  return pt_step_cols(a, p, st, coef_dev != nullptr && p == 1 && L->pval32 != nullptr);
+  return pt_step_cols(a, p, st, (coef_dev != nullptr || lz != nullptr) && p == 1 && L->pval32 != nullptr);
 }
 
 extern "C" int meld_pt_cheby_step(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,

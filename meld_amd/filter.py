@@ -280,7 +280,7 @@ def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
     state[3] = inv
     alphas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
     betas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
-    scratch = torch.zeros(3 * slots, dtype=torch.float64, device=dev)
+    scratch = torch.zeros(8 * slots, dtype=torch.float64, device=dev)  # (the tiled loop keeps parity buffers there: 8 x slots)
     it, theta, resid = 0, 0.0, float("inf")
     batch = 4 * check_every
     while it < max_iter:
