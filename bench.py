@@ -434,13 +434,15 @@ def main():
         }
         if "vfc_spmm" in ev2:
             R = int(vfc.n_probes)
-            t_sp = float(np.mean(ev2["vfc_spmm"])) * 1e-3
+            t_sp = float(np.median(ev2["vfc_spmm"])) * 1e-3  # (median: the first product of a fit also pays one-off costs)
             byts = cheby_bytes_per_step(G.nnz, N, R)
+            wide = getattr(vfc, "_fb", {}).get("spmm") == "wide"
             out["roofline_vfc"] = {
-                "kernel": "pt_step_kernel<P=2>, {} launches per SpMM of {} columns (the matrix is streamed once per column pair)".format((R + 1) // 2, R),
+                "kernel": ("cheby_step_wide_kernel: lanes = columns, one launch per SpMM of {} columns (the matrix is streamed once)".format(R) if wide else
+                           "pt_step_kernel<P=2>, {} launches per SpMM of {} columns (the matrix is streamed once per column pair)".format((R + 1) // 2, R)),
                 "bound": "hbm", "achieved": byts / t_sp / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byts / t_sp / 1e9 / PEAK_HBM_GBS,
                 "algorithmic": "{} B per SpMM (12*nnz + 4(N+1) + 8N + 40*N*p, p = {}: the matrix bytes counted once)".format(byts, R),
-                "ms_per_spmm": 1e3 * t_sp, "spmms": len(ev2["vfc_spmm"]), "traffic": None,
+                "ms_per_spmm": 1e3 * t_sp, "ms_per_spmm_mean": float(np.mean(ev2["vfc_spmm"])), "spmms": len(ev2["vfc_spmm"]), "traffic": None,
             }
     out["value_definition"] = ("X resident in HBM when the timed region starts (the bench contract: inputs resident, the PCIe-inclusive "
                                "rate is reported beside it as `value_host_input` and is SURVEY 8d's host-visible figure)")

@@ -351,6 +351,14 @@ int meld_cheby_step(const int64_t* rowptr, const int32_t* col, const double* val
                     const double* z, double* y, double* r, double alpha, double beta, double gamma,
                     double coef, double* dots, meld_stream_t stream);
 
+/* One step of the same recurrence for a WIDE signal (the probe block of the filter-bank VertexFrequencyCluster, stands in for the
+ * dense window products of /root/reference/meld/cluster.py:98-156,179-194): 1 <= p <= 64 columns, row-major [rows, p], lanes =
+ * columns -- the matrix is streamed once for all columns instead of once per column pair.  No accumulator, no dot products:
+ *   y = alpha (dw .* x - W x) + beta x + gamma z     (y and z may alias) */
+int meld_cheby_step_wide(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows, int p,
+                         const double* x_full, int64_t x_row_offset, const double* z, double* y, double alpha, double beta,
+                         double gamma, meld_stream_t stream);
+
 /* r = a * x  (n doubles) -- initialises r = c0/2 * T0 */
 /* Device-resident Lanczos iterations [it_begin, it_begin + n_iter) of L = diag(dw) - W (single GPU:
  * all n_rows rows local), for the lmax estimate ([UPSTREAM pygsp Graph.estimate_lmax], reference

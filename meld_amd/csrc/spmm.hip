@@ -398,9 +398,83 @@ static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double*
   return 0;
 }
 
+// Wide signals (the probe block of the filter-bank VertexFrequencyCluster, p = 64 columns): lanes = COLUMNS.  A wave owns a row at
+// a time; for every nonzero the 64 lanes read the 8 p contiguous bytes of the neighbour's row of the iterate (whole cache lines,
+// one request per 128 bytes instead of one per 16) and the matrix is streamed once for all columns -- against p / 2 launches of
+// the two-column kernel, each of which streams it again (3.4 ms per 64-column product at 1M cells).  The row's (value, column)
+// pairs are loaded eight at a time by the first lanes and handed round with v_readlane (scalar address arithmetic, the value as a
+// scalar operand of the FMA); eight gathers in flight per lane.  Rows of a workgroup are consecutive and workgroups are
+// XCD-contiguous, so the rows of the iterate a neighbourhood shares are served by that XCD's L2.
+//     y = alpha (dw .* x - W x) + beta x + gamma z      (y and z may alias: read before write per element)
+#ifndef MELD_WIDE_U
+#define MELD_WIDE_U 8
+#endif
+#ifndef MELD_WIDE_ROWS
+#define MELD_WIDE_ROWS 8
+#endif
+constexpr int WIDE_U = MELD_WIDE_U;        // gathers in flight per lane
+constexpr int WIDE_ROWS = MELD_WIDE_ROWS;  // rows per wave (consecutive)
+__global__ __launch_bounds__(256) void cheby_step_wide_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ col,
+                                                              const double* __restrict__ val, const double* __restrict__ dw,
+                                                              int64_t n_rows, int p, const double* __restrict__ x_full,
+                                                              int64_t x_row_offset, const double* z, double* y, double alpha,
+                                                              double beta, double gamma) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nb = gridDim.x;
+  const int per = (nb + 7) >> 3;
+  int64_t rb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (rb >= nb) return;
+  const int64_t row_first = (rb * 4 + wv) * WIDE_ROWS;
+  const bool on = lane < p;
+  const int lc = on ? lane : 0;
+  for (int rr = 0; rr < WIDE_ROWS; ++rr) {
+    const int64_t row = row_first + rr;
+    if (row >= n_rows) return;  // (uniform)
+    const int64_t rs = rowptr[row], re = rowptr[row + 1];
+    const double xi = x_full[(x_row_offset + row) * p + lc];
+    const double zi = gamma != 0.0 ? z[row * p + lc] : 0.0;
+    double acc = 0.0;
+    for (int64_t e0 = rs; e0 < re; e0 += WIDE_U) {
+      // lanes 0 .. U-1 fetch the next U entries of the row (clamped: entries past the row's end get weight 0)
+      const int64_t e = min(e0 + (lane & (WIDE_U - 1)), re - 1);
+      const double vv = (e0 + (lane & (WIDE_U - 1)) < re) ? __builtin_nontemporal_load(val + e) : 0.0;
+      const int cc = __builtin_nontemporal_load(col + e);
+      double xj[WIDE_U];
+#pragma unroll
+      for (int u = 0; u < WIDE_U; ++u) {
+        const int cu = __builtin_amdgcn_readlane(cc, u);
+        xj[u] = x_full[(int64_t)cu * p + lc];
+      }
+#pragma unroll
+      for (int u = 0; u < WIDE_U; ++u) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(vv), u), hi = __builtin_amdgcn_readlane(__double2hiint(vv), u);
+        acc = fma(__hiloint2double(hi, lo), xj[u], acc);
+      }
+    }
+    if (on) y[row * p + lane] = alpha * (dw[row] * xi - acc) + beta * xi + gamma * zi;
+  }
+}
+
 }  // namespace meld
 
 using namespace meld;
+
+// One step of the recurrence for a WIDE signal, 3 <= p <= 64 columns, row-major [rows, p] (lanes = columns; see
+// cheby_step_wide_kernel).  Same operator as meld_cheby_step without the accumulator and the dot products:
+//   y = alpha (dw .* x - W x) + beta x + gamma z;   x_full: the whole iterate [n_total, p], x_row_offset: first local row in it.
+extern "C" int meld_cheby_step_wide(const int64_t* rowptr, const int32_t* col, const double* val, const double* dw, int64_t n_rows,
+                                    int p, const double* x_full, int64_t x_row_offset, const double* z, double* y, double alpha,
+                                    double beta, double gamma, meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && col && val && dw && x_full && y && n_rows >= 0 && p >= 1 && p <= 64, "meld_cheby_step_wide: bad arguments (1 <= p <= 64)");
+  MELD_CHECK_ARG(gamma == 0.0 || z != nullptr, "meld_cheby_step_wide: z is required when gamma != 0");
+  if (n_rows == 0) return MELD_OK;
+  const int64_t nblk = ceil_div(n_rows, 4 * WIDE_ROWS);
+  const unsigned grid = (unsigned)(ceil_div(nblk, 8) * 8);
+  hipLaunchKernelGGL(cheby_step_wide_kernel, dim3(grid), dim3(256), 0, S(stream), rowptr, col, val, dw, n_rows, p, x_full, x_row_offset, z,
+                     y, alpha, beta, gamma);
+  MELD_LAUNCH_CHECK("cheby_step_wide_kernel");
+  return MELD_OK;
+}
 
 extern "C" int meld_spmm_dot_slots(void) { return DOT_SLOTS; }
 

@@ -1149,6 +1149,15 @@ class HipOps:
             "meld_cheby_step",
         )
 
+    def cheby_step_wide(self, G, p, x_full, x_row_off, z, y, alpha, beta, gamma):
+        """One recurrence step on a wide row-major signal [rows, p], 1 <= p <= 64 (``meld_cheby_step_wide``: lanes = columns, the
+        matrix streamed once for all columns)."""
+        check(
+            self.lib.meld_cheby_step_wide(ptr(G.rowptr), ptr(G.col), ptr(G.val), ptr(G.dw_dev), G.n_rows, int(p), ptr(x_full), int(x_row_off),
+                                          ptr(z), ptr(y), float(alpha), float(beta), float(gamma), _stream()),
+            "meld_cheby_step_wide",
+        )
+
     def cheby_run(self, G, p, t_prev2, t_prev1, r, coeffs, alpha2, beta2):
         """Steps 2 .. len(coeffs) - 1 of the Chebyshev recurrence in one call (``meld_pt_cheby_run``: single GPU, tiled layout;
         the accumulator is touched every other step).  Returns False when the graph has no tiled layout (the caller steps)."""

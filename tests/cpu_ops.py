@@ -103,6 +103,10 @@ class CpuOps:
             dots[0] = float((yv * xl).sum())
             dots[s] = float((yv * yv).sum())
 
+    def cheby_step_wide(self, G, p, x_full, x_row_off, z, y, alpha, beta, gamma):
+        """meld_cheby_step_wide: the same step on a row-major [rows, p] signal (no accumulator, no dot products)."""
+        self.cheby_step(G, p, x_full, x_row_off, z, y, None, alpha, beta, gamma, 0.0)
+
     # the four phases of the device-resident Lanczos iteration (meld_lanczos_spmv / _alpha / _axpy / _beta)
     def lanczos_spmv(self, G, x_full, z_local, y_local, state, dots):
         n = G.n_rows

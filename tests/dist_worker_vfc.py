@@ -23,7 +23,7 @@ def main(out_path, n, d, knn):
     op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X), labels, ops=CpuOps(), comm=mdist.Comm())
     G = op.graph
-    kw = dict(method="filterbank", n_probes=24, n_bands=6, window_sizes=np.array([1, 2, 4, 8]), chebyshev_order=48, random_state=3, n_clusters=3)
+    kw = dict(method="filterbank", n_probes=int(os.environ.get("MELD_TEST_PROBES", "24")), n_bands=6, window_sizes=np.array([1, 2, 4, 8]), chebyshev_order=48, random_state=3, n_clusters=3)
     vfc = meld_amd.VertexFrequencyCluster(**kw)
     vfc.fit(G)
     out = dict(spec=vfc._fb_spectrogram.numpy(), norm2=vfc._fb["window_norm2"].numpy(), ritz=vfc._fb["ritz"].numpy(), lmax=G.lmax)

@@ -155,3 +155,23 @@ def test_sharded_filterbank_vfc(tmp_path):
             assert np.abs(r["spec"] - ref["spec"]).max() < 1e-7  # (lmax itself differs in the last digits between shardings)
             assert np.abs(r["ritz"] - ref["ritz"]).max() < 1e-7 * float(ref["lmax"])
             assert np.abs(r["norm2"] - ref["norm2"]).max() < 1e-7 * np.abs(ref["norm2"]).max()
+
+
+def test_sharded_filterbank_vfc_wide_probe_block(tmp_path):
+    """The same with 40 probes: more than 32 columns take the wide step (row-major iterate, ONE all-gather per product instead of
+    one per column pair); world 1 and 2 agree, world 1 equals the path without a process group."""
+    res = {}
+    for world in (1, 2):
+        out = str(tmp_path / "vfcw{}".format(world))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "tests", "dist_worker_vfc.py"), out, "900", "6", "7"]
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="2", MELD_TEST_PROBES="40"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        res[world] = [np.load(out + ".rank{}.npz".format(k)) for k in range(world)]
+    ref = res[1][0]
+    assert ref["spec"].shape == (900, 40 + 6) and np.isfinite(ref["spec"]).all()
+    assert np.abs(ref["spec"] - ref["spec_unsharded"]).max() < 1e-9
+    for r in res[2]:
+        assert np.abs(r["spec"] - ref["spec"]).max() < 1e-7
+        assert np.abs(r["ritz"] - ref["ritz"]).max() < 1e-7 * float(ref["lmax"])

@@ -212,3 +212,58 @@ def test_filterbank_at_a_size_the_dense_method_cannot_reach():
     means = [lik["expt"].values[out == c].mean() for c in range(6)]
     assert means == sorted(means)
     assert np.isfinite(vfc.spectrogram).all() and vfc.spectrogram.min() >= 0.0
+
+
+def test_wide_recurrence_step_equals_the_two_column_kernel():
+    """meld_cheby_step_wide (lanes = columns, the matrix streamed once for all columns) against the recurrence kernel MELD's own
+    filter uses, column pair by column pair: p = 64 and a ragged p = 41, with and without the z operand, aliased y / z, and on a
+    row shard (x_row_offset > 0)."""
+    import torch
+
+    import meld_amd
+    from meld_amd import filter as mf
+    from oracle import meld_oracle as mo
+
+    X, _ = mo.synthetic_cells(70000, n_dims=20, seed=4)
+    G = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=9)
+    ops = mf._ops_of(G)
+    n = G.N
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for p in (64, 41):
+        x = torch.rand(n, p, dtype=torch.float64, device="cuda", generator=gen)
+        z = torch.rand(n, p, dtype=torch.float64, device="cuda", generator=gen)
+        for gamma in (0.0, -1.0):
+            y = z.clone()
+            ops.cheby_step_wide(G, p, x, 0, y if gamma != 0.0 else None, y, 0.7, -0.2, gamma)
+            ref = torch.empty_like(x)
+            for c in range(p):  # one column at a time through the product kernel
+                xc, zc = x[:, c].contiguous(), z[:, c].contiguous()
+                yc = torch.empty_like(xc)
+                ops.cheby_step(G, 1, xc, 0, zc if gamma != 0.0 else None, yc, None, 0.7, -0.2, gamma, 0.0)
+                ref[:, c] = yc
+            assert float((y - ref).abs().max() / ref.abs().max()) < 1e-13, (p, gamma)
+
+
+def test_filterbank_on_the_wide_kernel_equals_the_pair_path():
+    """64 probes: the filter bank on the wide kernel (row-major iterates) and on the two-column kernel (pair-major iterates) are the
+    same algorithm on the same random signs."""
+    import os
+
+    import torch
+
+    import meld_amd
+    from oracle import meld_oracle as mo
+
+    X, labels = mo.synthetic_cells(30000, n_dims=12, seed=8)
+    G = meld_amd.MELD(knn=9, verbose=0).fit(torch.from_numpy(X).cuda()).graph
+    out = {}
+    for w in ("1", "0"):
+        os.environ["MELD_VFC_WIDE"] = w
+        try:
+            vfc = meld_amd.VertexFrequencyCluster(method="filterbank", n_probes=64, n_bands=8, window_sizes=np.array([1, 2, 4, 8]),
+                                                  chebyshev_order=48, random_state=3).fit(G)
+        finally:
+            os.environ.pop("MELD_VFC_WIDE", None)
+        assert vfc._fb["spmm"] == ("wide" if w == "1" else "pairs")
+        out[w] = vfc._fb_spectrogram.cpu().numpy()
+    assert np.abs(out["1"] - out["0"]).max() < 1e-8 * max(1.0, np.abs(out["0"]).max())
