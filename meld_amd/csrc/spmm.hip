@@ -425,34 +425,91 @@ __global__ __launch_bounds__(256) void cheby_step_wide_kernel(const int64_t* __r
   int64_t rb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (rb >= nb) return;
   const int64_t row_first = (rb * 4 + wv) * WIDE_ROWS;
+  if (row_first >= n_rows) return;  // (uniform)
+  const int n_here = (int)min((int64_t)WIDE_ROWS, n_rows - row_first);
   const bool on = lane < p;
   const int lc = on ? lane : 0;
-  for (int rr = 0; rr < WIDE_ROWS; ++rr) {
-    const int64_t row = row_first + rr;
-    if (row >= n_rows) return;  // (uniform)
-    const int64_t rs = rowptr[row], re = rowptr[row + 1];
-    const double xi = x_full[(x_row_offset + row) * p + lc];
-    const double zi = gamma != 0.0 ? z[row * p + lc] : 0.0;
-    double acc = 0.0;
-    for (int64_t e0 = rs; e0 < re; e0 += WIDE_U) {
-      // lanes 0 .. U-1 fetch the next U entries of the row (clamped: entries past the row's end get weight 0)
-      const int64_t e = min(e0 + (lane & (WIDE_U - 1)), re - 1);
-      const double vv = (e0 + (lane & (WIDE_U - 1)) < re) ? __builtin_nontemporal_load(val + e) : 0.0;
-      const int cc = __builtin_nontemporal_load(col + e);
-      double xj[WIDE_U];
+  // The wave's WIDE_ROWS consecutive rows are ONE stream of entries [E0, E1): the (value, column) pairs are fetched a chunk ahead
+  // of the gathers they feed and the gathers a chunk ahead of the FMAs that consume them, so the two dependent memory latencies
+  // of a chunk overlap with the previous chunk's work and no bubble opens at a row boundary.  Row boundaries, degrees and the
+  // rows' own operands are loaded once, up front (lane r: row r), and handed round with v_readlane.
+  static_assert(WIDE_ROWS + 1 <= 64, "row pointers of a wave are held one per lane");
+  const int64_t rp = rowptr[min(row_first + min(lane, n_here), n_rows)];
+  const double dwl = dw[min(row_first + min(lane, n_here - 1), n_rows - 1)];
+  double xi[WIDE_ROWS], zi[WIDE_ROWS];
 #pragma unroll
-      for (int u = 0; u < WIDE_U; ++u) {
-        const int cu = __builtin_amdgcn_readlane(cc, u);
-        xj[u] = x_full[(int64_t)cu * p + lc];
-      }
-#pragma unroll
-      for (int u = 0; u < WIDE_U; ++u) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(vv), u), hi = __builtin_amdgcn_readlane(__double2hiint(vv), u);
-        acc = fma(__hiloint2double(hi, lo), xj[u], acc);
-      }
-    }
-    if (on) y[row * p + lane] = alpha * (dw[row] * xi - acc) + beta * xi + gamma * zi;
+  for (int r = 0; r < WIDE_ROWS; ++r) {
+    const int64_t row = min(row_first + r, n_rows - 1);
+    xi[r] = x_full[(x_row_offset + row) * p + lc];
+    zi[r] = gamma != 0.0 ? __builtin_nontemporal_load(z + row * p + lc) : 0.0;  // (streamed once: leave the L2 to the gathered rows)
   }
+  auto rp_at = [&](int r) __attribute__((always_inline)) {
+    return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rp >> 32), r) << 32) |
+                     (unsigned)__builtin_amdgcn_readlane((int)rp, r));
+  };
+  const int64_t E0 = rp_at(0), E1 = rp_at(n_here);
+  auto fetch_pairs = [&](int64_t e0, double& vv, int& cc) __attribute__((always_inline)) {
+    const int64_t e = min(e0 + (lane & (WIDE_U - 1)), E1 - 1);
+    vv = (e0 + (lane & (WIDE_U - 1)) < E1) ? __builtin_nontemporal_load(val + max(e, (int64_t)0)) : 0.0;
+    cc = E1 > E0 ? __builtin_nontemporal_load(col + max(e, (int64_t)0)) : 0;
+  };
+  auto gather = [&](int cc, double (&xj)[WIDE_U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < WIDE_U; ++u) xj[u] = x_full[(int64_t)__builtin_amdgcn_readlane(cc, u) * p + lc];
+  };
+  int r_cur = 0;
+  int64_t re_cur = rp_at(1);
+  double acc = 0.0;
+  auto flush_rows_until = [&](int64_t e) __attribute__((always_inline)) {  // (uniform) close every row that ends at or before entry e
+    while (r_cur < n_here && e >= re_cur) {
+      // xi / zi of row r_cur: a uniform select over the register array
+      double xr = xi[0], zr = zi[0];
+#pragma unroll
+      for (int r = 1; r < WIDE_ROWS; ++r) {
+        xr = (r == r_cur) ? xi[r] : xr;
+        zr = (r == r_cur) ? zi[r] : zr;
+      }
+      const int dlo = __builtin_amdgcn_readlane(__double2loint(dwl), r_cur), dhi = __builtin_amdgcn_readlane(__double2hiint(dwl), r_cur);
+      if (on) __builtin_nontemporal_store(alpha * (__hiloint2double(dhi, dlo) * xr - acc) + beta * xr + gamma * zr, y + (row_first + r_cur) * p + lane);
+      acc = 0.0;
+      ++r_cur;
+      re_cur = r_cur < n_here ? rp_at(r_cur + 1) : E1 + 1;
+    }
+  };
+  double vA, vB;
+  int cA, cB;
+  double xA[WIDE_U], xB[WIDE_U];
+  fetch_pairs(E0, vA, cA);
+  fetch_pairs(E0 + WIDE_U, vB, cB);
+  gather(cA, xA);
+  for (int64_t e0 = E0; e0 < E1; e0 += 2 * WIDE_U) {
+    // chunk A = [e0, e0 + U), chunk B = [e0 + U, e0 + 2 U); the pairs of the chunk after B and B's gathers go out before A is summed
+    gather(cB, xB);
+    double vN;
+    int cN;
+    fetch_pairs(e0 + 2 * WIDE_U, vN, cN);
+#pragma unroll
+    for (int u = 0; u < WIDE_U; ++u) {
+      flush_rows_until(e0 + u);
+      const int lo = __builtin_amdgcn_readlane(__double2loint(vA), u), hi = __builtin_amdgcn_readlane(__double2hiint(vA), u);
+      acc = fma(__hiloint2double(hi, lo), xA[u], acc);
+    }
+    gather(cN, xA);
+    double vM;
+    int cM;
+    fetch_pairs(e0 + 3 * WIDE_U, vM, cM);
+#pragma unroll
+    for (int u = 0; u < WIDE_U; ++u) {
+      flush_rows_until(e0 + WIDE_U + u);
+      const int lo = __builtin_amdgcn_readlane(__double2loint(vB), u), hi = __builtin_amdgcn_readlane(__double2hiint(vB), u);
+      acc = fma(__hiloint2double(hi, lo), xB[u], acc);
+    }
+    vA = vN;
+    cA = cN;
+    vB = vM;
+    cB = cM;
+  }
+  flush_rows_until(E1 + 1);  // the rows that are left (the last one, and rows without entries)
 }
 
 }  // namespace meld
