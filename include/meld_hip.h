@@ -185,7 +185,7 @@ int meld_knn16_block_work(const void* lb2, const float* thr_seed, int64_t n_ref,
  * down once: list[b * list_stride + i] = tile | (bit w set: wave w of block b cannot rule the tile out) << 24 for the
  * i-th step of block b in scan order, cnt[b] = its steps (>= 1), which is also the block's work for block_order.
  * list_stride >= ceil(n_ref / 64); q_begin as for meld_knn16_topk (it fixes where a block's scan starts).
- * meld_knn16_topk_listed is meld_knn16_topk(nprod = 1, n_slices = 1) walking those lists: same candidate rows, counts,
+ * meld_knn16_topk_listed is meld_knn16_topk(nprod = 1) walking those lists: same candidate rows, counts,
  * thresholds (the lists are a superset of the tiles the table-driven kernel visits; the extra ones hold no candidate). */
 int meld_knn16_step_lists(const void* lb2, const float* thr_seed, int64_t n_ref, int d, int64_t q_count, int nprod,
                           const float* norm2_max, const float* scale_info, int64_t q_begin, uint32_t* list,
@@ -202,7 +202,8 @@ int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, c
                            int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt, int64_t list_stride,
                            const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,
                            int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr, uint64_t* tiles_done,
-                           const int32_t* block_order, meld_stream_t stream);
+                           const int32_t* block_order, int n_slices /* as meld_knn16_topk: slice y walks the entries y, y + S, ... of a
+                           block's list into its own candidate rows; merge with meld_knn16_merge_slices */, meld_stream_t stream);
 /* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
  * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
  * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2

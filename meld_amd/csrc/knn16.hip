@@ -367,8 +367,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // read with scalar loads (constant address space), two steps ahead of their use
   typedef const __attribute__((address_space(4))) unsigned* k16_list_ptr;
   const k16_list_ptr my_list = LIST ? (k16_list_ptr)(uintptr_t)(a.step_list + (size_t)bx * (size_t)a.list_stride) : (k16_list_ptr)0;
-  const int n_scan = LIST ? __builtin_amdgcn_readfirstlane(a.step_cnt[bx]) : (n_tiles - sl_y + sl_n - 1) / sl_n;
-  auto list_entry = [&](int s_) __attribute__((always_inline)) { return s_ < n_scan ? my_list[s_] : 0u; };
+  // (reference slices of a LIST launch: slice y takes the entries y, y + S, ... of the block's list -- every slice gets its share
+  // of the nearest tiles, where the thresholds tighten, and the slices of a block are equally long)
+  const int n_scan = ((LIST ? __builtin_amdgcn_readfirstlane(a.step_cnt[bx]) : n_tiles) - sl_y + sl_n - 1) / sl_n;
+  auto list_entry = [&](int s_) __attribute__((always_inline)) { return s_ < n_scan ? my_list[sl_y + sl_n * s_] : 0u; };
   auto entry_live = [&](unsigned e) __attribute__((always_inline)) { return ((e >> (24 + wave)) & 1u) != 0u; };
   const int row_base = (int)(blockIdx.x * (gridDim.y * K16_BQ)) + q_base;  // first candidate row of this wave
   float* const wave_d2 = cand_d2 + (size_t)row_base * cap;                // (wave-uniform: SGPR pairs)
@@ -2417,8 +2419,8 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
                          float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, const uint32_t* step_list,
                          const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
-  MELD_CHECK_ARG(step_list == nullptr || (step_cnt != nullptr && nprod == 1 && n_slices == 1 && lb2 == nullptr && thr_init != nullptr),
-                 "meld_knn16_topk_listed: step lists go with the hi-only pass, one slice, start thresholds and no table");
+  MELD_CHECK_ARG(step_list == nullptr || (step_cnt != nullptr && nprod == 1 && lb2 == nullptr && thr_init != nullptr),
+                 "meld_knn16_topk_listed: step lists go with the hi-only pass, start thresholds and no table");
   // (reference slices combine with pruning, the radius cut and a dispatch order: a slice's table row is the wave's row, its
   // rows are cut at the radius ITS references imply -- looser than the global one, still valid -- and cand_thr then holds
   // n_slices x q_pad thresholds of which the caller takes the minimum per query)
@@ -2619,15 +2621,15 @@ extern "C" int meld_knn16_topk(const void* Q16, const float* Qn, const void* Rt1
 }
 
 // The hi-only first pass over precomputed step lists (meld_knn16_step_lists) instead of the pruning table: same rows,
-// counts and thresholds as meld_knn16_topk(nprod = 1, n_slices = 1, lb2, thr_init) up to the 1.5 % of blocks the per-step
+// counts and thresholds as meld_knn16_topk(nprod = 1, n_slices, lb2, thr_init) up to the 1.5 % of blocks the per-step
 // test against the CURRENT thresholds would have skipped (they hold no candidate: the lists are a superset).
 extern "C" int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
                                       int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
                                       int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
                                       double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
-                                      uint64_t* tiles_done, const int32_t* block_order, meld_stream_t stream) {
+                                      uint64_t* tiles_done, const int32_t* block_order, int n_slices, meld_stream_t stream) {
   MELD_CHECK_ARG(step_list && step_cnt && list_stride > 0, "meld_knn16_topk_listed: null step lists");
-  return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, 1, nullptr, norm2_max, q_begin, thr_init, knn,
+  return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, n_slices, nullptr, norm2_max, q_begin, thr_init, knn,
                        radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, step_list, step_cnt, list_stride,
                        stream);
 }

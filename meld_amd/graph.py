@@ -613,10 +613,12 @@ class HipOps:
                             comm.all_gather_rows(arr, mine)
                         spheres_shared = True
                 seeded_bounds = seeds is not None and self.seeded_bounds
-                # (few query blocks -- a row shard, a mid-sized data set -- are searched in reference slices, which the lists do not do)
+                # (few query blocks -- a row shard, a mid-sized data set -- are searched in reference slices: a slice of a list-driven
+                # launch walks every S-th entry of the block's list, MELD_KNN_LIST_SLICES=0 sends them to the table-driven kernel)
                 resident_all = lib.meld_knn16_resident_blocks(d, nprod)
+                few_blocks = resident_all > 0 and n_blocks < 2 * resident_all
                 want_lists = self.step_lists and seeds is not None and q_main == q_count and cand_thr is not None and nprod == 1 \
-                    and not os.environ.get("MELD_KNN_MAIN_SLICES") and not (resident_all > 0 and n_blocks < 2 * resident_all)
+                    and not (few_blocks and os.environ.get("MELD_KNN_LIST_SLICES", "1") == "0")
                 direct = want_lists and seeded_bounds and not spheres_shared and q_begin == 0 and q_count == N and not cross \
                     and os.environ.get("MELD_KNN_LIST_DIRECT", "1") != "0" and not os.environ.get("MELD_KNN_SYMMETRIC_BOUNDS_OFF")
                 if direct:
@@ -655,7 +657,7 @@ class HipOps:
             # 7-10 ms instead of 26 / 8).  The references are then cut into slices -- blocks x slices workgroups, each
             # with its own candidate rows, merged afterwards -- so that the heavy blocks are shared out.
             main_slices = 1
-            if will_prune and q_main == q_count and cand_thr is not None and step_list is None:
+            if will_prune and q_main == q_count and cand_thr is not None:
                 resident = lib.meld_knn16_resident_blocks(d, nprod)
                 if os.environ.get("MELD_KNN_MAIN_SLICES"):
                     main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
@@ -667,12 +669,15 @@ class HipOps:
                     s_d2 = torch.empty(main_slices * q_pad * cap, dtype=torch.float32, device=dev)
                     s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
                     s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
+                    if step_list is not None:
+                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
+                    else:
+                        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
                     check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_main, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
                 elif step_list is not None:
-                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk_listed")
+                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
                 else:
                     check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do

@@ -53,7 +53,7 @@ def run(seed, label):
     e0.record()
     if LISTS is not None:
         check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, ptr(LISTS[0]), ptr(LISTS[1]), n_tiles, ptr(nmax), 0, ptr(seed),
-                                         knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), ptr(ORDER) if ORDER is not None else None, st))
+                                         knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), ptr(ORDER) if ORDER is not None else None, 1, st))
     else:
       check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(sinfo), N, d, N, ksel, 1, 1, ptr(lb2), ptr(nmax), 0, ptr(seed) if seed is not None else None,
                               knn, rf, ptr(ci), ptr(cd), ptr(cc), ptr(cthr), ptr(done), ptr(ORDER) if ORDER is not None else None, st))
