@@ -60,11 +60,12 @@ print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1)
   python tools/time_wide.py 1000000 64 2>&1 | grep -v amdgpu.ids | tail -2
   CMD="python tools/time_wide.py 1000000 64" bash tools/pmc_kernel.sh cheby_step_wide 2>&1 | tail -15; } > $out/wide_spmm.txt
 { stamp; echo "# search ablations (-DK16_PROFILING build of knn16.hip; list-driven kernel) + what perfect seeds would be worth + list statistics"
-  bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING -DK16_DEV_KB4 > /dev/null 2>&1
-  MELD_HIP_LIB=$PWD/meld_amd/libmeld_hip_prof.so python tools/knn_ablate.py 2>&1 | grep -v amdgpu.ids
+  # (meld_amd/libmeld_hip_prof.so: built BEFORE the call, on the build host -- `bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING
+  # -DK16_DEV_KB4`; the object files it links against do not travel to the GPU box)
+  if [ -f meld_amd/libmeld_hip_prof.so ]; then MELD_HIP_LIB=$PWD/meld_amd/libmeld_hip_prof.so python tools/knn_ablate.py 2>&1 | grep -v amdgpu.ids; else echo "(no profiling build of the library in the tree: ablations skipped)"; python tools/knn_ablate.py 2>&1 | grep -v amdgpu.ids | grep "product\|table\|per wave\|seed /"; fi
   python tools/list_stats.py 2>&1 | grep -v amdgpu.ids | tail -9
   MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats" | head -2
-  rm -f meld_amd/libmeld_hip_prof.so; } > $out/knn_ablation.txt
+  } > $out/knn_ablation.txt
 { stamp; echo "# per-rank compute of the sharded driver on ONE GPU (stand-in collectives, results wrong by construction): tools/shard_emulate.py"
   for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done; } > $out/shard_emulation.txt
 ls -la $out $out/pmc
