@@ -407,7 +407,7 @@ static int launch_cheby(const int64_t* rowptr, const int32_t* col, const double*
 // XCD-contiguous, so the rows of the iterate a neighbourhood shares are served by that XCD's L2.
 //     y = alpha (dw .* x - W x) + beta x + gamma z      (y and z may alias: read before write per element)
 #ifndef MELD_WIDE_U
-#define MELD_WIDE_U 8
+#define MELD_WIDE_U 16
 #endif
 #ifndef MELD_WIDE_ROWS
 #define MELD_WIDE_ROWS 8

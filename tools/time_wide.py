@@ -7,7 +7,7 @@ from bench import synthetic_cells
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 X, _ = synthetic_cells(N, 50, seed=0)
-G = meld_amd.MELD(verbose=0).fit(torch.from_numpy(X).cuda()).graph
+G = meld_amd.MELD(knn=int(os.environ.get("KNN", "15")), verbose=0).fit(torch.from_numpy(X).cuda()).graph  # (the benchmark graph: knn = 15, 39.4 M nonzeros)
 ops = mf._ops_of(G)
 x = torch.rand(N, p, dtype=torch.float64, device="cuda"); z = torch.rand(N, p, dtype=torch.float64, device="cuda")
 y = torch.empty_like(x)
