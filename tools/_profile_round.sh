@@ -58,7 +58,9 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1))"; } > $out/vfc_1M.txt
 { stamp; echo "# the wide (lanes = columns) recurrence step, 64 columns at 1M cells: tools/time_wide.py; counters: tools/pmc_kernel.sh cheby_step_wide"
   python tools/time_wide.py 1000000 64 2>&1 | grep -v amdgpu.ids | tail -2
-  CMD="python tools/time_wide.py 1000000 64" bash tools/pmc_kernel.sh cheby_step_wide 2>&1 | tail -15; } > $out/wide_spmm.txt
+  CMD="python tools/time_wide.py 1000000 64" bash tools/pmc_kernel.sh cheby_step_wide 2>&1 | tail -15
+  echo "# where the neighbours lie in the device order (tools/row_locality.py): the share of the nonzeros inside a window of rows"
+  python tools/row_locality.py 2>&1 | grep -v amdgpu.ids | tail -8; } > $out/wide_spmm.txt
 { stamp; echo "# search ablations (-DK16_PROFILING build of knn16.hip; list-driven kernel) + what perfect seeds would be worth + list statistics"
   # (meld_amd/libmeld_hip_prof.so: built BEFORE the call, on the build host -- `bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING
   # -DK16_DEV_KB4`; the object files it links against do not travel to the GPU box)
