@@ -469,10 +469,12 @@ int meld_pt_cheby_run(const meld_pt_layout_t* layout, const int64_t* rowptr, con
 /* meld_lanczos_steps / meld_lanczos_spmv on the layout.  Same contracts, except that meld_pt_lanczos_steps needs
  * scratch = 8 * meld_spmm_dot_slots() doubles (it keeps its partial sums and scalars in parity buffers there: two launches per
  * iteration, the SpMV derives its own scalars; only state[0] = 1 / |start| is read, before iteration 0) and that betas[it] of
- * the LAST iteration of a call is written by a closing one-wave launch. */
+ * the LAST iteration of a call is written by a closing one-wave launch.  stop (optional, device memory): a launch of the call that
+ * finds *stop != 0 when it starts does nothing -- the caller checks convergence on the host while the NEXT batch already runs
+ * and voids what is left of it once it has its answer (the vectors and the entries of that batch are then undefined). */
 int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                           double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,
-                          int it_begin, int n_iter, double* scratch, meld_stream_t stream);
+                          int it_begin, int n_iter, double* scratch, const int32_t* stop, meld_stream_t stream);
 int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                          const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
                          const double* state, double* dots, meld_stream_t stream);

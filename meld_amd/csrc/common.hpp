@@ -64,6 +64,7 @@ struct PtLanczos {
   double* state_cur;         // [0] <- s_k
   double* betas;             // betas[it - 1] <- beta_{k-1} (it > 0)
   int it;
+  const int* stop;  // (optional) nonzero when the launch starts: it does nothing (a stop request of the host's convergence check)
 };
 
 // one recurrence step on the panel-tiled layout (spmm_tiled.hip); coef_dev: device-resident Lanczos scalars

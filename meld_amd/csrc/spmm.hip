@@ -279,9 +279,10 @@ __global__ __launch_bounds__(256) void lanczos_axpy_fused_kernel(double* __restr
 __global__ __launch_bounds__(256) void lanczos_axpy_pp_kernel(const double* __restrict__ state_cur, const double* __restrict__ dots_cur,
                                                               double* __restrict__ nrm2_cur, double* __restrict__ dots_next,
                                                               double* __restrict__ alphas, int it, const double* __restrict__ x,
-                                                              double* __restrict__ y, int64_t n) {
+                                                              double* __restrict__ y, int64_t n, const int* __restrict__ stop) {
   __shared__ double s_a;
   __shared__ double s_part[4];
+  if (stop != nullptr && *stop != 0) return;  // (uniform) stop request: see PtLanczos
   if (threadIdx.x < 64) {
     const double v = wave_sum(dots_cur[threadIdx.x]);
     if (threadIdx.x == 0) {
@@ -318,7 +319,9 @@ __global__ __launch_bounds__(256) void lanczos_pp_init_kernel(const double* __re
   }
 }
 // end of a batch: beta of the last iteration (the next SpMV would have recorded it)
-__global__ __launch_bounds__(64) void lanczos_pp_last_beta_kernel(const double* __restrict__ nrm2_last, double* __restrict__ betas, int it_last) {
+__global__ __launch_bounds__(64) void lanczos_pp_last_beta_kernel(const double* __restrict__ nrm2_last, double* __restrict__ betas, int it_last,
+                                                                  const int* __restrict__ stop) {
+  if (stop != nullptr && *stop != 0) return;
   const double v = wave_sum(nrm2_last[threadIdx.x]);
   if (threadIdx.x == 0) betas[it_last] = sqrt(v);
 }
@@ -633,7 +636,7 @@ extern "C" int meld_lanczos_spmv(const int64_t* rowptr, const int32_t* col, cons
 // The same two drivers on the panel-tiled layout (spmm_tiled.hip).
 extern "C" int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64_t* rowptr, const double* dw, int64_t n_rows,
                                      double* v0, double* v1, double* v2, double* state, double* alphas, double* betas,
-                                     int it_begin, int n_iter, double* scratch, meld_stream_t stream) {
+                                     int it_begin, int n_iter, double* scratch, const int32_t* stop, meld_stream_t stream) {
   MELD_CHECK_ARG(layout && rowptr && dw && v0 && v1 && v2 && state && alphas && betas && scratch && n_rows > 0 &&
                      it_begin >= 0 && n_iter >= 0,
                  "meld_pt_lanczos_steps: bad arguments");
@@ -654,15 +657,15 @@ extern "C" int meld_pt_lanczos_steps(const meld_pt_layout_t* layout, const int64
     double* u = V[(it + 1) % 3];
     double* y = V[(it + 2) % 3];
     const int cur = it & 1, prv = cur ^ 1;
-    PtLanczos lz{nrm2_pp + prv * DOT_SLOTS, nrm2_pp + cur * DOT_SLOTS, st_pp + prv * 8, st_pp + cur * 8, betas, it};
+    PtLanczos lz{nrm2_pp + prv * DOT_SLOTS, nrm2_pp + cur * DOT_SLOTS, st_pp + prv * 8, st_pp + cur * 8, betas, it, stop};
     const int rc = pt_step(layout, rowptr, dw, 1, u, 0, u_prev, y, nullptr, 0.0, 0.0, 0.0, 0.0, dots_pp + cur * 2 * DOT_SLOTS, nullptr, st, 0.0, &lz);
     if (rc != MELD_OK) return rc;
     hipLaunchKernelGGL(lanczos_axpy_pp_kernel, dim3(grid_ax), dim3(256), 0, st, st_pp + cur * 8, dots_pp + cur * 2 * DOT_SLOTS,
-                       nrm2_pp + cur * DOT_SLOTS, dots_pp + prv * 2 * DOT_SLOTS, alphas, it, u, y, n_rows);
+                       nrm2_pp + cur * DOT_SLOTS, dots_pp + prv * 2 * DOT_SLOTS, alphas, it, u, y, n_rows, stop);
   }
   if (n_iter > 0) {
     const int last = it_begin + n_iter - 1;
-    hipLaunchKernelGGL(lanczos_pp_last_beta_kernel, dim3(1), dim3(64), 0, st, nrm2_pp + (last & 1) * DOT_SLOTS, betas, last);
+    hipLaunchKernelGGL(lanczos_pp_last_beta_kernel, dim3(1), dim3(64), 0, st, nrm2_pp + (last & 1) * DOT_SLOTS, betas, last, stop);
   }
   MELD_LAUNCH_CHECK("meld_pt_lanczos_steps");
   return MELD_OK;

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(48))) void 
   const int per = nbp >> 3;
   const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (b >= a.nb) return;  // padding workgroup (whole workgroup leaves: no barrier is left hanging)
+  if (a.lz.stop != nullptr && *a.lz.stop != 0) return;  // (uniform) the host has what it needs: the rest of the batch is void
 
   double alpha = a.alpha, gamma = a.gamma;
   const double beta = a.beta, coef = a.coef, coef_x = a.coef_x;
@@ -1399,7 +1400,7 @@ int meld::pt_step(const meld_pt_layout_t* L, const int64_t* rowptr, const double
   a.ablate = g_pt_ablate;
   a.stamps = g_pt_stamps;
   a.pval32 = L->pval32;
-  if (lz != nullptr) a.lz = *lz; else a.lz = PtLanczos{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (lz != nullptr) a.lz = *lz; else a.lz = PtLanczos{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   // the fp32 copy of the values serves the lmax estimate only (p = 1 with device-resident Lanczos scalars)
   return pt_step_cols(a, p, st, (coef_dev != nullptr || lz != nullptr) && p == 1 && L->pval32 != nullptr);
 }

@@ -265,11 +265,33 @@ def _ritz_check(alphas, betas, tol):
     return theta, resid
 
 
+class _LanczosHostSide:
+    """What the host's half of the device-resident Lanczos loop keeps per device: a side stream that carries the tridiagonal
+    entries to a pinned buffer behind every batch of iterations, so that the main stream never waits for a convergence check."""
+
+    _per_device = {}
+
+    def __init__(self, dev, max_iter):
+        self.side = torch.cuda.Stream(device=dev)
+        self.ab = torch.empty(2, max_iter, dtype=torch.float64, pin_memory=True)
+
+    @classmethod
+    def of(cls, dev, max_iter):
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        h = cls._per_device.get(key)
+        if h is None or h.ab.shape[1] < max_iter:
+            h = cls._per_device[key] = cls(dev, max_iter)
+        return h
+
+
 def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
-    """Single-GPU Lanczos with every scalar on the device (``meld_lanczos_steps``): iterations are
-    enqueued in batches and the tridiagonal entries are read back only when a convergence check is
-    due -- a first batch of 4 checks' worth, then one check per ``check_every`` iterations -- instead of
-    two host round trips per iteration."""
+    """Single-GPU Lanczos with every scalar on the device (``meld_lanczos_steps``): iterations are enqueued in batches -- a
+    first batch of 4 checks' worth, then one check per ``check_every`` iterations -- and the tridiagonal entries of a batch
+    travel to the host on a side stream while the NEXT batch already runs: the convergence check (a k x k tridiagonal
+    eigenproblem on the host) overlaps with device work instead of idling the GPU once per batch (12 idle gaps of ~0.1 ms at
+    500k cells, 75 iterations).  Once the check has passed, a flag set from the side stream voids what is left of the batch in
+    flight (its launches return at once, ``stop`` of ``meld_pt_lanczos_steps``), so the overlap costs an iteration or two of
+    wasted work, not a batch (``MELD_LANCZOS_SPECULATE=0``: the serial loop)."""
     dev, n = G.val.device, G.N
     slots = ops.dot_slots()
     V = torch.zeros(3, n, dtype=torch.float64, device=dev)
@@ -278,27 +300,55 @@ def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
     inv = 1.0 / torch.linalg.vector_norm(V[1])
     state[0] = inv
     state[3] = inv
-    alphas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
-    betas_d = torch.zeros(max_iter, dtype=torch.float64, device=dev)
+    ab_d = torch.zeros(2, max_iter, dtype=torch.float64, device=dev)
+    alphas_d, betas_d = ab_d[0], ab_d[1]
     scratch = torch.zeros(8 * slots, dtype=torch.float64, device=dev)  # (the tiled loop keeps parity buffers there: 8 x slots)
-    it, theta, resid = 0, 0.0, float("inf")
-    batch = 4 * check_every
-    while it < max_iter:
-        n_iter = min(batch, max_iter - it)
-        ops.lanczos_steps(G, V, state, alphas_d, betas_d, it, n_iter, scratch)
-        it_new = it + n_iter
-        ab = torch.stack([alphas_d[:it_new], betas_d[:it_new]]).cpu().numpy()  # the one synchronisation per batch
-        alphas, betas = ab[0], ab[1]
+    host = _LanczosHostSide.of(dev, max_iter)
+    main = torch.cuda.current_stream(dev)
+    ab_d.record_stream(host.side)
+    in_flight = 2 if os.environ.get("MELD_LANCZOS_SPECULATE", "1") != "0" else 1
+    stop = torch.zeros(1, dtype=torch.int32, device=dev)  # set once the check has passed: what is left of the batch in flight is void
+    stop.record_stream(host.side)
+
+    def finish(theta, info):
+        if in_flight > 1:
+            with torch.cuda.stream(host.side):
+                stop.fill_(1)
+        return theta, info
+
+    def enqueue(lo, hi):
+        """iterations [lo, hi) on the main stream, their alphas / betas to the pinned buffer behind them on the side stream"""
+        ops.lanczos_steps(G, V, state, alphas_d, betas_d, lo, hi - lo, scratch, stop)
+        ran = torch.cuda.Event()
+        ran.record(main)
+        host.side.wait_event(ran)
+        with torch.cuda.stream(host.side):
+            host.ab[0, lo:hi].copy_(alphas_d[lo:hi], non_blocking=True)
+            host.ab[1, lo:hi].copy_(betas_d[lo:hi], non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(host.side)
+        return lo, hi, landed
+
+    it = min(4 * check_every, max_iter)
+    pending = [enqueue(0, it)]
+    theta, resid, examined = 0.0, float("inf"), 0
+    while pending or it < max_iter:
+        while it < max_iter and len(pending) < in_flight:
+            hi = min(it + check_every, max_iter)
+            pending.append(enqueue(it, hi))
+            it = hi
+        lo, hi, landed = pending.pop(0)
+        landed.synchronize()
+        alphas, betas = host.ab[0, :hi].numpy(), host.ab[1, :hi].numpy()
         # examine the prefixes a per-iteration loop would have examined
-        for k in range(it + 1, it_new + 1):
+        for k in range(lo + 1, hi + 1):
             done = betas[k - 1] <= 1e-14 * max(abs(alphas[k - 1]), 1e-300) or not np.isfinite(betas[k - 1])
             if k % check_every == 0 or done or k == max_iter:
                 theta, resid = _ritz_check(alphas[:k], betas[:k], tol)
                 if resid <= tol or done:
-                    return theta, dict(iterations=k, residual=resid, tol=tol, device_resident=True)
-        it = it_new
-        batch = check_every
-    return theta, dict(iterations=it, residual=resid, tol=tol, device_resident=True)
+                    return finish(theta, dict(iterations=k, residual=resid, tol=tol, device_resident=True, enqueued=it))
+        examined = hi
+    return theta, dict(iterations=examined, residual=resid, tol=tol, device_resident=True, enqueued=it)
 
 
 def _lanczos_lmax_phases(G, ops, comm, u0, tol, max_iter, check_every):

@@ -1179,9 +1179,10 @@ class HipOps:
         )
         return True
 
-    def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch):
+    def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch, stop=None):
         """Iterations [it_begin, it_begin + n_iter) of the device-resident Lanczos recurrence
-        (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors."""
+        (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors.  ``stop`` (int32 device tensor, optional): a launch
+        that finds it nonzero does nothing (tiled layout only; the CSR kernels of small graphs run their batch out)."""
         pt = self.pt_layout(G)
         if pt is not None:
             import ctypes as C
@@ -1189,7 +1190,7 @@ class HipOps:
             check(
                 self.lib.meld_pt_lanczos_steps(C.byref(pt["struct"]), ptr(G.rowptr), ptr(G.dw_dev), G.n_rows, ptr(V[0]), ptr(V[1]),
                                                ptr(V[2]), ptr(state), ptr(alphas), ptr(betas), int(it_begin), int(n_iter),
-                                               ptr(scratch), _stream()),
+                                               ptr(scratch), ptr(stop) if stop is not None else None, _stream()),
                 "meld_pt_lanczos_steps",
             )
             return
