@@ -1295,6 +1295,9 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
     for (int g = 0; g < 2; ++g)
       if (c_base + g * 32 + jq < n_tiles) wcol[g] = wthr[c_base + g * 32 + jq];
   }
+  // the closing pass of a step: lane l finishes centroid c_base + l (group h, member jq)
+  const int c_l = c_base + lane;
+  const float cn_l = h == 0 ? cn[0] : cn[1], cr_l = h == 0 ? cr[0] : cr[1], wcol_l = h == 0 ? wcol[0] : wcol[1];
   f16x8 bx[2];  // centroid side of the extra K block: (-1, -2 rho_t, 0 ...) in the lower half-lanes
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -1387,43 +1390,40 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
       }
     }
     if ((step % TPB) == TPB - 1) {
+      // One pass for both groups: the half-lanes of a group hold the two halves of the tile's cells, so after the exchange every
+      // lane knows both minima -- lanes 0 .. 31 finish group 0 (centroids c_base .. c_base + 31), lanes 32 .. 63 group 1
+      // (c_base + 32 .. c_base + 63): lane l = centroid c_base + l.  (Two passes with the upper half-lanes idle were 40 % of the
+      // kernel's vector instructions, and the kernel is bound by those.)
       const int b = b_lo + step / TPB;
       const float wrow = BITS ? wthr[b] : 0.0f;
-      bool bit_a[2] = {false, false}, bit_b[2] = {false, false};
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const float v = fminf(m[g], __shfl_xor(m[g], 32, 64)) + cn[g];  // min_p |p - c|^2, approximate
-        const float dist = sqrtf(fmaxf(v - err_abs, 0.0f)) * 0.9999f - cr[g];
-        const int c = c_base + g * 32 + jq;
-        // (fp16, rounded towards zero: a smaller bound only prunes less)
-        __half out = __float2half_rz(dist > 0.0f ? fminf(dist * dist, 60000.0f) : 0.0f);
-        const float outv = __half2float(out);  // (the value the table would hold: the tests below are the table-driven ones)
-        bool dead = false;
-        if (SEEDED) {
-          const float vb = fminf(mb[g], __shfl_xor(mb[g], 32, 64)) + cn[g] - cr[g] * cr[g];
-          if (vb > 1.01f * err_abs + 1e-6f * (cn[g] + cr[g] * cr[g])) {  // dead for every query of the wave
-            // (+inf; or, when the table is symmetrised afterwards, the bound with its sign bit set: the bound itself is
-            // still wanted for the transposed entry)
-            out = mark_sign ? __ushort_as_half((unsigned short)(__half_as_ushort(out) | 0x8000u)) : __ushort_as_half((unsigned short)0x7C00);
-            dead = true;
-          }
-          mb[g] = INFINITY;
+      const float m0 = fminf(m[0], __shfl_xor(m[0], 32, 64)), m1 = fminf(m[1], __shfl_xor(m[1], 32, 64));
+      const float v = (h == 0 ? m0 : m1) + cn_l;  // min_p |p - c|^2, approximate
+      const float dist = sqrtf(fmaxf(v - err_abs, 0.0f)) * 0.9999f - cr_l;
+      // (fp16, rounded towards zero: a smaller bound only prunes less)
+      __half out = __float2half_rz(dist > 0.0f ? fminf(dist * dist, 60000.0f) : 0.0f);
+      const float outv = __half2float(out);  // (the value the table would hold: the tests below are the table-driven ones)
+      bool dead = false;
+      if (SEEDED) {
+        const float b0 = fminf(mb[0], __shfl_xor(mb[0], 32, 64)), b1 = fminf(mb[1], __shfl_xor(mb[1], 32, 64));
+        const float vb = (h == 0 ? b0 : b1) + cn_l - cr_l * cr_l;
+        if (vb > 1.01f * err_abs + 1e-6f * (cn_l + cr_l * cr_l)) {  // dead for every query of the wave
+          // (+inf; or, when the table is symmetrised afterwards, the bound with its sign bit set: the bound itself is
+          // still wanted for the transposed entry)
+          out = mark_sign ? __ushort_as_half((unsigned short)(__half_as_ushort(out) | 0x8000u)) : __ushort_as_half((unsigned short)0x7C00);
+          dead = true;
         }
-        if (BITS) {
-          bit_a[g] = h == 0 && c < n_tiles && !dead && outv <= wrow;
-          bit_b[g] = h == 0 && c < n_tiles && outv <= wcol[g];
-        } else {
-          if (h == 0 && c < n_tiles) lb2[(size_t)b * n_tiles + c] = out;
-        }
-        m[g] = INFINITY;
+        mb[0] = mb[1] = INFINITY;
       }
-      if (BITS) {  // lanes 0 .. 31 hold the centroids c_base .. c_base + 31 (g = 0) and c_base + 32 .. c_base + 63 (g = 1)
-        const unsigned long long a0 = __ballot(bit_a[0]), a1 = __ballot(bit_a[1]);
-        const unsigned long long b0 = __ballot(bit_b[0]), b1 = __ballot(bit_b[1]);
+      m[0] = m[1] = INFINITY;
+      if (BITS) {
+        const unsigned long long ba = __ballot(c_l < n_tiles && !dead && outv <= wrow);
+        const unsigned long long bb = __ballot(c_l < n_tiles && outv <= wcol_l);
         if (lane == 0 && c_base < wpr * 64) {
-          bits_a[(size_t)b * wpr + (c_base >> 6)] = (a0 & 0xffffffffull) | (a1 << 32);
-          bits_b[(size_t)b * wpr + (c_base >> 6)] = (b0 & 0xffffffffull) | (b1 << 32);
+          bits_a[(size_t)b * wpr + (c_base >> 6)] = ba;
+          bits_b[(size_t)b * wpr + (c_base >> 6)] = bb;
         }
+      } else {
+        if (c_l < n_tiles) lb2[(size_t)b * n_tiles + c_l] = out;
       }
     }
     if (step + 1 < n_steps) store(buf ^ 1);

@@ -15,8 +15,10 @@ def _resource_usage(src):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
-           "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull]
+    from meld_amd import build as mbuild  # (the flags the library is built with, per-file additions included)
+
+    cmd = [hipcc] + mbuild.FLAGS + mbuild.FILE_FLAGS.get(os.path.basename(src), []) + [
+        "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200).stdout
     rows, cur = {}, None
     for line in out.splitlines():

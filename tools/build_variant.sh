@@ -5,7 +5,8 @@ set -e
 name=$1; src=$2; shift 2
 here=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/variant_${name}_$(basename $src .hip).o
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c $here/meld_amd/csrc/$src -o $obj
+file_flags=$(python3 -c "import sys; sys.path.insert(0, '$here'); from meld_amd import build as b; print(' '.join(b.FILE_FLAGS.get('$src', [])))")
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $file_flags "$@" -c $here/meld_amd/csrc/$src -o $obj
 objs=""
 for o in $here/meld_amd/build/*.o; do
   if [ "$(basename $o)" == "$(basename $src .hip).o" ]; then objs="$objs $obj"; else objs="$objs $o"; fi
