@@ -1683,8 +1683,21 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
       if (j < HV) stage[u] = R4[(size_t)t * (KB * 256) + ((j >> 6) << 7) + (j & 63)];
     }
   };
-  if (t_lo < t_hi) fetch(t_lo);
-  for (int t = t_lo; t < t_hi; ++t) {
+  // Nearest tiles first: the workgroup's own tiles, then outwards on both sides in turn.  The k smallest of a set do not depend on
+  // the order it is scanned in, the work does: walking the window from one end to the other kept the thresholds loose for half of
+  // it, with the distances falling tile after tile -- insertions (one lane's insertion is paid by the wave) in most of them.
+  const int own_hi = min(t_own + SEED_WAVES, t_hi);
+  int n_below = 0, n_above = 0, t_next;  // tiles taken so far on either side; the tile after the one in hand
+  auto advance = [&](int t) __attribute__((always_inline)) {  // (uniform) the tile that follows t in the scan, t_hi when none is left
+    if (t >= t_own && t + 1 < own_hi) return t + 1;
+    const bool more_below = t_own - 1 - n_below >= t_lo, more_above = own_hi + n_above < t_hi;
+    if (more_below && (n_below <= n_above || !more_above)) return t_own - 1 - n_below++;
+    if (more_above) return own_hi + n_above++;
+    return t_hi;
+  };
+  t_next = t_own < own_hi ? t_own : advance(t_hi);  // (a workgroup past the last tile has no tiles of its own)
+  if (t_next < t_hi) fetch(t_next);
+  for (int t = t_next; t < t_hi; t = t_next) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -1692,7 +1705,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
       if (j < HV) lds_a[j] = stage[u];
     }
     __syncthreads();
-    if (t + 1 < t_hi) fetch(t + 1);
+    t_next = advance(t);
+    if (t_next < t_hi) fetch(t_next);
     const f16x8* a8 = reinterpret_cast<const f16x8*>(lds_a);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
