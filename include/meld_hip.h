@@ -158,7 +158,7 @@ int meld_knn16_seed_thresholds(const double* X, int64_t N, int d, const double* 
                                const float* norm2_max, int64_t q_begin, int64_t q_count, int knn, double radius_factor,
                                int nprod, float* thr_init, meld_stream_t stream);
 /* The same start values from the fp16 operands of meld_knn16_prepare, computed on the matrix pipe over the query
- * block's own tiles and side_tiles on either side in index order (side_tiles <= 0: n_ref^2 / 2e10, between 4 and 64 --
+ * block's own tiles and side_tiles on either side in index order (side_tiles <= 0: n_ref / 12500, between 8 and 64 --
  * the cost grows with N, what tighter seeds save in the search and through meld_knn16_bounds' per-query test with N^2). */
 int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info,
                                     const float* norm2_max, int64_t n_ref, int d, int64_t q_begin, int64_t q_count,

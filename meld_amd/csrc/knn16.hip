@@ -1632,8 +1632,10 @@ __global__ __launch_bounds__(256) void knn16_seed_kernel(const double* __restric
 // `side` = tiles on either side of the workgroup's own K16_BQ / K16_TS tiles.  Tighter seeds pay twice since the pruning
 // table tests every query against its own seed (meld_knn16_bounds): at 1M x 50, side 4 / 16 / 32 / 64 cost 0.6 / 1.2 /
 // 1.9 / 3.3 ms and leave the search at 45.9 / 41.9 / 40.9 / 38.9 ms.  The cost grows with N, the gain with N^2: the
-// automatic choice is N^2 / 2e10 tiles, between 4 and 64 (500k cells: 12, best of 16 / 32 / 64 measured there; 1M: 50,
-// where 48 and 64 measure the same and 32 is 0.7 ms behind).
+// automatic choice WAS N^2 / 2e10 tiles, between 4 and 64 (500k cells: 12; 1M: 50).  With the window scanned nearest tiles first a
+// far tile costs little more than its MFMAs, and wider windows pay at the mid sizes: N / 12500 tiles, between 8 and 64 -- whole
+// step at 100k / 200k / 300k / 500k / 750k cells 7.9 -> 7.7 / 10.4 -> 10.2 / 14.8 -> 14.4 / 24.6 -> 23.8 / 34.1 -> 33.7 ms;
+// flat from 50 to 128 at 1M and 2M (what the seeds cost more, the search costs less).
 // (SEED_WAVES waves = 64 SEED_WAVES queries per workgroup share every staged tile: the kernel is bound by its tile loads and
 // barriers, and a workgroup of 8 waves stages 8 + 2 side tiles where two of 4 waves staged 2 (4 + 2 side))
 constexpr int SEED_WAVES = 8;
@@ -2373,7 +2375,7 @@ extern "C" int meld_knn16_seed_thresholds_mfma(const void* Q16, const float* Qn,
                                                const float* norm2_max, int64_t n_ref, int d, int64_t q_begin,
                                                int64_t q_count, int knn, double radius_factor, int nprod, int side_tiles,
                                                float* thr_init, meld_stream_t stream) {
-  const int side = side_tiles > 0 ? side_tiles : (int)std::min<double>(64.0, std::max<double>(4.0, (double)n_ref * (double)n_ref / 2.0e10));
+  const int side = side_tiles > 0 ? side_tiles : (int)std::min<double>(64.0, std::max<double>(8.0, (double)n_ref / 12500.0));
   MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && norm2_max && thr_init && n_ref > 0 && q_count > 0 && q_begin >= 0,
                  "meld_knn16_seed_thresholds_mfma: bad arguments");
   MELD_CHECK_ARG(q_begin % K16_BQ == 0, "meld_knn16_seed_thresholds_mfma: q_begin must be a multiple of the query block (%d)", K16_BQ);
