@@ -107,3 +107,14 @@ if os.environ.get("PROFILE"):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         mdist.fit_transform_sharded(op, Xd, labels, comm=comm); torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60))
+if os.environ.get("CPROFILE"):  # where the HOST time of a rank's step goes (the step is issue-bound at 8 ranks)
+    import cProfile, pstats
+    comm = FakeComm(WORLD, RANK)
+    op = meld_amd.MELD(knn=15, beta=60, chebyshev_order=30, verbose=0)
+    pr = cProfile.Profile()
+    pr.enable()
+    mdist.fit_transform_sharded(op, Xd, labels, comm=comm); torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(30)
