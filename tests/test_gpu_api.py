@@ -609,6 +609,35 @@ def test_one_reduction_lanczos_equals_the_device_resident_loop(n):
     assert abs(t_fld - t_dev) < 1e-10 * t_dev and abs(t_pha - t_dev) < 1e-10 * t_dev
 
 
+@pytest.mark.parametrize("n", [4000, 90000])  # CSR-stream kernel (its batches run out) / panel-tiled layout (stop flag)
+def test_overlapped_convergence_checks_stop_where_the_serial_loop_stops(n, monkeypatch):
+    """The lmax estimate checks a batch on the host while the next one runs and voids the rest of it once a check has passed:
+    same prefix examined, same Ritz value (bit for bit -- the same tridiagonal entries reach the same solver) as the loop that
+    waits for every batch; a second estimate right behind a voided batch starts clean."""
+    meld = _meld()
+    import torch
+
+    from meld_amd import filter as mf
+
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(n, 6))
+    G = meld.MELD(knn=10, verbose=0).fit(X).graph
+    idx = torch.arange(G.n_pad, dtype=torch.float64, device=G.val.device)
+    u = torch.frac(torch.sin(idx * 12.9898 + 1.0) * 43758.5453) - 0.5
+    monkeypatch.setenv("MELD_LANCZOS_SPECULATE", "0")
+    t_ser, i_ser = mf._lanczos_lmax_device(G, G.ops, u, 1e-3, 300, 5)
+    monkeypatch.setenv("MELD_LANCZOS_SPECULATE", "1")
+    t_ovl, i_ovl = mf._lanczos_lmax_device(G, G.ops, u, 1e-3, 300, 5)
+    t_again, i_again = mf._lanczos_lmax_device(G, G.ops, u, 1e-3, 300, 5)
+    torch.cuda.synchronize()
+    assert i_ser["iterations"] == i_ovl["iterations"] == i_again["iterations"]
+    assert t_ser == t_ovl == t_again
+    assert i_ovl["enqueued"] >= i_ovl["iterations"] and i_ser["enqueued"] <= i_ser["iterations"] + 4
+    # a tight iteration cap: the last batch is the cap's, speculation does not run past it
+    t_cap, i_cap = mf._lanczos_lmax_device(G, G.ops, u, 1e-12, 23, 5)
+    assert i_cap["iterations"] == 23 and i_cap["enqueued"] == 23 and t_cap > 0
+
+
 def test_results_lent_from_pinned_buffers_stay_valid_and_come_back():
     """The densities are handed over in the pinned buffer they left the device through (no second host copy).  A result that
     is still held must not be touched by later calls -- more results than the pool lends out are copied as before -- and a
