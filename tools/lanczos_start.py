@@ -8,13 +8,14 @@ from bench import synthetic_cells
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 X, _ = synthetic_cells(N, 50, seed=0)
-G = meld_amd.MELD(verbose=0).fit(torch.from_numpy(X).cuda()).graph
+G = meld_amd.MELD(knn=15, verbose=0).fit(torch.from_numpy(X).cuda()).graph
 ops = mf._ops_of(G)
 idx = torch.arange(G.n_pad, dtype=torch.float64, device="cuda")
 rnd = torch.frac(torch.sin(idx * 12.9898 + 1.0) * 43758.5453) - 0.5
 dw = G.dw_dev[: G.n_pad].clone()
 cands = {"pseudo-random (current)": rnd, "dw * random": dw * rnd, "dw": dw.clone(), "dw - mean": dw - dw.mean(), "dw^2 * random": dw * dw * rnd,
-         "dw^4 * random": dw ** 4 * rnd}
+         "dw^4 * random": dw ** 4 * rnd, "dw^8 * random": (dw / dw.max()) ** 8 * rnd, "dw^16 * random": (dw / dw.max()) ** 16 * rnd,
+         "dw^4": (dw / dw.max()) ** 4, "dw^16": (dw / dw.max()) ** 16}
 ref = None
 for name, u in cands.items():
     u = u.clone(); u[G.N:] = 0
