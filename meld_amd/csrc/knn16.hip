@@ -1133,7 +1133,11 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
                                                            const float* __restrict__ scale_info, int KB,
                                                            _Float16* __restrict__ cent16, float* __restrict__ cent_n,
                                                            float* __restrict__ cent_r, int tile0) {
-  __shared__ float xs[K16_TS][K16_DMAX + 4];
+  // the tile's cells, row stride ld = d | 1 floats (odd: conflict-free column walks; sized by d, not by the largest d the
+  // library takes -- 13 KB instead of 37 at d = 50, three times the workgroups per CU of a kernel that is all latency)
+  extern __shared__ float xs_dyn[];
+  const int ld = d | 1;
+#define XS(r, k) xs_dyn[(r) * ld + (k)]
   __shared__ float cs[K16_DMAX + 19];
   const int tid = threadIdx.x;
   const int tile = tile0 + (int)blockIdx.x;  // (a row-sharded build computes the spheres of a range of tiles per rank)
@@ -1143,13 +1147,13 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
   for (int u = tid; u < K16_TS * d; u += 256) {
     const int r = u / d, k = u - r * d;
     const int64_t i = row0 + r;
-    xs[r][k] = i < N ? s * (float)(X[i * d + k] - mean[k]) : 0.0f;
+    XS(r, k) = i < N ? s * (float)(X[i * d + k] - mean[k]) : 0.0f;
   }
   __syncthreads();
   if (tid < KB * 16) {
     float acc = 0.0f;
     if (tid < d)
-      for (int r = 0; r < cnt; ++r) acc += xs[r][tid];
+      for (int r = 0; r < cnt; ++r) acc += XS(r, tid);
     cs[tid] = tid < d ? acc / (float)cnt : 0.0f;
   }
   __syncthreads();
@@ -1163,24 +1167,38 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
     auto far2 = [&](int* who) {
       float r2 = -1.0f;
       if (lane < cnt) {
+        // (eight LDS reads in flight: the plain loop waited out one LDS round trip per coordinate, 25 times per tile in ONE wave
+        // of the workgroup -- 0.76 ms at 1M cells for a kernel that reads 400 MB; same summation order)
         r2 = 0.0f;
-        for (int k = 0; k < d; ++k) {
-          const float t = xs[lane][k] - cs[k];
+        int k = 0;
+        for (; k + 8 <= d; k += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = XS(lane, k + u) - cs[k + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r2 = fmaf(t[u], t[u], r2);
+        }
+        for (; k < d; ++k) {
+          const float t = XS(lane, k) - cs[k];
           r2 = fmaf(t, t, r2);
         }
       }
+      // the farthest cell, lowest index among equals: a DPP maximum (in-row butterflies, then lane 15 / 31 handed to the rows
+      // above: six vector instructions) and a ballot -- the (value, index) butterfly over ds_bpermute was twelve dependent LDS
+      // round trips per step, 25 steps per tile, in the one wave of the workgroup that works here
+      auto dppf = [](float old, float v, auto ctrl, auto rows) __attribute__((always_inline)) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
+      };
+      using std::integral_constant;
       float m = r2;
-      int mi = lane;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float om = __shfl_xor(m, off, 64);
-        const int oi = __shfl_xor(mi, off, 64);
-        if (om > m || (om == m && oi < mi)) {
-          m = om;
-          mi = oi;
-        }
-      }
-      *who = mi;
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{}));   // quad_perm [1, 0, 3, 2]
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{}));   // quad_perm [2, 3, 0, 1]
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{}));  // row_half_mirror
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{}));  // row_mirror: every lane holds its row's maximum
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{}));  // row_bcast15 -> rows 1 and 3
+      m = fmaxf(m, dppf(m, m, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{}));  // row_bcast31 -> rows 2 and 3
+      m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+      *who = __ffsll((long long)__ballot(r2 == m)) - 1;
       return m;
     };
     float best = INFINITY;
@@ -1197,7 +1215,7 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
       }
       if (it <= MEB_STEPS) {
         const float wgt = 1.0f / (float)(it + 1);
-        for (int k = lane; k < d; k += 64) cs[k] = fmaf(wgt, xs[who][k] - cs[k], cs[k]);
+        for (int k = lane; k < d; k += 64) cs[k] = fmaf(wgt, XS(who, k) - cs[k], cs[k]);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);  // (one wave: its LDS operations complete in order)
       asm volatile("" ::: "memory");
@@ -1234,6 +1252,7 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
     qrow[g * 2 + 0] = hi;
     qrow[g * 2 + 1] = lo;
   }
+#undef XS
 }
 
 // Workgroup = 256 centroids (4 waves x 2 groups of 32, B fragments, hi parts) x a slice of the query
@@ -1964,7 +1983,7 @@ extern "C" int meld_knn16_tile_spheres(const double* X, int64_t N, int d, const 
   _Float16* c16 = reinterpret_cast<_Float16*>(temp);
   float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
   float* cr = cn + n_c;
-  hipLaunchKernelGGL(tile_spheres_kernel, dim3((unsigned)tile_count), dim3(256), 0, S(stream), X, N, d, mean, scale_info, KB, c16, cn, cr,
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3((unsigned)tile_count), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), S(stream), X, N, d, mean, scale_info, KB, c16, cn, cr,
                      (int)tile_begin);
   MELD_LAUNCH_CHECK("tile_spheres_kernel");
   return MELD_OK;
@@ -1999,7 +2018,7 @@ static int k16_bounds_impl(const double* X, int64_t N, int d, const double* mean
   float* cr = cn + n_c;
   if (!spheres_ready) {
     MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
-    hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+    hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
   }
   const int bt = KB <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2;
   const int gx = (int)(n_c / bt);
@@ -2269,7 +2288,7 @@ extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, c
   unsigned long long* bits_b = bits_a + (size_t)n_q * wpr;
   unsigned long long* live = bits_b + (size_t)n_q * wpr;
   MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
-  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), 0, st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
   const float es = (float)meld_knn16_error_coef(nprod, d);
   hipLaunchKernelGGL(knn16_wave_thresholds_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, st, thr_seed, N, n_q, es, norm2_max,
                      scale_info, wthr);
