@@ -214,18 +214,26 @@ __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restric
     __syncthreads();
   }
   int* rg = rank + (size_t)blockIdx.x * m;
-  auto argmin = [&](double v) {  // lowest index among the minima
-    int i = lane;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_xor(v, off, 64);
-      const int oi = __shfl_xor(i, off, 64);
-      if (ov < v || (ov == v && oi < i)) {
-        v = ov;
-        i = oi;
-      }
+  // lowest index among the minima: a DPP minimum (in-row butterflies, then lane 15 / 31 handed to the rows above) and a ballot.
+  // (The (value, index) butterfly over ds_bpermute was 18 dependent LDS round trips per step of a walk that is one wave and up
+  // to 64 steps long, on the critical path of every level of the ordering.)
+  auto argmin = [&](double v) {
+    double mn = v;
+#define CHAIN_DPP_MIN(CTRL, ROWS)                                                                                         \
+    {                                                                                                                      \
+      const int lo = __builtin_amdgcn_update_dpp(__double2loint(mn), __double2loint(mn), CTRL, ROWS, 0xF, false);          \
+      const int hi = __builtin_amdgcn_update_dpp(__double2hiint(mn), __double2hiint(mn), CTRL, ROWS, 0xF, false);          \
+      mn = fmin(mn, __hiloint2double(hi, lo));                                                                             \
     }
-    return i;
+    CHAIN_DPP_MIN(0xB1, 0xF)   // quad_perm [1, 0, 3, 2]
+    CHAIN_DPP_MIN(0x4E, 0xF)   // quad_perm [2, 3, 0, 1]
+    CHAIN_DPP_MIN(0x141, 0xF)  // row_half_mirror
+    CHAIN_DPP_MIN(0x140, 0xF)  // row_mirror: every lane holds its row's minimum
+    CHAIN_DPP_MIN(0x142, 0xA)  // row_bcast15 -> rows 1 and 3
+    CHAIN_DPP_MIN(0x143, 0xC)  // row_bcast31 -> rows 2 and 3: lane 63 holds the wave's
+#undef CHAIN_DPP_MIN
+    mn = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mn), 63), __builtin_amdgcn_readlane(__double2loint(mn), 63));
+    return __ffsll((long long)__ballot(v == mn)) - 1;
   };
   bool used = lane >= m;
   int cur = argmin(lane < m ? Pr[lane * ld] : INFINITY);
@@ -237,7 +245,15 @@ __global__ __launch_bounds__(64) void chain_order_kernel(const double* __restric
     double dist = INFINITY;
     if (!used) {
       dist = 0.0;
-      for (int k = 0; k < d; ++k) {
+      int k = 0;
+      for (; k + 8 <= d; k += 8) {  // (eight pairs of reads in flight; same summation order)
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = Pr[lane * ld + k + u] - Pr[cur * ld + k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dist = fma(t[u], t[u], dist);
+      }
+      for (; k < d; ++k) {
         const double t = Pr[lane * ld + k] - Pr[cur * ld + k];
         dist = fma(t, t, dist);
       }

@@ -17,3 +17,5 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     p = ro.locality_permutation(Xd); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=50))
+import hashlib
+print("permutation sha1 %s" % hashlib.sha1(p.cpu().numpy().tobytes()).hexdigest()[:16])
