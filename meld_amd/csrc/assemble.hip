@@ -409,8 +409,8 @@ __global__ __launch_bounds__(256) void coo_emit_scatter_fallback_kernel(const in
   }
 }
 
-template <int SL>
-__device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], int lane) {
+template <int SL, typename K>
+__device__ __forceinline__ void csr_bitonic_sort(K (&key)[SL], int lane) {
   constexpr int NE = 64 * SL;
 #pragma unroll
   for (int k = 2; k <= NE; k <<= 1) {
@@ -422,7 +422,7 @@ __device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], 
         for (int e = 0; e < SL; ++e) {
           if ((e & je) == 0) {
             const bool asc = ((64 * e + lane) & k) == 0;
-            const unsigned long long a = key[e], b = key[e | je];
+            const K a = key[e], b = key[e | je];
             const bool sw = asc ? (b < a) : (a < b);
             key[e] = sw ? b : a;
             key[e | je] = sw ? a : b;
@@ -432,7 +432,7 @@ __device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], 
 #pragma unroll
         for (int e = 0; e < SL; ++e) {
           const int i = 64 * e + lane;
-          const unsigned long long o = __shfl_xor(key[e], j, 64);
+          const K o = __shfl_xor(key[e], j, 64);
           const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
           key[e] = keep_min ? (o < key[e] ? o : key[e]) : (o < key[e] ? key[e] : o);
         }
@@ -446,20 +446,48 @@ __device__ __forceinline__ void csr_bitonic_sort(unsigned long long (&key)[SL], 
 template <int SL>
 __device__ __forceinline__ int csr_row_merge(int* __restrict__ tcol, double* __restrict__ tval, int64_t base, int n, int lane,
                                              bool* bad) {
-  unsigned long long key[SL];
+  // keys (column : slot), slot < CSR_BUCKET = 2^8.  Columns below 2^24 - 1 -- every graph of fewer than 16.7 M cells -- fit a 32-bit
+  // key with the slot: the network then compares and selects single words (the kernel is bound by the vector instructions of
+  // its compare-exchanges, not by the exchanges themselves); same order, same result.  Decided per row, wave-uniformly.
+  static_assert(CSR_BUCKET <= 256, "the slot shares a 32-bit key with a 24-bit column");
+  unsigned cin[SL];
+  bool wide = false;
 #pragma unroll
   for (int e = 0; e < SL; ++e) {
     const int i = lane + 64 * e;
-    key[e] = i < n ? (((unsigned long long)(unsigned)tcol[base + i] << 32) | (unsigned)i) : ~0ull;
+    cin[e] = i < n ? (unsigned)tcol[base + i] : 0u;
+    wide |= cin[e] >= 0xFFFFFFu;
   }
-  csr_bitonic_sort<SL>(key, lane);
   double v[SL];
   unsigned c[SL];
+  if (!__any(wide)) {
+    unsigned key[SL];
 #pragma unroll
-  for (int e = 0; e < SL; ++e) {
-    const int i = lane + 64 * e;
-    c[e] = (unsigned)(key[e] >> 32);
-    v[e] = i < n ? tval[base + (unsigned)key[e]] : 0.0;
+    for (int e = 0; e < SL; ++e) {
+      const int i = lane + 64 * e;
+      key[e] = i < n ? ((cin[e] << 8) | (unsigned)i) : ~0u;
+    }
+    csr_bitonic_sort<SL>(key, lane);
+#pragma unroll
+    for (int e = 0; e < SL; ++e) {
+      const int i = lane + 64 * e;
+      c[e] = i < n ? (key[e] >> 8) : 0xffffffffu;
+      v[e] = i < n ? tval[base + (key[e] & 255u)] : 0.0;
+    }
+  } else {
+    unsigned long long key[SL];
+#pragma unroll
+    for (int e = 0; e < SL; ++e) {
+      const int i = lane + 64 * e;
+      key[e] = i < n ? (((unsigned long long)cin[e] << 32) | (unsigned)i) : ~0ull;
+    }
+    csr_bitonic_sort<SL>(key, lane);
+#pragma unroll
+    for (int e = 0; e < SL; ++e) {
+      const int i = lane + 64 * e;
+      c[e] = (unsigned)(key[e] >> 32);
+      v[e] = i < n ? tval[base + (unsigned)key[e]] : 0.0;
+    }
   }
   // neighbours in sorted order: position i - 1, i + 1, i + 2 (across the lane / slot boundary)
   int total = 0;

@@ -70,6 +70,36 @@ def test_bucket_assembly_of_a_row_slice(monkeypatch):
     assert np.array_equal(r2, r) and np.array_equal(c2, c) and np.array_equal(v2, v)
 
 
+def test_columns_beyond_24_bits_take_the_wide_keys(monkeypatch):
+    """One wave sorts a row on 32-bit (column : slot) keys when every column of the row is below 2^24 - 1 and on 64-bit keys
+    otherwise -- decided per row.  A row slice of a graph of 20 M cells: some rows hold small columns only, some large ones only,
+    most a mix; both paths against scipy and against the sort-based assembly."""
+    rng = np.random.default_rng(24)
+    N, row_begin, n_rows = 20_000_000, 1000, 3000
+    i = np.repeat(np.arange(row_begin, row_begin + n_rows), 30)
+    kind = rng.integers(0, 3, size=n_rows)[i - row_begin]  # 0: small columns, 1: beyond 2^24, 2: both
+    small = rng.integers(0, (1 << 24) - 1, size=i.shape[0])
+    large = rng.integers((1 << 24) - 1, N, size=i.shape[0])
+    j = np.where(kind == 0, small, np.where(kind == 1, large, np.where(rng.random(i.shape[0]) < 0.5, small, large)))
+    j[::7] = (1 << 24) - 1 + (j[::7] % 3) - 1  # the boundary itself: 2^24 - 2 (narrow), 2^24 - 1 and 2^24 (wide)
+    keys = (i.astype(np.int64) << 32) | j
+    keys, first = np.unique(keys, return_index=True)
+    vals = rng.random(keys.shape[0])
+    dup = rng.random(keys.shape[0]) < 0.3  # a second entry of the same (row, column), as the transposed copy of a mutual pair is
+    keys = np.concatenate([keys, keys[dup]])
+    vals = np.concatenate([vals, rng.random(int(dup.sum()))])
+    p = rng.permutation(keys.shape[0])
+    keys, vals = keys[p], vals[p]
+    rb, cb, vb = _assemble(keys, vals, row_begin, n_rows, N, "bucket", monkeypatch)
+    rs, cs, vs = _assemble(keys, vals, row_begin, n_rows, N, "sort", monkeypatch)
+    assert np.array_equal(rb, rs) and np.array_equal(cb, cs) and np.array_equal(vb, vs)
+    W = sparse.coo_matrix((vals, ((keys >> 32) - row_begin, keys & 0xFFFFFFFF)), shape=(n_rows, N)).tocsr()
+    W.sum_duplicates()
+    W.sort_indices()
+    assert np.array_equal(rb, W.indptr) and np.array_equal(cb, W.indices)
+    np.testing.assert_allclose(vb, W.data, rtol=1e-15)
+
+
 def test_long_rows_and_repeated_keys_take_the_sort_path(monkeypatch):
     """a hub row of more than 256 entries, and a key that occurs three times: the bucket path must hand over to the
     sort-based one (same result as asking for it)"""
