@@ -330,6 +330,11 @@ int meld_csr_row_sums(const int64_t* rowptr, const double* val, int64_t n_rows, 
 int meld_csr_anisotropy(const int64_t* rowptr, const int32_t* col, double* val, int64_t n_rows,
                         const double* ksum_all, int64_t ksum_row_offset, double anisotropy,
                         meld_stream_t stream);
+/* The same, and the degrees dw[r] = sum_j W_rj of the result in the same pass: equal, bit for bit, to meld_csr_row_sums(diag = 0)
+ * called afterwards (same lanes, same order). */
+int meld_csr_anisotropy_degrees(const int64_t* rowptr, const int32_t* col, double* val, int64_t n_rows,
+                                const double* ksum_all, int64_t ksum_row_offset, double anisotropy, double* dw,
+                                meld_stream_t stream);
 
 /* ---- Laplacian operator: lmax and the Chebyshev recurrence (replaces [UPSTREAM pygsp
  *      Graph.estimate_lmax] at meld/filter.py:39 and [UPSTREAM pygsp

@@ -85,6 +85,7 @@ SIGNATURES = {
     "meld_csr_compact_rows": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),
     "meld_csr_anisotropy": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr]),
+    "meld_csr_anisotropy_degrees": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr, _ptr]),
     "meld_spmm_dot_slots": (_i32, []),
     "meld_cheby_step": (
         _i32,

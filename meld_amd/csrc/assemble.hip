@@ -122,18 +122,49 @@ __global__ __launch_bounds__(256) void csr_row_sums_kernel(const int64_t* __rest
   if (r < n_rows && g == 0) out[r] = diag + s;
 }
 
+// W_ij = K_ij / (ksum_i ksum_j)^a in place; dw_out (optional): the row sums of the result, in the order csr_row_sums_kernel adds
+// them (lane g of the row's eight takes entries g, g + 8, ...; then the same three exchanges), so the separate pass over the values
+// that computed the degrees is gone without moving a bit.  Four entries per lane at a time: columns, values, then the four
+// gathers of ksum_j together -- the plain loop waited out a column load and a dependent gather per entry, five times per lane.
 __global__ __launch_bounds__(256) void csr_anisotropy_kernel(const int64_t* __restrict__ rowptr,
                                                              const int* __restrict__ col, double* __restrict__ val,
                                                              int64_t n_rows, const double* __restrict__ ksum_all,
-                                                             int64_t row_off, double anisotropy) {
+                                                             int64_t row_off, double anisotropy, double* __restrict__ dw_out) {
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int g = threadIdx.x & 7;
-  if (r >= n_rows) return;
-  const double di = ksum_all[row_off + r];
-  const int64_t b = rowptr[r], e = rowptr[r + 1];
-  for (int64_t k = b + g; k < e; k += 8) {
-    const double dd = di * ksum_all[col[k]];
-    val[k] = (anisotropy == 1.0) ? val[k] / dd : val[k] / pow(dd, anisotropy);
+  double s = 0.0;
+  if (r < n_rows) {
+    const double di = ksum_all[row_off + r];
+    const int64_t b = rowptr[r], e = rowptr[r + 1];
+    constexpr int U = 4;
+    for (int64_t k0 = b + g; k0 < e; k0 += 8 * U) {
+      int c[U];
+      double v[U], kj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t k = k0 + 8 * u;
+        c[u] = k < e ? col[k] : 0;
+        v[u] = k < e ? val[k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) kj[u] = ksum_all[c[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t k = k0 + 8 * u;
+        if (k < e) {
+          const double dd = di * kj[u];
+          const double w = (anisotropy == 1.0) ? v[u] / dd : v[u] / pow(dd, anisotropy);
+          val[k] = w;
+          s += w;
+        }
+      }
+    }
+  }
+  if (dw_out != nullptr) {  // (uniform)
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (r < n_rows && g == 0) dw_out[r] = 0.0 + s;
   }
 }
 
@@ -668,7 +699,20 @@ extern "C" int meld_csr_anisotropy(const int64_t* rowptr, const int32_t* col, do
   MELD_CHECK_ARG(rowptr && ksum_all && n_rows > 0, "meld_csr_anisotropy: bad arguments");
   if (anisotropy == 0.0) return MELD_OK;
   hipLaunchKernelGGL(csr_anisotropy_kernel, dim3((unsigned)ceil_div(n_rows * 8, 256)), dim3(256), 0, S(stream),
-                     rowptr, col, val, n_rows, ksum_all, ksum_row_offset, anisotropy);
+                     rowptr, col, val, n_rows, ksum_all, ksum_row_offset, anisotropy, (double*)nullptr);
+  MELD_LAUNCH_CHECK("csr_anisotropy_kernel");
+  return MELD_OK;
+}
+
+// The same, and the degrees dw[r] = sum_j W_rj of the result in the same pass (equal, bit for bit, to meld_csr_row_sums(diag = 0)
+// called afterwards).
+extern "C" int meld_csr_anisotropy_degrees(const int64_t* rowptr, const int32_t* col, double* val, int64_t n_rows,
+                                           const double* ksum_all, int64_t ksum_row_offset, double anisotropy, double* dw,
+                                           meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && ksum_all && dw && n_rows > 0, "meld_csr_anisotropy_degrees: bad arguments");
+  if (anisotropy == 0.0) return meld_csr_row_sums(rowptr, val, n_rows, 0.0, dw, stream);
+  hipLaunchKernelGGL(csr_anisotropy_kernel, dim3((unsigned)ceil_div(n_rows * 8, 256)), dim3(256), 0, S(stream),
+                     rowptr, col, val, n_rows, ksum_all, ksum_row_offset, anisotropy, dw);
   MELD_LAUNCH_CHECK("csr_anisotropy_kernel");
   return MELD_OK;
 }

@@ -171,8 +171,7 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
         ksum_all = torch.empty(R * comm.world, dtype=torch.float64, device=dev)
         comm.all_gather_rows(ksum_all, ksum_loc)
         if n_loc > 0:
-            ops.anisotropy(rowptr, col, val, n_loc, ksum_all, r0, anisotropy)
-            dw = ops.row_sums(rowptr, val, n_loc, 0.0)
+            dw = ops.anisotropy_degrees(rowptr, col, val, n_loc, ksum_all, r0, anisotropy)
         else:
             dw = torch.zeros(1, dtype=torch.float64, device=dev)
         tot = torch.cat([torch.tensor([int(col.shape[0]), int(info["n_flagged_rows"])], dtype=torch.int64, device=dev), over])

@@ -1017,6 +1017,14 @@ class HipOps:
     def anisotropy(self, rowptr, col, val, n_rows, ksum_all, row_off, a):
         check(self.lib.meld_csr_anisotropy(ptr(rowptr), ptr(col), ptr(val), n_rows, ptr(ksum_all), row_off, float(a), _stream()), "meld_csr_anisotropy")
 
+    def anisotropy_degrees(self, rowptr, col, val, n_rows, ksum_all, row_off, a):
+        """``anisotropy`` and the row sums of its result in one pass (``meld_csr_anisotropy_degrees``: the same bits as
+        ``row_sums(..., 0.0)`` afterwards)."""
+        dw = torch.empty(n_rows, dtype=torch.float64, device=val.device)
+        check(self.lib.meld_csr_anisotropy_degrees(ptr(rowptr), ptr(col), ptr(val), n_rows, ptr(ksum_all), row_off, float(a), ptr(dw), _stream()),
+              "meld_csr_anisotropy_degrees")
+        return dw
+
     # ---- A9 / A10: operator steps -----------------------------------------------------------------
     def dot_slots(self):
         return self.lib.meld_spmm_dot_slots()
@@ -1314,8 +1322,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     del keys, vals
     tm.stop("symmetrize")
     ksum = ops.row_sums(rowptr, val, N, 1.0)
-    ops.anisotropy(rowptr, col, val, N, ksum, 0, anisotropy)
-    dw = ops.row_sums(rowptr, val, N, 0.0)
+    dw = ops.anisotropy_degrees(rowptr, col, val, N, ksum, 0, anisotropy)
     tm.stop("anisotropy_degree")
 
     nnz = int(col.shape[0])

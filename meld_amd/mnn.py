@@ -176,8 +176,7 @@ def build_mnn_graph(X, sample_idx, knn=5, decay=40, thresh=1e-4, anisotropy=1, b
         raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
     rowptr, col, val = ops.assemble_rows(keys.contiguous(), vals, 0, N, N)
     ksum = ops.row_sums(rowptr, val, N, 1.0)
-    ops.anisotropy(rowptr, col, val, N, ksum, 0, anisotropy)
-    dw = ops.row_sums(rowptr, val, N, 0.0)
+    dw = ops.anisotropy_degrees(rowptr, col, val, N, ksum, 0, anisotropy)
     nnz = int(col.shape[0])
     info = dict(N=N, d=d, knn=int(knn), nnz=nnz, mean_degree=nnz / N, graph="mnn", n_samples=len(samples),
                 n_flagged_rows=n_flagged, search="f16x3 within and between samples")

@@ -83,6 +83,10 @@ class CpuOps:
         v = val.numpy()
         v /= (ks[row_off + rows] * ks[col.numpy()]) ** a
 
+    def anisotropy_degrees(self, rowptr, col, val, n_rows, ksum_all, row_off, a):
+        self.anisotropy(rowptr, col, val, n_rows, ksum_all, row_off, a)
+        return self.row_sums(rowptr, val, n_rows, 0.0)
+
     def dot_slots(self):
         return 4
 

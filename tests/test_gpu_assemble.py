@@ -132,3 +132,31 @@ def test_candidates_straight_into_the_buckets_build_the_same_graph(n, force, mon
     B = meld_amd.build_knn_graph(X, knn=9, force_fallback=force)
     assert torch.equal(A.rowptr, B.rowptr) and torch.equal(A.col, B.col) and torch.equal(A.val, B.val)
     assert torch.equal(A.dw_dev, B.dw_dev)
+
+
+@pytest.mark.parametrize("a", [1.0, 0.5, 0.0])
+def test_anisotropy_and_degrees_in_one_pass_equal_the_two_kernels(a):
+    """meld_csr_anisotropy_degrees = meld_csr_anisotropy followed by meld_csr_row_sums(diag = 0), bit for bit (same lanes, same
+    order of additions), on rows of every length from empty to a few hundred."""
+    from meld_amd.graph import HipOps
+
+    rng = np.random.default_rng(5)
+    n = 5000
+    lens = rng.integers(0, 60, size=n)
+    lens[::97] = 0
+    lens[5::211] = rng.integers(100, 400, size=lens[5::211].shape[0])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = rng.integers(0, n, size=int(rp[-1])).astype(np.int32)
+    val = rng.random(int(rp[-1]))
+    ops = HipOps()
+    rowptr, cols = torch.from_numpy(rp).cuda(), torch.from_numpy(col).cuda()
+    v1, v2 = torch.from_numpy(val).cuda(), torch.from_numpy(val.copy()).cuda()
+    ksum = ops.row_sums(rowptr, v1, n, 1.0)
+    ops.anisotropy(rowptr, cols, v1, n, ksum, 0, a)
+    dw1 = ops.row_sums(rowptr, v1, n, 0.0)
+    dw2 = ops.anisotropy_degrees(rowptr, cols, v2, n, ksum, 0, a)
+    torch.cuda.synchronize()
+    assert torch.equal(v1, v2) and torch.equal(dw1, dw2)
+    ks = ksum.cpu().numpy()
+    rows = np.repeat(np.arange(n), lens)
+    np.testing.assert_allclose(v2.cpu().numpy(), val / (ks[rows] * ks[col]) ** a, rtol=1e-14)
