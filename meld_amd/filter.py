@@ -277,7 +277,10 @@ class _LanczosHostSide:
 
     @classmethod
     def of(cls, dev, max_iter):
-        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        import threading
+
+        # (per thread as well: two estimates running side by side must not share the pinned buffer)
+        key = (threading.get_ident(), torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
         h = cls._per_device.get(key)
         if h is None or h.ab.shape[1] < max_iter:
             h = cls._per_device[key] = cls(dev, max_iter)
