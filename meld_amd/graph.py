@@ -804,13 +804,22 @@ class HipOps:
                 ),
                 "meld_knn_refine(stage 2)",
             )
-            n_flag_h = int(n_flag.item())
             del Q2, c2_idx, c2_d2, c2_cnt
+            n_flag_stale = True
             tm.stop("knn_stage2")
+        else:
+            n_flag_stale = False
         research = None
         Rt = None
         keep_off = _scan_i32(lib, keep_cnt, st)
-        m_main = int(keep_off[q_count].item())
+        # ONE read-back for the three scalars the host wants here (each one is an idle gap of the GPU of ~50 us: nothing is queued
+        # behind it): rows still flagged after the second stage, kept entries, (wave, tile) pairs the first pass computed
+        heads = [n_flag[0].to(torch.int64), keep_off[q_count]] + ([tiles_done[0]] if tiles_done is not None else [])
+        heads_h = torch.stack(heads).tolist()
+        if n_flag_stale:
+            n_flag_h = int(heads_h[0])
+        m_main = int(heads_h[1])
+        tiles_done_h = int(heads_h[2]) if tiles_done is not None else None
 
         # Many uncertified rows with a short candidate list (dense low-dimensional data: more than ksel cells
         # inside the radius inflated by the search-error allowance): search once more with the longest list
@@ -917,7 +926,7 @@ class HipOps:
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
-                    wave_tiles_done=int(tiles_done.item()) if tiles_done is not None else None)
+                    wave_tiles_done=tiles_done_h)
         if assembled is not None:
             info["assembled"] = assembled  # (rowptr, col, val) of the symmetrised rows: the caller skips assemble_rows
         return keys, vals, bw, info

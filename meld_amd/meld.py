@@ -241,9 +241,11 @@ class MELD(GraphEstimator):
         by_code = torch.argsort(inv, stable=True)
         first = by_code[torch.cumsum(cnt, 0) - cnt]
         ok = (t == t[first][inv]).all()
+        # (what the host reads afterwards, in one buffer: one device -> host copy instead of three)
+        packed = torch.cat([ok.reshape(1).to(torch.int64), first, cnt])
         done = torch.cuda.Event()
         done.record()
-        return dict(lab=lab, inv=inv, cnt=cnt, first=first, ok=ok, done=done, device=device)
+        return dict(lab=lab, inv=inv, cnt=cnt, first=first, ok=ok, packed=packed, done=done, device=device)
 
     @staticmethod
     def _factorize_device_end(h):
@@ -253,19 +255,21 @@ class MELD(GraphEstimator):
         cur = torch.cuda.current_stream()
         cur.wait_event(h["done"])
         lab, inv, cnt, first, device = h["lab"], h["inv"], h["cnt"], h["first"], h["device"]
-        for t in (inv, cnt, first, h["ok"]):
+        for t in (inv, cnt, first, h["ok"], h["packed"]):
             # allocated from the side stream's pool, consumed from here on by the current stream: without this the caching
             # allocator may hand their blocks to the next side-stream hook while kernels of this stream still read them
             if t.is_cuda:
                 t.record_stream(cur)
-        if not bool(h["ok"].item()):
+        packed = h["packed"].cpu().numpy()  # [ok | first occurrence of every group | group sizes]
+        n_groups = int(first.shape[0])
+        if not bool(packed[0]):
             return None  # two different labels share a key
-        uniques = lab[first.cpu().numpy()]
+        uniques = lab[packed[1 : 1 + n_groups]]
         order = np.argsort(uniques, kind="stable")  # the p uniques, ordered as np.unique does
         rank = np.empty_like(order)
         rank[order] = np.arange(order.shape[0])
         codes = torch.from_numpy(rank).to(device)[inv]
-        counts = cnt.cpu().numpy()[order]
+        counts = packed[1 + n_groups :][order]
         return codes, uniques[order], counts
 
     @staticmethod

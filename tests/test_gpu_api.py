@@ -612,8 +612,7 @@ def test_one_reduction_lanczos_equals_the_device_resident_loop(n):
 @pytest.mark.parametrize("n", [4000, 90000])  # CSR-stream kernel (its batches run out) / panel-tiled layout (stop flag)
 def test_overlapped_convergence_checks_stop_where_the_serial_loop_stops(n, monkeypatch):
     """The lmax estimate checks a batch on the host while the next one runs and voids the rest of it once a check has passed:
-    same prefix examined, same Ritz value (bit for bit -- the same tridiagonal entries reach the same solver) as the loop that
-    waits for every batch; a second estimate right behind a voided batch starts clean."""
+    same prefix examined, same Ritz value as the loop that waits for every batch; a second estimate right behind a voided batch starts clean."""
     meld = _meld()
     import torch
 
@@ -631,7 +630,8 @@ def test_overlapped_convergence_checks_stop_where_the_serial_loop_stops(n, monke
     t_again, i_again = mf._lanczos_lmax_device(G, G.ops, u, 1e-3, 300, 5)
     torch.cuda.synchronize()
     assert i_ser["iterations"] == i_ovl["iterations"] == i_again["iterations"]
-    assert t_ser == t_ovl == t_again
+    # (the partial sums of a Lanczos step are added into their slots by atomics: equal up to the order of those additions)
+    assert abs(t_ser - t_ovl) <= 1e-12 * t_ser and abs(t_again - t_ovl) <= 1e-12 * t_ser
     assert i_ovl["enqueued"] >= i_ovl["iterations"] and i_ser["enqueued"] <= i_ser["iterations"] + 4
     # a tight iteration cap: the last batch is the cap's, speculation does not run past it
     t_cap, i_cap = mf._lanczos_lmax_device(G, G.ops, u, 1e-12, 23, 5)
