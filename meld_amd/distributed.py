@@ -267,7 +267,12 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
 
         X = pca_project(X, op.n_pca, seed=42 if op.random_state is None else int(op.random_state)).contiguous()
         op.data_nu = X
+    from .graph import metric_front_end
+
+    # (cosine = the euclidean graph of the unit rows with the decay doubled: MELD._build_graph; every rank normalises all of X)
     op.X = X
+    X, decay_m, bw_to_metric = metric_front_end(X, op.distance, op.decay)
+    decay = float("inf") if decay_m is None else decay_m
     # (the label factorisation of transform starts under this rank's candidate search, as on one GPU)
     finish = op._prefactor_under_search(sample_labels, eligible=X.is_cuda) if hasattr(op, "_prefactor_under_search") else (lambda publish=True: None)
     try:
@@ -287,6 +292,7 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
         finish(publish=False)
         op._prefactored = None
         raise
+    op.graph.bandwidth_to_metric = bw_to_metric
     finish()
     try:
         return op.transform(sample_labels)

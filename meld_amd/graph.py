@@ -307,7 +307,11 @@ class DeviceGraph:
 
     @property
     def bandwidth_host(self):
-        return None if self.bandwidth is None else self._vec_host(self.bandwidth)
+        """bandwidths in the units of the graph's metric (``bandwidth`` itself is the euclidean one of the rows the search saw)"""
+        if self.bandwidth is None:
+            return None
+        to_metric = getattr(self, "bandwidth_to_metric", None)
+        return self._vec_host(self.bandwidth if to_metric is None else to_metric(self.bandwidth))
 
     @property
     def L(self):
@@ -1251,6 +1255,24 @@ class HipOps:
 
     def axpby(self, a, x, b, y, nrm2=None):
         check(self.lib.meld_axpby_f64(float(a), ptr(x), float(b), ptr(y), y.numel(), ptr(nrm2), _stream()), "meld_axpby_f64")
+
+
+def metric_front_end(X, distance, decay):
+    """The graph builders are euclidean; other metrics come in through the data.  ``distance="cosine"`` ([UPSTREAM graphtools
+    ``kNNGraph(distance=...)`` -> sklearn ``NearestNeighbors(metric="cosine")``]: d(x, y) = 1 - x.y / (|x| |y|)): on unit rows
+    d_cos = |x^ - y^|^2 / 2, so the neighbours are those of the euclidean search on the normalised rows, and since the kernel sees
+    distances only as the ratio d / bandwidth, d_cos / bw_cos = (d_euc / bw_euc)^2:  exp(-(d_cos / bw_cos)^decay) =
+    exp(-(d_euc / bw_euc)^(2 decay)) -- the euclidean graph of the normalised rows with the decay doubled, entry for entry (the
+    oracle, which hands the metric to sklearn, agrees to 1e-14: tests/test_oracle.py).  Returns (X', decay', to_metric) where
+    to_metric maps a euclidean bandwidth of X' to the metric's own units."""
+    if distance == "euclidean":
+        return X, decay, None
+    if distance != "cosine":
+        raise NotImplementedError("distance {!r} is not implemented by the MI355X graph builder (euclidean, cosine)".format(distance))
+    nrm = torch.linalg.vector_norm(X, dim=1, keepdim=True)
+    if bool((nrm == 0).any()):
+        raise ValueError("cosine distance is undefined for all-zero rows")
+    return (X / nrm).contiguous(), (None if decay is None else 2 * decay), (lambda bw: 0.5 * bw * bw)
 
 
 def _exact_bandwidth(X, rows, knn, n_refs=None):

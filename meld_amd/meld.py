@@ -155,25 +155,34 @@ class MELD(GraphEstimator):
             self._log("Calculating PCA ({} components)...".format(self.n_pca))
             X = pca_project(X, self.n_pca, seed=42 if self.random_state is None else int(self.random_state))
             self.data_nu = X
+        from .graph import metric_front_end
+
+        # (the metric enters through the data: cosine = the euclidean graph of the unit rows with the decay doubled)
+        X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
         if opts.get("sample_idx") is not None:
             # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
             if self.thresh == 0:
                 raise NotImplementedError("sample_idx (MNN graph) with thresh=0 is not implemented")
             from .mnn import build_mnn_graph
 
-            return build_mnn_graph(
-                X, opts["sample_idx"], knn=self.knn, decay=float("inf") if self.decay is None else self.decay,
+            G = build_mnn_graph(
+                X, opts["sample_idx"], knn=self.knn, decay=float("inf") if decay_m is None else decay_m,
                 thresh=self.thresh, anisotropy=self.anisotropy, ksel=opts.get("ksel"),
             )
+            G.bandwidth_to_metric = bw_to_metric
+            return G
         if self.thresh == 0:
             from .dense import build_dense_graph
 
-            return build_dense_graph(X, knn=self.knn, decay=self.decay, anisotropy=self.anisotropy)
+            G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy)
+            G.bandwidth_to_metric = bw_to_metric
+            return G
         G = build_knn_graph(
-            X, knn=self.knn, decay=float("inf") if self.decay is None else self.decay,  # None: unweighted kNN graph
+            X, knn=self.knn, decay=float("inf") if decay_m is None else decay_m,  # None: unweighted kNN graph
             thresh=self.thresh, anisotropy=self.anisotropy,
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)),
         )
+        G.bandwidth_to_metric = bw_to_metric
         # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the
         # same kernel, weights and Laplacian as the plain kNN graph -- the landmark operator is a lazily built extra
         # (`landmark_op`, `transitions`, `interpolate`) that MELD's filter never touches -- so the densities do not

@@ -72,8 +72,12 @@ def knn_kernel(
     n_jobs=1,
     algorithm="ball_tree",
     return_intermediates=False,
+    distance="euclidean",
 ):
     """Directed alpha-decay kernel K (CSR, N x N, includes K_ii = 1).
+
+    ``distance``: the metric handed to sklearn's ``NearestNeighbors`` ([UPSTREAM graphtools ``kNNGraph.knn_tree``: the ball tree
+    with ``metric=self.distance``, ``algorithm="auto"`` when the tree does not take that metric -- "cosine" is brute force]).
 
     [UPSTREAM graphtools 1.5.x ``kNNGraph.build_kernel`` -> ``build_kernel_to_data(Y=data,
     knn=self.knn + 1)``], reached from reference ``meld/meld.py:273`` (``self.fit``) with the
@@ -101,7 +105,7 @@ def knn_kernel(
         knn = N - 2  # [UPSTREAM kNNGraph.__init__] (warns upstream)
     k1 = knn + 1
     knn_max = N
-    tree = NearestNeighbors(n_neighbors=k1, algorithm=algorithm, metric="euclidean", n_jobs=n_jobs).fit(X)
+    tree = NearestNeighbors(n_neighbors=k1, algorithm=algorithm if distance == "euclidean" else "auto", metric=distance, n_jobs=n_jobs).fit(X)
     if decay is None or thresh == 1:
         # [UPSTREAM graphtools kNNGraph.build_kernel_to_data]: without alpha decay the kernel is the binary
         # connectivity of the knn + 1 nearest neighbours, self included ("unweighted kNN graph")
@@ -133,7 +137,7 @@ def knn_kernel(
         update_idx = update_idx[keep]
         search_knn = min(search_knn * search_multiplier, knn_max)
     if search_knn > N / 2:
-        tree = NearestNeighbors(n_neighbors=search_knn, algorithm="brute", n_jobs=n_jobs).fit(X)
+        tree = NearestNeighbors(n_neighbors=search_knn, algorithm="brute", metric=distance, n_jobs=n_jobs).fit(X)
     if len(update_idx) > 0:
         if search_knn == knn_max:
             dist_new, ind_new = tree.kneighbors(X[update_idx], n_neighbors=search_knn)
@@ -473,12 +477,14 @@ def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, 
     return K
 
 
-def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None):
+def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean"):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
     ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
     ``pca_reduce`` first.  ``sample_idx``: the MNN kernel between samples (``mnn_kernel``)."""
     if n_pca is not None:
         X = pca_reduce(X, n_pca)
+    if distance != "euclidean" and (sample_idx is not None or thresh == 0):
+        raise NotImplementedError("the oracle restates non-euclidean distances for the kNN graph only")
     if sample_idx is not None:
         Kd = mnn_kernel(X, sample_idx, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm)
         K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
@@ -492,7 +498,7 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         W = weights_from_kernel(K)
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
-    Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True)
+    Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True, distance=distance)
     K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
     K.sort_indices()
     W = weights_from_kernel(K)
@@ -535,11 +541,12 @@ def fit_transform(
     algorithm="ball_tree",
     lmax=None,
     return_graph=False,
+    distance="euclidean",
 ):
     """``meld.MELD(**params).fit_transform(X, sample_labels)`` -- reference
     ``meld/meld.py:252-274`` with the constructor defaults of ``meld/meld.py:94-107`` and the
     graphtools defaults knn=5, decay=40, thresh=1e-4 [UPSTREAM GraphEstimator]."""
-    G = build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=anisotropy, n_jobs=n_jobs, algorithm=algorithm)
+    G = build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=anisotropy, n_jobs=n_jobs, algorithm=algorithm, distance=distance)
     samples, ind = sample_indicators(sample_labels, sample_normalize)
     dens = meld_filter(ind, G, filter=filter, beta=beta, offset=offset, order=order, solver=solver, chebyshev_order=chebyshev_order, lmax=lmax)
     if return_graph:

@@ -22,7 +22,8 @@ def main(out_path, n, d, knn, n_labels, n_pca=0):
     if n_labels == 3:
         labels = np.random.default_rng(1).choice(["A", "B", "C"], size=n)
     mode = os.environ.get("MELD_TEST_MODE", "")
-    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None, decay=None if mode == "unweighted" else 40)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, n_pca=n_pca or None, decay=None if mode == "unweighted" else 40,
+                       distance="cosine" if mode == "cosine" else "euclidean")
     if mode == "replicated":
         # a graph every rank holds in full (here: the oracle's, uploaded like a graph built elsewhere), rows sharded for the
         # recurrences only (meld_amd.distributed.shard_of_graph)

@@ -99,15 +99,17 @@ def test_exchange_overflow_falls_back_to_the_variable_length_exchange(tmp_path):
         assert np.abs(r["dens"] - ref).max() / np.abs(ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("mode", ["unweighted", "replicated"])
+@pytest.mark.parametrize("mode", ["unweighted", "replicated", "cosine"])
 def test_sharded_breadth_unweighted_graph_and_replicated_build(mode, tmp_path):
     """(a) decay=None (graphtools' unweighted kNN graph, forwarded at reference meld/meld.py:106,118) on the row-sharded
     builder; (b) a graph every rank holds in full -- the route of the MNN graph (sample_idx) and of graphs built elsewhere --
-    sharded for the recurrences only (shard_of_graph).  3 ranks, ragged tail; graph and densities against the oracle."""
+    sharded for the recurrences only (shard_of_graph); (c) distance="cosine" (the metric enters through the data on every rank:
+    graph.metric_front_end).  3 ranks, ragged tail; graph and densities against the oracle."""
     n, d, knn, world = 700, 8, 7, 3
     ranks = _run(world, tmp_path, n, d, knn, 2, extra_env=dict(MELD_TEST_MODE=mode))
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
-    G = mo.build_graph(X, knn=knn, algorithm="brute", decay=None if mode == "unweighted" else 40)
+    G = mo.build_graph(X, knn=knn, algorithm="brute", decay=None if mode == "unweighted" else 40,
+                       distance="cosine" if mode == "cosine" else "euclidean")
     W = sparse.vstack([
         sparse.csr_matrix((r["val"], r["col"], r["rowptr"][: int(r["n_rows"]) + 1]), shape=(int(r["n_rows"]), n)) for r in ranks
     ]).tocsr()

@@ -216,7 +216,50 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
-        meld.MELD(distance="cosine")
+        meld.MELD(distance="manhattan")  # (euclidean and cosine are built)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decay,thresh,n", [(40, 1e-4, 6000), (None, 1e-4, 3000), (10, 0, 700)])
+def test_cosine_distance_matches_the_oracle(decay, thresh, n):
+    """distance="cosine" ([UPSTREAM graphtools kNNGraph(distance=...)] -> sklearn's cosine metric): the oracle hands the metric to
+    sklearn, the product builds the euclidean graph of the unit rows with the decay doubled (graph.metric_front_end).  Same
+    pattern, weights and densities; bandwidths are reported in cosine units; all-zero rows are refused."""
+    from scipy import sparse
+
+    meld = _meld()
+    mo = _oracle()
+    rng = np.random.default_rng(n)
+    X = rng.normal(size=(n, 12)) * rng.uniform(0.2, 5.0, size=(n, 1)) + 1.5  # rows of very different lengths
+    labels = np.where(rng.random(n) < 0.4, "a", "b")
+    op = meld.MELD(knn=7, decay=decay, thresh=thresh, distance="cosine", n_pca=None, verbose=0)
+    dens = op.fit_transform(X, labels)
+    if thresh == 0:
+        from scipy.spatial.distance import pdist, squareform
+
+        D = squareform(pdist(X, metric="cosine"))
+        bw = np.sort(D, axis=1)[:, 7]
+        Kd = np.exp(-((D / bw[:, None]) ** decay))
+        K = 0.5 * (Kd + Kd.T)
+        ks = K.sum(axis=1)
+        W = K / np.outer(ks, ks)
+        np.fill_diagonal(W, 0.0)
+        got = op.graph.W.toarray()
+        np.testing.assert_allclose(got, W, rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(op.graph.bandwidth_host, bw, rtol=1e-10)
+        return
+    G = mo.build_graph(X, knn=7, decay=decay, thresh=thresh, distance="cosine")
+    A, B = sparse.csr_matrix(op.graph.W), sparse.csr_matrix(G.W)
+    A.sort_indices(); B.sort_indices()
+    assert A.nnz == B.nnz and np.array_equal(A.indices, B.indices)
+    np.testing.assert_allclose(A.data, B.data, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.bandwidth_host, G.info["bandwidth"], rtol=1e-10)
+    samples, ref = mo.fit_transform(X, labels, knn=7, decay=decay, thresh=thresh, distance="cosine", lmax=op.graph.lmax)
+    np.testing.assert_allclose(dens.values, ref, rtol=1e-7)
+    Xz = X.copy()
+    Xz[5] = 0.0
+    with pytest.raises(ValueError):
+        meld.MELD(distance="cosine", n_pca=None, verbose=0).fit(Xz)
 
 
 @pytest.mark.gpu
