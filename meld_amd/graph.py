@@ -1264,15 +1264,23 @@ def metric_front_end(X, distance, decay):
     distances only as the ratio d / bandwidth, d_cos / bw_cos = (d_euc / bw_euc)^2:  exp(-(d_cos / bw_cos)^decay) =
     exp(-(d_euc / bw_euc)^(2 decay)) -- the euclidean graph of the normalised rows with the decay doubled, entry for entry (the
     oracle, which hands the metric to sklearn, agrees to 1e-14: tests/test_oracle.py).  Returns (X', decay', to_metric) where
-    to_metric maps a euclidean bandwidth of X' to the metric's own units."""
-    if distance == "euclidean":
+    to_metric maps a euclidean bandwidth of X' to the metric's own units.
+    The same argument covers "sqeuclidean" (d = d_euc^2: the decay doubled, the rows as they are) and "correlation" (the cosine
+    distance of the rows with their own means removed); "l2" is euclidean."""
+    if distance in ("euclidean", "l2"):
         return X, decay, None
-    if distance != "cosine":
-        raise NotImplementedError("distance {!r} is not implemented by the MI355X graph builder (euclidean, cosine)".format(distance))
+    decay2 = None if decay is None else 2 * decay
+    if distance == "sqeuclidean":
+        return X, decay2, (lambda bw: bw * bw)
+    if distance not in ("cosine", "correlation"):
+        raise NotImplementedError(
+            "distance {!r} is not implemented by the MI355X graph builder (euclidean, l2, sqeuclidean, cosine, correlation)".format(distance))
+    if distance == "correlation":
+        X = X - X.mean(dim=1, keepdim=True)
     nrm = torch.linalg.vector_norm(X, dim=1, keepdim=True)
     if bool((nrm == 0).any()):
-        raise ValueError("cosine distance is undefined for all-zero rows")
-    return (X / nrm).contiguous(), (None if decay is None else 2 * decay), (lambda bw: 0.5 * bw * bw)
+        raise ValueError("{} distance is undefined for {} rows".format(distance, "all-zero" if distance == "cosine" else "constant"))
+    return (X / nrm).contiguous(), decay2, (lambda bw: 0.5 * bw * bw)
 
 
 def _exact_bandwidth(X, rows, knn, n_refs=None):

@@ -220,6 +220,27 @@ def test_unsupported_options_fail_loudly():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["correlation", "sqeuclidean", "l2"])
+def test_other_reducible_metrics_match_the_oracle(metric):
+    """correlation = cosine of the rows with their means removed, sqeuclidean = euclidean with the decay doubled, l2 = euclidean:
+    each against the oracle, which hands the metric to sklearn."""
+    from scipy import sparse
+
+    meld = _meld()
+    mo = _oracle()
+    rng = np.random.default_rng(17)
+    n = 4000
+    X = rng.normal(size=(n, 10)) * rng.uniform(0.5, 3.0, size=(n, 1)) + rng.normal(size=(n, 1))
+    op = meld.MELD(knn=6, decay=20, distance=metric, n_pca=None, verbose=0).fit(X)
+    G = mo.build_graph(X, knn=6, decay=20, distance=metric)
+    A, B = sparse.csr_matrix(op.graph.W), sparse.csr_matrix(G.W)
+    A.sort_indices(); B.sort_indices()
+    assert A.nnz == B.nnz and np.array_equal(A.indices, B.indices)
+    np.testing.assert_allclose(A.data, B.data, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.bandwidth_host, G.info["bandwidth"], rtol=1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("decay,thresh,n", [(40, 1e-4, 6000), (None, 1e-4, 3000), (10, 0, 700)])
 def test_cosine_distance_matches_the_oracle(decay, thresh, n):
     """distance="cosine" ([UPSTREAM graphtools kNNGraph(distance=...)] -> sklearn's cosine metric): the oracle hands the metric to
