@@ -1,0 +1,45 @@
+"""How many iterations a BLOCK Lanczos recurrence (block size b) needs for the lmax estimate, against the single-vector one:
+python tools/block_lanczos_probe.py [N] [b]   (plain torch arithmetic, sparse matmul of the library: an iteration count, not a timing)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import meld_amd
+from meld_amd.filter import lanczos_lmax
+from bench import synthetic_cells
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+X, _ = synthetic_cells(N, 50, seed=0)
+G = meld_amd.MELD(knn=15, verbose=0).fit(torch.from_numpy(X).cuda()).graph
+ref, info = lanczos_lmax(G, tol=1e-9, max_iter=400)
+th, inf1 = lanczos_lmax(G, tol=1e-3)
+print("N=%d: reference %.12g (%d its); single vector, residual 1e-3: %d iterations, rel.err %.2e" % (N, ref, info["iterations"], inf1["iterations"], abs(th - ref) / ref))
+n = G.N
+W = torch.sparse_csr_tensor(G.rowptr[: n + 1], G.col.long(), G.val, size=(n, n))
+dw = G.dw_dev[:n]
+def L(V): return dw[:, None] * V - torch.sparse.mm(W, V)
+idx = torch.arange(n, dtype=torch.float64, device="cuda")
+V = torch.stack([torch.frac(torch.sin(idx * 12.9898 + 1.0 + 7.7 * j) * 43758.5453) - 0.5 for j in range(b)], dim=1)
+V, _ = torch.linalg.qr(V)
+Vp = torch.zeros_like(V); Bp = torch.zeros(b, b, dtype=torch.float64, device="cuda")
+As, Bs = [], []
+for k in range(1, 121):
+    Wk = L(V) - Vp @ Bp.T
+    A = V.T @ Wk
+    Wk = Wk - V @ A
+    Vn, B = torch.linalg.qr(Wk)
+    As.append(A.cpu().numpy()); Bs.append(B.cpu().numpy())
+    Vp, Bp, V = V, B, Vn
+    if k % 5 == 0:
+        m = b * k
+        T = np.zeros((m, m))
+        for i in range(k):
+            T[b * i : b * i + b, b * i : b * i + b] = 0.5 * (As[i] + As[i].T)
+            if i + 1 < k:
+                T[b * (i + 1) : b * (i + 2), b * i : b * i + b] = Bs[i]
+                T[b * i : b * i + b, b * (i + 1) : b * (i + 2)] = Bs[i].T
+        ev, evec = np.linalg.eigh(T)
+        theta = ev[-1]
+        resid = np.linalg.norm(Bs[k - 1] @ evec[-b:, -1]) / theta
+        print("  block %d, iteration %3d (%3d products): theta rel.err %.2e  residual %.2e" % (b, k, b * k, abs(theta - ref) / ref, resid))
+        if resid < 1e-4:
+            break
