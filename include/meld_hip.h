@@ -255,6 +255,11 @@ int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, co
                           int32_t n_flag, const double* bw, int knn, double decay, double thresh,
                           int mode, int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor,
                           int32_t* fb_col, double* fb_val, int32_t* err_flag, meld_stream_t stream);
+/* out[i][c] = |X[rows[i]] - X[cand[i][c]]| (rows, cand: global row numbers; cand [n][kk]) in the summation order of meld_knn_refine
+ * and meld_knn_radius_exact: a bandwidth ranked from these is one the sweep confirms (it counts the references strictly closer
+ * in this arithmetic; a library norm differs by a few ulps at d ~ 50). */
+int meld_knn_pair_distances(const double* X, int d, const int64_t* rows, const int64_t* cand, int64_t n, int kk, double* out,
+                            meld_stream_t stream);
 
 /* ---- symmetrise / anisotropy / Laplacian pieces (replaces [UPSTREAM graphtools
  *      BaseGraph.symmetrize_kernel, apply_anisotropy, PyGSPGraph._build_weight_from_kernel;

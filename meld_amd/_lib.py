@@ -66,6 +66,7 @@ SIGNATURES = {
         _i32,
         [_ptr, _i64, _i32, _i64, _ptr, _i32, _ptr, _i32, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     ),
+    "meld_knn_pair_distances": (_i32, [_ptr, _i32, _ptr, _ptr, _i64, _i32, _ptr, _ptr]),
     "meld_scan_temp_bytes": (_sz, [_i64]),
     "meld_exclusive_scan_i32_i64": (_i32, [_ptr, _ptr, _i64, _ptr, _sz, _ptr]),
     "meld_coo_emit": (

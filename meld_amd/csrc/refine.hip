@@ -304,6 +304,25 @@ __global__ void radius_check_kernel(int* __restrict__ lt_then_cursor, int n_flag
   lt_then_cursor[f] = 0;
 }
 
+// Distances of given (row, reference) pairs in the arithmetic of refine_kernel and radius_exact_kernel (even / odd coordinate
+// chains of FMAs, their sum, the square root): what the caller ranks to recompute a bandwidth the sweep will then CONFIRM -- the
+// sweep counts the references strictly closer than the bandwidth in this very arithmetic, and a bandwidth taken from a library
+// norm differs from it by a few ulps at d ~ 50 (the row was flagged again: "could not settle the bandwidth").
+__global__ __launch_bounds__(256) void pair_distances_kernel(const double* __restrict__ X, int d, const int64_t* __restrict__ rows,
+                                                             const int64_t* __restrict__ cand, int64_t n, int kk,
+                                                             double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * kk) return;
+  const double* xq = X + rows[e / kk] * d;
+  const double* xr = X + cand[e] * d;
+  double s = 0.0, s1 = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double t = xq[k] - xr[k];
+    if ((k & 1) == 0) s = fma(t, t, s); else s1 = fma(t, t, s1);
+  }
+  out[e] = sqrt(s + s1);
+}
+
 }  // namespace meld
 
 using namespace meld;
@@ -360,5 +379,15 @@ extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t 
     hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, st, fb_cursor, n_flag, knn,
                        err_flag, flag_rows, bw, fb_cnt);
   MELD_LAUNCH_CHECK("radius_exact_kernel");
+  return MELD_OK;
+}
+
+// out[i][c] = |X[rows[i]] - X[cand[i][c]]| in the summation order of meld_knn_refine / meld_knn_radius_exact (see the kernel).
+extern "C" int meld_knn_pair_distances(const double* X, int d, const int64_t* rows, const int64_t* cand, int64_t n, int kk, double* out,
+                                       meld_stream_t stream) {
+  MELD_CHECK_ARG(X && rows && cand && out && d > 0 && n >= 0 && kk > 0, "meld_knn_pair_distances: bad arguments");
+  if (n == 0) return MELD_OK;
+  hipLaunchKernelGGL(pair_distances_kernel, dim3((unsigned)ceil_div(n * kk, 256)), dim3(256), 0, S(stream), X, d, rows, cand, n, kk, out);
+  MELD_LAUNCH_CHECK("pair_distances_kernel");
   return MELD_OK;
 }

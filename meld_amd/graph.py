@@ -1296,14 +1296,15 @@ def _exact_bandwidth(X, rows, knn, n_refs=None):
         r = rows[lo : lo + 256]
         Xq = X[r]
         d2 = (Xq * Xq).sum(1)[:, None] + n2[None, :] - 2.0 * (Xq @ Xr.T)
-        cand = torch.topk(d2, kk, dim=1, largest=False).indices
-        dist = torch.linalg.vector_norm(Xr[cand] - Xq[:, None, :], dim=2)
+        cand = torch.topk(d2, kk, dim=1, largest=False).indices.contiguous()
+        # the candidates' distances in the SWEEP's arithmetic (meld_knn_pair_distances: even / odd FMA chains): the sweep counts
+        # the references strictly closer than the bandwidth with its own summation order, and confirms a bandwidth ranked from
+        # these by construction.  (A library norm, two ulps down, was flagged again at d = 52: "could not settle".)
+        dist = torch.empty(cand.shape, dtype=torch.float64, device=X.device)
+        r64 = r.to(torch.int64).contiguous()
+        check(get_lib().meld_knn_pair_distances(ptr(X), int(X.shape[1]), ptr(r64), ptr(cand), int(r64.shape[0]), kk, ptr(dist), _stream()),
+              "meld_knn_pair_distances")
         out[lo : lo + 256] = torch.sort(dist, dim=1).values[:, min(knn, kk - 1)]
-    # Two ulps down: the sweep counts the references STRICTLY closer than the bandwidth with its own summation order
-    # (even / odd FMA chains); a value that this routine rounds one ulp above the sweep's would count the bandwidth
-    # entry itself and flag the row again (seen on 11 % of 150k such rows).  4e-16 relative, 1.6e-14 on a kernel value.
-    zero = torch.zeros_like(out)
-    out = torch.nextafter(torch.nextafter(out, zero), zero)
     return out.clamp_(min=float(np.finfo(np.float64).eps))
 
 

@@ -97,6 +97,20 @@ def test_clusters_of_very_different_scale_settle_through_the_exact_bandwidth():
     assert DG.info["n_flagged_rows"] >= 1000 and DG.info["n_rows_bandwidth_recomputed"] > 0
 
 
+@pytest.mark.parametrize("seed", [4, 6])  # (two of the three seeds below 11 on which the library-norm routine gave up)
+def test_recomputed_bandwidths_are_ranked_in_the_sweeps_own_arithmetic(seed):
+    """The same situation in 52 dimensions (a fuzz case of round 4: tools/fuzz_graph.py 120 2026, case 14).  A bandwidth taken from a
+    library norm differs from the sweep's own value of that distance by a few ulps at this width -- more than the two ulps the
+    routine used to step down -- and the sweep then counts the bandwidth entry itself as "strictly closer", flags the row again and
+    the build gave up ("could not settle the bandwidth").  The candidates' distances now come from meld_knn_pair_distances, the
+    sweep's summation order: confirmed by construction."""
+    rng = np.random.default_rng(seed)
+    N, d = 6000, 52
+    X = np.concatenate([rng.normal(size=(N // 2, d)) * 1e-3, rng.normal(size=(N - N // 2, d)) * 3 + 20])
+    DG, G = _check_graph(X, knn=6, decay=10, thresh=1e-2, rtol=1e-9, algorithm="ball_tree")
+    assert DG.info["n_rows_bandwidth_recomputed"] > 100
+
+
 @pytest.mark.parametrize("knn", [1, 2, 30, 60])
 def test_knn_range(knn):
     rng = np.random.default_rng(knn)

@@ -24,6 +24,8 @@ for c in range(n_cases):
     else: X = rng.standard_t(2.0, size=(N, d))
     knn = min(knn, N - 2)
     tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g" % (kind, N, d, knn, decay, thresh, aniso)
+    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:  # (the generator has been advanced as the full run does)
+        continue
     try:
         G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree")
         DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso)
