@@ -12,7 +12,7 @@ kinds = ["gauss", "clusters", "duplicates", "grid", "multiscale", "line", "heavy
 bad = 0
 for c in range(n_cases):
     kind = kinds[rng.integers(len(kinds))]
-    N = int(rng.integers(300, 20000)); d = int(rng.integers(1, 60)); knn = int(rng.integers(1, 25))
+    N = int(rng.integers(300, int(os.environ.get("FUZZ_N_MAX", "20000")))); d = int(rng.integers(int(os.environ.get("FUZZ_D_MIN", "1")), int(os.environ.get("FUZZ_D_MAX", "60")))); knn = int(rng.integers(int(os.environ.get("FUZZ_KNN_MIN", "1")), int(os.environ.get("FUZZ_KNN_MAX", "25"))))
     decay = float(rng.choice([2, 10, 40, 100])); thresh = float(rng.choice([1e-2, 1e-4, 1e-6])); aniso = float(rng.choice([0, 1]))
     if kind == "gauss": X = rng.normal(size=(N, d))
     elif kind == "clusters": X = rng.normal(size=(N, d)) * 0.3 + rng.normal(size=(8, d))[rng.integers(0, 8, N)] * 4
@@ -25,6 +25,18 @@ for c in range(n_cases):
     knn = min(knn, N - 2)
     tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g" % (kind, N, d, knn, decay, thresh, aniso)
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:  # (the generator has been advanced as the full run does)
+        continue
+    if os.environ.get("FUZZ_NO_ORACLE"):  # product only: does it build, is W symmetric and finite (hundreds of cases a minute)
+        try:
+            DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso)
+            A = sparse.csr_matrix(DG.W)
+            asym = abs(A - A.T).max() if A.nnz else 0.0
+            okv = np.isfinite(A.data).all() and asym <= 1e-15 * max(abs(A.data).max(), 1e-300) * 4
+            bad += not okv
+            print("ok  " if okv else "BAD ", tag, "nnz %d asym %.1e flagged %d rebw %d" % (A.nnz, asym, DG.info["n_flagged_rows"], DG.info["n_rows_bandwidth_recomputed"]), flush=True)
+        except Exception as e:
+            bad += 1
+            print("EXC ", tag, type(e).__name__, str(e)[:120], flush=True)
         continue
     try:
         G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree")
