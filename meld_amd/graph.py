@@ -879,6 +879,13 @@ class HipOps:
                 n_rebandwidth = int(bad.shape[0])
             fb_off = _scan_i32(lib, fb_cnt, st)
             fb_total = int(fb_off[n_flag_h].item())
+            # (a radius that covers most of the data -- small decay with a small thresh -- makes the graph effectively dense: say so
+            # instead of failing inside an allocation; the reference's scipy matrices would be as large)
+            need = 12 * fb_total + 32 * (m_main + fb_total)
+            if need > torch.cuda.get_device_properties(dev).total_memory:
+                raise MemoryError(
+                    "the kernel radius covers {:.3g} neighbours per cell on average: the graph would hold {:.3g} entries ({:.0f} GB to "
+                    "assemble) -- raise decay or thresh".format((m_main + fb_total) / max(q_count, 1), float(m_main + fb_total), need / 1e9))
             fb_col = torch.empty(max(fb_total, 1), dtype=torch.int32, device=dev)
             fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
             check(  # (the count pass left the cursors at zero)

@@ -218,3 +218,14 @@ def test_more_exact_duplicates_than_the_candidate_list_holds():
     X = np.concatenate([base, np.repeat(base[:1], 45, axis=0), np.repeat(base[1:2], 70, axis=0)])
     DG, G = _check_graph(X, knn=5)
     assert np.isfinite(DG.dw).all() and DG.info["n_flagged_rows"] >= 115
+
+
+def test_a_radius_that_covers_the_data_is_refused_with_an_explanation():
+    """decay = 2 with thresh = 1e-6: the kernel radius is 3.7 bandwidths and in a gaussian blob covers nearly every cell -- at 150k
+    cells the graph itself would be 330 GB.  The builder says so (MemoryError) instead of dying inside an allocation."""
+    import meld_amd
+
+    rng = np.random.default_rng(3)
+    X = torch.from_numpy(rng.normal(size=(150_000, 12))).cuda()
+    with pytest.raises(MemoryError, match="raise decay or thresh"):
+        meld_amd.build_knn_graph(X, knn=18, decay=2, thresh=1e-6)

@@ -12,7 +12,7 @@ kinds = ["gauss", "clusters", "duplicates", "grid", "multiscale", "line", "heavy
 bad = 0
 for c in range(n_cases):
     kind = kinds[rng.integers(len(kinds))]
-    N = int(rng.integers(300, int(os.environ.get("FUZZ_N_MAX", "20000")))); d = int(rng.integers(int(os.environ.get("FUZZ_D_MIN", "1")), int(os.environ.get("FUZZ_D_MAX", "60")))); knn = int(rng.integers(int(os.environ.get("FUZZ_KNN_MIN", "1")), int(os.environ.get("FUZZ_KNN_MAX", "25"))))
+    N = int(rng.integers(int(os.environ.get("FUZZ_N_MIN", "300")), int(os.environ.get("FUZZ_N_MAX", "20000")))); d = int(rng.integers(int(os.environ.get("FUZZ_D_MIN", "1")), int(os.environ.get("FUZZ_D_MAX", "60")))); knn = int(rng.integers(int(os.environ.get("FUZZ_KNN_MIN", "1")), int(os.environ.get("FUZZ_KNN_MAX", "25"))))
     decay = float(rng.choice([2, 10, 40, 100])); thresh = float(rng.choice([1e-2, 1e-4, 1e-6])); aniso = float(rng.choice([0, 1]))
     if kind == "gauss": X = rng.normal(size=(N, d))
     elif kind == "clusters": X = rng.normal(size=(N, d)) * 0.3 + rng.normal(size=(8, d))[rng.integers(0, 8, N)] * 4
