@@ -326,6 +326,9 @@ int meld_csr_rows_sort_merge(const int32_t* cursor, int64_t n_rows, int32_t* tco
                              int32_t* flags, meld_stream_t stream);
 int meld_csr_compact_rows(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval,
                           int32_t* col, double* val, meld_stream_t stream);
+/* The same, and sums[r] = diag + the row's sum on the way out: bit for bit what meld_csr_row_sums returns for the compacted rows. */
+int meld_csr_compact_rows_sums(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval, int32_t* col,
+                               double* val, double diag, double* sums, meld_stream_t stream);
 
 /* ksum[i] = diag + sum_j val[i,j]   (row sums of the symmetrised kernel; diag = K_ii = 1) */
 int meld_csr_row_sums(const int64_t* rowptr, const double* val, int64_t n_rows, double diag,
@@ -509,6 +512,8 @@ int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, 
  * starting at the row with the smallest first coordinate: rank[g][i] = position of row i along the chain
  * (orders the centroids of the locality permutation so that consecutive groups are close in space). */
 int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream);
+/* out[i][:] = X[perm[i]][:] (rows of d doubles; out must not alias X): the cells brought into the device order. */
+int meld_gather_rows_f64(const double* X, const int64_t* perm, int64_t N, int d, double* out, meld_stream_t stream);
 /* Glue of the ordering levels, one launch each (meld_amd/reorder.py): stable argsort of 32-bit keys below 2^end_bit
  * (order[i] = index of the i-th smallest key; keys_sorted alongside); starts[g] = first position of key g among the sorted
  * keys, g = 0 .. n_groups; cents[(g f + c) d ..] = the cell at fraction (c + 1/2) / f of group g's sorted members;

@@ -84,6 +84,7 @@ SIGNATURES = {
     "meld_coo_partition_remote": (_i32, [_ptr, _ptr, _i64, _i64, _i32, _i32, _i64, _ptr, _ptr, _ptr]),
     "meld_csr_rows_sort_merge": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_compact_rows": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_csr_compact_rows_sums": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _f64, _ptr, _ptr]),
     "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),
     "meld_csr_anisotropy": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr]),
     "meld_csr_anisotropy_degrees": (_i32, [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _f64, _ptr, _ptr]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "meld_normalize_rows_l1": (_i32, [_ptr, _ptr, _i64, _i32, _ptr]),
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
+    "meld_gather_rows_f64": (_i32, [_ptr, _ptr, _i64, _i32, _ptr, _ptr]),
     "meld_argsort_u32_temp_bytes": (_sz, [_i64]),
     "meld_argsort_u32": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _sz, _ptr]),
     "meld_order_starts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),

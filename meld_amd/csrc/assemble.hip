@@ -615,6 +615,32 @@ __global__ __launch_bounds__(256) void csr_compact_rows_kernel(const int64_t* __
   }
 }
 
+// The same copy with the rows' sums on the way out: 8 lanes per row taking entries g, g + 8, ... and the three exchanges of
+// csr_row_sums_kernel, so sums[r] = diag + sum equals what meld_csr_row_sums returns for the compacted rows, bit for bit, and the
+// pass over the values that computed the kernel's row sums is gone.
+__global__ __launch_bounds__(256) void csr_compact_rows_sums_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows,
+                                                                    const int* __restrict__ tcol, const double* __restrict__ tval,
+                                                                    int* __restrict__ col, double* __restrict__ val, double diag,
+                                                                    double* __restrict__ sums) {
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int g = threadIdx.x & 7;
+  double s = 0.0;
+  if (r < n_rows) {
+    const int64_t src = r * CSR_BUCKET, dst = rowptr[r];
+    const int len = (int)(rowptr[r + 1] - dst);
+    for (int k = g; k < len; k += 8) {
+      const double v = tval[src + k];
+      col[dst + k] = tcol[src + k];
+      val[dst + k] = v;
+      s += v;
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (r < n_rows && g == 0) sums[r] = diag + s;
+}
+
 extern "C" int meld_csr_bucket_slots(void) { return CSR_BUCKET; }
 
 extern "C" int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
@@ -681,6 +707,15 @@ extern "C" int meld_csr_compact_rows(const int64_t* rowptr, int64_t n_rows, cons
   hipLaunchKernelGGL(csr_compact_rows_kernel, dim3((unsigned)ceil_div(n_rows * 16, 256)), dim3(256), 0, S(stream), rowptr,
                      n_rows, tcol, tval, col, val);
   MELD_LAUNCH_CHECK("csr_compact_rows_kernel");
+  return MELD_OK;
+}
+
+extern "C" int meld_csr_compact_rows_sums(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval, int32_t* col,
+                                          double* val, double diag, double* sums, meld_stream_t stream) {
+  MELD_CHECK_ARG(rowptr && n_rows > 0 && tcol && tval && col && val && sums, "meld_csr_compact_rows_sums: bad arguments");
+  hipLaunchKernelGGL(csr_compact_rows_sums_kernel, dim3((unsigned)ceil_div(n_rows * 8, 256)), dim3(256), 0, S(stream), rowptr, n_rows, tcol,
+                     tval, col, val, diag, sums);
+  MELD_LAUNCH_CHECK("csr_compact_rows_sums_kernel");
   return MELD_OK;
 }
 

@@ -520,6 +520,31 @@ extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const doub
   return MELD_OK;
 }
 
+// out[i] = X[perm[i]] for rows of d doubles: the cells in the device order.  32 lanes per row, 16-byte pieces when the rows are
+// 16-byte aligned (d even); the library gather moved the 2 x 400 MB of 1M x 50 cells at 1.5 TB/s.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ X, const int64_t* __restrict__ perm, int64_t N,
+                                                          int d, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
+  if (i >= N) return;
+  const int64_t src = perm[i];
+  if ((d & 1) == 0) {
+    const double2* a = reinterpret_cast<const double2*>(X + src * d);
+    double2* b = reinterpret_cast<double2*>(out + i * d);
+    for (int c = l; c < d / 2; c += 32) b[c] = a[c];
+  } else {
+    for (int c = l; c < d; c += 32) out[i * d + c] = X[src * d + c];
+  }
+}
+
+extern "C" int meld_gather_rows_f64(const double* X, const int64_t* perm, int64_t N, int d, double* out, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && perm && out && N >= 0 && d > 0, "meld_gather_rows_f64: bad arguments");
+  if (N == 0) return MELD_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(N, 8)), dim3(256), 0, S(stream), X, perm, N, d, out);
+  MELD_LAUNCH_CHECK("gather_rows_kernel");
+  return MELD_OK;
+}
+
 extern "C" int meld_chain_order(const double* P, int64_t n_groups, int m, int d, int32_t* rank, meld_stream_t stream) {
   MELD_CHECK_ARG(P && rank && n_groups > 0 && m >= 1 && m <= 64 && d > 0, "meld_chain_order: bad arguments (1 <= m <= 64)");
   const size_t chain_bytes = sizeof(double) * (size_t)m * (d + 1);

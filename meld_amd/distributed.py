@@ -125,7 +125,7 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
 
         perm = locality_permutation(X, comm=comm)  # (the assignment passes are split over the ranks)
         if perm is not None:
-            X = X.index_select(0, perm)
+            X = ops.gather_rows(X, perm) if hasattr(ops, "gather_rows") else X.index_select(0, perm)
     R, r0, n_loc = shard_range(N, comm.world, comm.rank)
     dev = X.device
 

@@ -914,7 +914,9 @@ class HipOps:
                                                 ptr(fb_off), ptr(fb_col), ptr(fb_val), fb_total, ptr(cursor), ptr(tcol), ptr(tval), st),
                       "meld_coo_emit_scatter")
                 tm.stop("coo_emit")
-                assembled = self._finish_buckets(cursor, tcol, tval, q_count)  # None: a bucket overflowed / a column thrice
+                assembled = self._finish_buckets(cursor, tcol, tval, q_count, sums_diag=1.0)  # None: a bucket overflowed / a column thrice
+                if assembled is not None and self.last_row_sums is not None:
+                    assembled = assembled + (self.last_row_sums[1],)  # (kernel row sums incl. the unit diagonal)
                 tm.stop("symmetrize")
                 del cursor, tcol, tval
         keys = vals = None
@@ -967,7 +969,7 @@ class HipOps:
                                                  int(cap), ptr(counts), ptr(send), _stream()), "meld_coo_partition_remote")
         return send, counts
 
-    def _finish_buckets(self, cursor, tcol, tval, n_rows):
+    def _finish_buckets(self, cursor, tcol, tval, n_rows, sums_diag=None):
         """Row buckets (meld_coo_scatter_rows / meld_coo_emit_scatter) -> CSR: every bucket sorted by column and its pairs
         of equal columns summed inside one wave, then compacted.  None when a bucket overflowed or a column occurs more
         than twice (the caller takes the sort-based path, whose summation order is defined)."""
@@ -982,7 +984,14 @@ class HipOps:
             return None
         col = torch.empty(nnz, **i32)
         val = torch.empty(nnz, dtype=torch.float64, device=dev)
-        if nnz > 0:
+        self.last_row_sums = None
+        if nnz > 0 and sums_diag is not None:
+            # (the rows' sums on the way out of the buckets: meld_csr_row_sums' bits without its pass over the values)
+            sums = torch.empty(n_rows, dtype=torch.float64, device=dev)
+            check(lib.meld_csr_compact_rows_sums(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), float(sums_diag), ptr(sums), st),
+                  "meld_csr_compact_rows_sums")
+            self.last_row_sums = (sums_diag, sums)
+        elif nnz > 0:
             check(lib.meld_csr_compact_rows(ptr(rowptr), n_rows, ptr(tcol), ptr(tval), ptr(col), ptr(val), st), "meld_csr_compact_rows")
         self.last_assemble = "bucket"
         return rowptr, col, val
@@ -1028,6 +1037,14 @@ class HipOps:
         col = torch.empty(nnz, dtype=torch.int32, device=dev)
         check(lib.meld_csr_from_keys(ptr(ukeys), nnz, row_begin, n_rows, ptr(rowptr), ptr(col), st), "meld_csr_from_keys")
         return rowptr, col, uvals[:nnz].clone()
+
+    def gather_rows(self, X, perm):
+        """X[perm] for an fp64 [N, d] matrix (``meld_gather_rows_f64``)."""
+        X = X.contiguous()
+        perm = perm.to(torch.int64).contiguous()
+        out = torch.empty((int(perm.shape[0]), int(X.shape[1])), dtype=torch.float64, device=X.device)
+        check(self.lib.meld_gather_rows_f64(ptr(X), ptr(perm), int(perm.shape[0]), int(X.shape[1]), ptr(out), _stream()), "meld_gather_rows_f64")
+        return out
 
     def row_sums(self, rowptr, val, n_rows, diag):
         out = torch.empty(n_rows, dtype=torch.float64, device=rowptr.device)
@@ -1355,20 +1372,24 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         tm.start()
         perm = locality_permutation(X)
         if perm is not None:
-            X = X.index_select(0, perm)
+            X = ops.gather_rows(X, perm)
         tm.stop("reorder")
 
     keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True)
     if info.get("nnz_directed", 0) == 0:
         raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
     tm.start()
+    ksum = None
     if info.get("assembled") is not None:  # (the kept candidates went straight into the row buckets)
-        rowptr, col, val = info.pop("assembled")
+        asm = info.pop("assembled")
+        rowptr, col, val = asm[:3]
+        ksum = asm[3] if len(asm) > 3 else None  # (the row sums came out of the buckets with the rows)
     else:
         rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
     del keys, vals
     tm.stop("symmetrize")
-    ksum = ops.row_sums(rowptr, val, N, 1.0)
+    if ksum is None:
+        ksum = ops.row_sums(rowptr, val, N, 1.0)
     dw = ops.anisotropy_degrees(rowptr, col, val, N, ksum, 0, anisotropy)
     tm.stop("anisotropy_degree")
 

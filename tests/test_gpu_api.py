@@ -727,3 +727,17 @@ def test_results_lent_from_pinned_buffers_stay_valid_and_come_back():
     del held, out
     gc.collect()
     assert mf._POOL.out.get(key, 0) == 0 and len(mf._POOL.free.get(key, [])) == mf._PinnedPool.MAX_OUT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 7, 50, 141])
+def test_row_gather_equals_index_select(d):
+    """meld_gather_rows_f64 (the cells brought into the device order): even and odd row lengths, a permutation and repeats."""
+    import torch
+
+    from meld_amd.graph import HipOps
+
+    g = torch.Generator(device="cuda").manual_seed(d)
+    X = torch.randn(5003, d, dtype=torch.float64, device="cuda", generator=g)
+    for perm in (torch.randperm(5003, device="cuda", generator=g), torch.randint(0, 5003, (777,), device="cuda", generator=g)):
+        assert torch.equal(HipOps().gather_rows(X, perm), X.index_select(0, perm))

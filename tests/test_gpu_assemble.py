@@ -160,3 +160,30 @@ def test_anisotropy_and_degrees_in_one_pass_equal_the_two_kernels(a):
     ks = ksum.cpu().numpy()
     rows = np.repeat(np.arange(n), lens)
     np.testing.assert_allclose(v2.cpu().numpy(), val / (ks[rows] * ks[col]) ** a, rtol=1e-14)
+
+
+def test_row_sums_out_of_the_compaction_equal_the_row_sum_kernel():
+    """meld_csr_compact_rows_sums = meld_csr_compact_rows followed by meld_csr_row_sums, bit for bit (eight lanes per row in the
+    row-sum kernel's order), empty rows and rows of a few hundred entries included."""
+    from meld_amd._lib import check, get_lib, ptr
+    from meld_amd.graph import HipOps
+
+    lib = get_lib()
+    B = int(lib.meld_csr_bucket_slots())
+    rng = np.random.default_rng(8)
+    n = 3000
+    lens = rng.integers(0, 70, size=n)
+    lens[::53] = 0
+    lens[7::301] = B
+    rp = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+    tcol = torch.from_numpy(rng.integers(0, n, size=n * B).astype(np.int32)).cuda()
+    tval = torch.from_numpy(rng.random(n * B)).cuda()
+    nnz = int(rp[-1])
+    st = torch.cuda.current_stream().cuda_stream
+    c1, v1 = torch.empty(nnz, dtype=torch.int32, device="cuda"), torch.empty(nnz, dtype=torch.float64, device="cuda")
+    c2, v2, s2 = torch.empty_like(c1), torch.empty_like(v1), torch.empty(n, dtype=torch.float64, device="cuda")
+    check(lib.meld_csr_compact_rows(ptr(rp), n, ptr(tcol), ptr(tval), ptr(c1), ptr(v1), st))
+    check(lib.meld_csr_compact_rows_sums(ptr(rp), n, ptr(tcol), ptr(tval), ptr(c2), ptr(v2), 1.0, ptr(s2), st))
+    s1 = HipOps().row_sums(rp, v1, n, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(v1, v2) and torch.equal(s1, s2)
