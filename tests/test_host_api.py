@@ -208,3 +208,37 @@ def test_benchmarker_ground_truth_follows_the_reference_draws():
     assert b.data_phate is not None and np.allclose(b.data_phate, z)
     b.set_phate(b.data_phate + 1)
     np.testing.assert_allclose(b.data_phate.mean(axis=0), 0, atol=1e-12)
+
+
+def test_metric_front_end_reduces_to_the_euclidean_search_or_refuses():
+    """distance= enters through the data (meld_amd.graph.metric_front_end): unit rows and a doubled decay for cosine / correlation,
+    a doubled decay for sqeuclidean, nothing for euclidean / l2; zero (constant) rows and other metrics are refused by name."""
+    import torch
+
+    from meld_amd.graph import metric_front_end
+
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(rng.normal(size=(50, 6)) + 1.0)
+    for name in ("euclidean", "l2"):
+        Y, decay, to_metric = metric_front_end(X, name, 40)
+        assert Y is X and decay == 40 and to_metric is None
+    Y, decay, to_metric = metric_front_end(X, "sqeuclidean", 40)
+    assert Y is X and decay == 80 and float(to_metric(torch.tensor(3.0))) == 9.0
+    Y, decay, to_metric = metric_front_end(X, "cosine", None)
+    assert decay is None and torch.allclose(torch.linalg.vector_norm(Y, dim=1), torch.ones(50, dtype=torch.float64))
+    # cosine distance of two rows = half the squared distance of their unit rows
+    d_cos = 1.0 - float((X[0] @ X[1]) / (torch.linalg.vector_norm(X[0]) * torch.linalg.vector_norm(X[1])))
+    assert abs(float(to_metric(torch.linalg.vector_norm(Y[0] - Y[1]))) - d_cos) < 1e-14
+    Y, decay, _ = metric_front_end(X, "correlation", 10)
+    assert decay == 20 and float(Y.sum(dim=1).abs().max()) < 1e-12
+    Z = X.clone()
+    Z[3] = 0.0
+    with pytest.raises(ValueError, match="all-zero"):
+        metric_front_end(Z, "cosine", 40)
+    Z[3] = 2.5
+    with pytest.raises(ValueError, match="constant"):
+        metric_front_end(Z, "correlation", 40)
+    with pytest.raises(NotImplementedError, match="manhattan"):
+        metric_front_end(X, "manhattan", 40)
+    with pytest.raises(ValueError):
+        meld.MELD(distance="manhattan")
