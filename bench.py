@@ -79,8 +79,7 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
         runs.append((n, time.perf_counter() - t0))
     ln = np.log([r[0] for r in runs])
     lt = np.log([r[1] for r in runs])
-    expo, icpt = np.polyfit(ln, lt, 1)
-    t_target = float(np.exp(icpt + expo * math.log(n_target)))
+    expo, _ = np.polyfit(ln, lt, 1)
     n_big, t_big = runs[-1]
     X, labels = mo.synthetic_cells(n_big, n_dims=dims, seed=0)
     t0 = time.perf_counter()
@@ -94,18 +93,14 @@ def cpu_baseline(sample_cells, dims, knn, beta, order, n_target, full_protocol=F
         "sample": "N={} cells x {} dims, full fit_transform, sklearn ball_tree n_jobs=1 + scipy CSR (the reference "
         "stack's defaults); {:.1f} s".format(n_big, dims, t_big),
         "runs": [{"cells": n, "seconds": round(t, 2), "cells_per_s": n / t} for n, t in runs],
-        "fitted_exponent": float(expo),
-        "extrapolated": {
-            "cells": int(n_target),
-            "seconds": t_target,
-            "cells_per_s": n_target / t_target,
-            "note": "EXTRAPOLATED from the three runs above with t ~ N^{:.2f}; not measured".format(expo),
-        },
+        # (descriptive only: the ball tree's cost grows between N^1.6 at these sizes and N^2.7 past 50k cells -- the two fits of earlier
+        # rounds disagreed 44x at 1M cells, so NO figure is extrapolated to the benchmark size any more; the measured sizes stand alone)
+        "fitted_exponent_over_these_runs": float(expo),
         "host_cores_available": os.cpu_count(),
         "measured_full_size": measured_full_size(n_target),
-        "speedup_basis": "a quoted GPU / CPU ratio at the benchmark size uses `measured_full_size` (all host cores, brute force: the "
-        "fastest CPU configuration measured) when present; `extrapolated` (1 core, ball tree: the reference stack's defaults) is a "
-        "fit over three small samples with the exponent printed beside it and is never the basis of a headline ratio",
+        "speedup_basis": "a GPU / CPU ratio at the benchmark size may only use `measured_full_size` (whole oracle on all host cores, "
+        "brute-force kNN: the fastest CPU configuration measured, REPLAYED from the file named in it) or the runs above at THEIR "
+        "sizes; nothing on this line is extrapolated",
         "recorded_full_protocol": recorded_full_protocol(),
         "best_effort": {
             "value": n_big / t_best,
@@ -119,12 +114,17 @@ def measured_full_size(n_cells):
     """The one MEASURED CPU number at the benchmark size: the whole oracle (brute-force kNN on all host cores) run by the round's
     evidence script (tools/parity_200k.py under tools/_profile_round.sh, 160 s at 1M cells -- too long for a default bench run),
     recorded with its commit in profiles/r04_cpu_full_size.json."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_cpu_full_size.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(str(int(n_cells)))
-    except Exception:
-        return None
+    for name in ("r05_cpu_full_size.json", "r04_cpu_full_size.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(str(int(n_cells)))
+        except Exception:
+            rec = None
+        if rec:
+            # (first key: this object was not measured in this run)
+            return dict({"replayed_from": "profiles/{}@{}".format(name, rec.get("commit", "?"))}, **rec)
+    return None
 
 
 def recorded_full_protocol():
@@ -134,9 +134,12 @@ def recorded_full_protocol():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_baseline_full.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            rec = json.load(f)
     except Exception:
         return None
+    # the measured runs only (the record's own extrapolation to 1M cells is not carried: see fitted_exponent_over_these_runs)
+    keep = {k: rec[k] for k in ("commit", "host", "protocol", "runs", "best_effort", "note") if k in rec}
+    return dict({"replayed_from": "profiles/r03_cpu_baseline_full.json@{}".format(rec.get("commit", "?"))}, **keep)
 
 
 def cpu_chebyshev_full_size(G, labels, beta, order):
@@ -184,6 +187,38 @@ def measured_traffic(kernel, n_cells, dims):
     return rec
 
 
+def replayed_from(rec):
+    """`traffic` is not measured by a bench run (counters need their own rocprofv3 --pmc pass): say where it comes from."""
+    return "profiles/pmc/traffic.json@{}".format(rec.get("commit", "?")) if rec else None
+
+
+def cheby_roofline(G, ev, order, p, N, d):
+    """`roofline_cheby` object from the recorded `cheby_steps` spans of graph G (HIP events around the recurrence launches)."""
+    t_ch = float(np.mean(ev["cheby_steps"])) * 1e-3
+    steps = order - 1
+    rows = G.info.get("rows_local", N)
+    byts = cheby_bytes_per_step(G.nnz, rows, p)
+    tiled = G.info.get("spmm") == "tiled"
+    tr = measured_traffic("pt_step" if tiled else "cheby_step", N, d)
+    return {
+        "kernel": ("pt_step_kernel<P=2> (panel-tiled, symmetry-folded Laplacian recurrence, iterate staged in LDS)" if tiled else
+                   "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence)") + ", {} launches".format(steps),
+        "bound": "hbm",
+        "achieved": byts * steps / t_ch / 1e9,
+        "peak": PEAK_HBM_GBS,
+        "unit": "GB/s",
+        "frac": byts * steps / t_ch / 1e9 / PEAK_HBM_GBS,
+        "traffic": (tr or {}).get("bytes_per_launch"),
+        "traffic_replayed_from": replayed_from(tr),
+        "traffic_note": (tr or {}).get("note", "no PMC pass on record for this size (profiles/pmc/traffic.json)"),
+        "traffic_commit": (tr or {}).get("commit"),
+        "algorithmic": "{} B per launch (12*nnz + 4(N+1) + 8N + 40*N*p)".format(byts),
+        "us_per_launch": 1e6 * t_ch / steps,
+        "cells": int(N),
+        "nnz_W": int(G.nnz),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +236,8 @@ def main():
     ap.add_argument("--cpu-full", action="store_true", help="time SURVEY 8d's 50k / 100k / 200k samples (27 minutes of host time)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the extra untimed-region passes with X on the host")
     ap.add_argument("--stages", action="store_true", help="extra untimed step with per-stage host timers")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra untimed passes of the default 1M run (C3's recurrence "
+                                                            "roofline at 500k cells, the unpruned search)")
     ap.add_argument("--vfc", action="store_true", help="also time VertexFrequencyCluster (filter-bank method) on the benchmark graph "
                                                        "(BASELINE configs[4] on one GPU) and report `vfc` / `roofline_vfc`")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded driver even with one rank (testing)")
@@ -273,15 +310,24 @@ def main():
     gc.enable()
     ev = mgraph.event_times_ms()
     mgraph.record_events(False)
-    # the same step with X handed over as a HOST array (SURVEY 8d counts the H2D copy; `value` does not)
-    host_ms = []
+    # the same step with X handed over as a HOST array (SURVEY 8d counts the H2D copy; `value` does not -- the bench contract
+    # starts with the inputs resident): the SAME protocol as `value` -- one warm-up, then args.steps steps in one
+    # synchronize-bracketed region
+    host_ms, host_elapsed = [], None
     if world == 1 and not args.no_host_input:
         X_host = X.cpu().numpy()
-        for i in range(4):
+        meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0).fit_transform(X_host, labels)
+        gc.collect()
+        gc.disable()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(args.steps):
             ts = time.perf_counter()
             meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0).fit_transform(X_host, labels)
-            if i > 0:
-                host_ms.append(1e3 * (time.perf_counter() - ts))
+            host_ms.append(1e3 * (time.perf_counter() - ts))
+        torch.cuda.synchronize()
+        host_elapsed = time.perf_counter() - th
+        gc.enable()
         del X_host
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -361,6 +407,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": executed / t_knn / 1e12 / peak,
             "traffic": (measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch"),
+            "traffic_replayed_from": replayed_from(measured_traffic("knn16_topk", N, d)),
             "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
             "traffic_commit": (measured_traffic("knn16_topk", N, d) or {}).get("commit"),
@@ -378,26 +425,53 @@ def main():
             "ms": 1e3 * t_knn,
         }
     if "cheby_steps" in ev:
-        t_ch = float(np.mean(ev["cheby_steps"])) * 1e-3
-        steps = args.order - 1
-        rows = G.info.get("rows_local", N)
-        byts = cheby_bytes_per_step(G.nnz, rows, p)
-        tiled = G.info.get("spmm") == "tiled"
-        out["roofline_cheby"] = {
-            "kernel": ("pt_step_kernel<P=2> (panel-tiled, symmetry-folded Laplacian recurrence, iterate staged in LDS)" if tiled else
-                       "cheby_step_kernel<P=2> (fused CSR Laplacian recurrence)") + ", {} launches".format(steps),
-            "bound": "hbm",
-            "achieved": byts * steps / t_ch / 1e9,
-            "peak": PEAK_HBM_GBS,
-            "unit": "GB/s",
-            "frac": byts * steps / t_ch / 1e9 / PEAK_HBM_GBS,
-            "traffic": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get("bytes_per_launch"),
-            "traffic_note": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get(
-                "note", "no PMC pass on record for this size (profiles/pmc/traffic.json)"),
-            "traffic_commit": (measured_traffic("pt_step" if tiled else "cheby_step", N, d) or {}).get("commit"),
-            "algorithmic": "{} B per launch (12*nnz + 4(N+1) + 8N + 40*N*p)".format(byts),
-            "us_per_launch": 1e6 * t_ch / steps,
-        }
+        out["roofline_cheby"] = cheby_roofline(G, ev, args.order, p, N, d)
+    if world == 1 and not args.no_extra and N == 1_000_000 and d == 50:
+        # BASELINE configs[2] (C3, 500k x 50) is the configuration the north star's 70 % recurrence target is quoted on: one extra
+        # untimed pass at that size (a warm-up + two steps), its recurrence launches timed by the same HIP events
+        Xc, lc = synthetic_cells(500_000, n_dims=d, seed=0)
+        Xc = torch.from_numpy(Xc).cuda()
+        opc = None
+        for i in range(3):
+            if i == 1:
+                torch.cuda.synchronize()
+                mgraph.record_events(True)
+            opc = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)
+            tc = time.perf_counter()
+            densc = opc.fit_transform(Xc, lc)
+            tc = time.perf_counter() - tc
+        torch.cuda.synchronize()
+        evc = mgraph.event_times_ms()
+        mgraph.record_events(False)
+        if "cheby_steps" in evc:
+            out["roofline_cheby_c3"] = dict(cheby_roofline(opc.graph, evc, args.order, densc.shape[1], 500_000, d),
+                                            ms_per_step_whole_fit_transform=1e3 * tc,
+                                            note="BASELINE configs[2] (500k x 50): untimed extra pass of this run, X resident")
+        del Xc, opc, densc
+        # the data dependence of the search on the line: the same step with the exact tile pruning switched off (every
+        # 64 x 64 block computed -- what iid data without cluster structure would cost), one untimed step
+        os.environ["MELD_KNN_PRUNE"] = "0"
+        try:
+            mgraph.record_events(True)
+            opu = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)
+            tu = time.perf_counter()
+            opu.fit_transform(X, labels)
+            tu = time.perf_counter() - tu
+            torch.cuda.synchronize()
+            evu = mgraph.event_times_ms()
+        finally:
+            del os.environ["MELD_KNN_PRUNE"]
+            mgraph.record_events(False)
+        if "knn_topk" in evu and "roofline" in out:
+            t_u = float(np.mean(evu["knn_topk"])) * 1e-3
+            kbu = (d + 3 + 15) // 16
+            out["roofline"]["unpruned"] = {
+                "ms": 1e3 * t_u, "ms_per_step_whole_fit_transform": 1e3 * tu, "cells_per_s_whole_fit_transform": N / tu,
+                "achieved": 2.0 * N * N * 16 * kbu / t_u / 1e12, "frac": 2.0 * N * N * 16 * kbu / t_u / 1e12 / PEAK_MFMA_F16_TFLOPS,
+                "note": "MELD_KNN_PRUNE=0: same kernel, same graph, every 64 x 64 block computed (no tile bounds, no step lists); "
+                        "the pruned rate above depends on the cluster structure of the data, this one does not",
+            }
+        del opu
     if args.stages and world == 1:
         op2 = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order)
         t0 = time.perf_counter()
@@ -448,13 +522,16 @@ def main():
                                "rate is reported beside it as `value_host_input` and is SURVEY 8d's host-visible figure)")
     if host_ms:
         # SURVEY 8d's metric counts the H2D copy of X: this is the figure to compare with it (`value` starts X-resident)
-        out["value_host_input"] = N / (1e-3 * float(np.median(host_ms)))
+        out["value_host_input"] = N * len(host_ms) / host_elapsed
         out["host_input"] = {
+            "ms_per_step": 1e3 * host_elapsed / len(host_ms),
             "ms_per_step_median": float(np.median(host_ms)),
-            "value": N / (1e-3 * float(np.median(host_ms))),
+            "steps": len(host_ms),
+            "value": N * len(host_ms) / host_elapsed,
             "unit": "cells/s",
-            "note": "same step with X as a host ndarray (the {:.0f} MB H2D copy over PCIe inside the step), median of {}; "
-            "SURVEY 8d's host-visible definition -- reported beside `value`, which starts with X resident".format(N * d * 8 / 1e6, len(host_ms)),
+            "note": "same step with X as a host ndarray (the {:.0f} MB H2D copy over PCIe inside the step), {} steps in one "
+            "synchronize-bracketed region after one warm-up -- the protocol of `value`; SURVEY 8d's host-visible definition, "
+            "reported beside `value`, which starts with X resident as the bench contract prescribes".format(N * d * 8 / 1e6, len(host_ms)),
         }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, d, args.knn, args.beta, args.order, N, full_protocol=args.cpu_full)

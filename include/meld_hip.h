@@ -143,6 +143,14 @@ int meld_knn16_prepare_cross(const double* X, int64_t n_refs, int64_t n_total, i
 int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
                             int64_t q_begin, const int32_t* rows, int64_t n_rows, void* Q16, float* Qn,
                             meld_stream_t stream);
+/* Start thresholds (scaled units, thr[roundup(n_rows, BQ)]) for the re-search of those rows through
+ * meld_knn16_topk(thr_init = thr): a first pass that found ksel references with approximate d2 <= tau bounds the re-search's
+ * ksel-th distance by tau + E1 + E3 (both passes' error allowances); rows with a shorter first list start at +inf.
+ * cand_cnt / cand_d2 (stride cap): the first pass's lists; err_coef / err_lin: its coefficients, err3: meld_knn16_error_coef(3, d). */
+int meld_knn16_research_thresholds(const int32_t* rows, int64_t n_rows, int64_t q_begin, const int32_t* cand_cnt,
+                                   const float* cand_d2, int cap, int ksel, const float* norm2, const float* norm2_max,
+                                   double err_coef, double err_lin, double err3, const float* scale_info, float* thr,
+                                   meld_stream_t stream);
 /* thr_init (optional, roundup(q_count, BQ) floats in the SCALED units of the search, i.e. input
  * d2 * scale_info[0]^2): per query, a bound below which all wanted neighbours are known to lie; the
  * selection thresholds start there instead of at +inf (the re-search passes the first pass's
@@ -526,6 +534,31 @@ int meld_order_pick_centroids(const double* X, int64_t N, int d, const int64_t* 
                               double* cents, meld_stream_t stream);
 int meld_order_update_keys(uint32_t* key, const int32_t* child, const int32_t* rank, int64_t n, int f, meld_stream_t stream);
 
+
+/* ---- sample labels -> codes, counts and the indicator signal (replaces MELD._create_sample_indicators,
+ *      meld/meld.py:143-191: np.unique + LabelBinarizer, and the column normalisation of meld/meld.py:229-232;
+ *      csrc/labels.hip) ------------------------------------------------------------------------------------
+ * Labels arrive as fixed-width words (numpy 'U' / 'S' / 64-bit integer arrays viewed as int32 [n_rows, n_words],
+ * n_words <= meld_factorize_max_words()).  Two labels get the same group iff all their words are equal (a dictionary
+ * of whole labels in LDS: no hashing).  meld_factorize_labels leaves in head (int64 [2 + 2 G], G =
+ * meld_factorize_max_groups()): [0] status (1: more than G distinct labels, nothing else valid), [1] number of groups,
+ * [2 .. 2 + G) the first row of every group, [2 + G ..) the group sizes; the per-row group numbers stay in temp.
+ * meld_factorize_codes then writes codes[i] = rank[group of row i] (rank: int32 on the device, the position of every
+ * group among the SORTED labels as np.unique orders them -- only the host can compare label strings; NULL: the group
+ * numbers themselves). */
+int meld_factorize_max_groups(void);
+int meld_factorize_max_words(void);
+size_t meld_factorize_temp_bytes(int64_t n_rows);
+int meld_factorize_labels(const int32_t* words, int64_t n_rows, int n_words, void* temp, size_t temp_bytes, int64_t* head,
+                          meld_stream_t stream);
+int meld_factorize_codes(const void* temp, int64_t n_rows, const int32_t* rank, int64_t* codes, meld_stream_t stream);
+/* out[n_pad, p] (fp64): row i = scale[c] at column c = codes[perm[i]], 0 elsewhere (scale NULL: 1; perm NULL: i);
+ * rows n_rows .. n_pad are zero.  The filter's input signal in the device's row order, one pass. */
+int meld_indicator_signal(const int64_t* codes, const double* scale, const int64_t* perm, int64_t n_rows, int64_t n_pad, int p,
+                          double* out, meld_stream_t stream);
+/* out[perm[i]][:] = in[i][:] for i < n_rows (rows of p doubles): the densities back in the caller's cell order
+ * (meld/meld.py:246-250 wraps them with the labels' index). */
+int meld_scatter_rows_f64(const double* in, const int64_t* perm, int64_t n_rows, int p, double* out, meld_stream_t stream);
 
 /* ---- next#1: normalize_densities (meld/utils.py:35-47) ------------------------------------ */
 /* out[i,:] = in[i,:] / sum_j |in[i,j]|  (rows of zeros are copied unchanged, as sklearn does) */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "meld_knn16_prepare": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_cross": (_i32, [_ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_rows": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
+    "meld_knn16_research_thresholds": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _f64, _f64, _f64, _ptr, _ptr, _ptr]),
     "meld_knn16_bounds_bytes": (_sz, [_i64, _i64]),
     "meld_knn16_bounds_temp_bytes": (_sz, [_i64, _i32, _i64]),
     "meld_knn16_bounds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
@@ -126,6 +127,13 @@ SIGNATURES = {
     "meld_order_starts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),
     "meld_order_pick_centroids": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
     "meld_order_update_keys": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
+    "meld_factorize_max_groups": (_i32, []),
+    "meld_factorize_max_words": (_i32, []),
+    "meld_factorize_temp_bytes": (_sz, [_i64]),
+    "meld_factorize_labels": (_i32, [_ptr, _i64, _i32, _ptr, _sz, _ptr, _ptr]),
+    "meld_factorize_codes": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr]),
+    "meld_indicator_signal": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr]),
+    "meld_scatter_rows_f64": (_i32, [_ptr, _ptr, _i64, _i32, _ptr, _ptr]),
 }
 
 

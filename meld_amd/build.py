@@ -8,7 +8,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "knn.hip", "knn16.hip", "refine.hip", "assemble.hip", "spmm.hip", "spmm_tiled.hip", "reorder.hip", "kmeans.hip"]
+SOURCES = ["api.hip", "knn.hip", "knn16.hip", "refine.hip", "assemble.hip", "spmm.hip", "spmm_tiled.hip", "reorder.hip", "kmeans.hip", "labels.hip"]
 OUT = os.path.join(_HERE, "libmeld_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-file additions.  knn16.hip: the minima over MFMA accumulators (tile bounds, seeds) are fmin chains on values the compiler
@@ -101,10 +101,14 @@ def gate_stream_slots(hipcc=None, verbose=True):
     cmd = [hipcc] + FLAGS + ["--cuda-device-only", "-S", src, "-o", "-"]
     if verbose:
         print("[meld_amd.build] gate:", " ".join(cmd), flush=True)
-    asm = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if run.returncode != 0 or not run.stdout:
+        raise RuntimeError("meld_amd.build: `hipcc -S` of spmm_tiled.hip failed (status {}), the register-slot guard of pt_step_kernel "
+                           "could not run -- not linking:\n{}".format(run.returncode, run.stderr[-2000:]))
+    asm = run.stdout
     try:
         return check_stream_slots(asm)
-    except AssertionError as e:
+    except (AssertionError, ValueError, StopIteration) as e:  # (ValueError: no loop-header label matched -- another label format)
         raise RuntimeError("meld_amd.build: the register-slot guard of pt_step_kernel failed ({}); the tiled recurrence kernel "
                            "cannot be trusted with this toolchain -- not linking".format(e))
 

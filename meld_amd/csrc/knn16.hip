@@ -1919,6 +1919,46 @@ extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const 
 }
 
 namespace meld {
+// Start thresholds of the re-search (scaled units): the first pass found ksel references with approximate d2 <= tau, so the true
+// ksel-th distance is <= tau + E1 and its full-precision approximation <= tau + E1 + E3 -- nothing above that can enter the
+// list; a row whose first list is shorter than ksel starts at +inf.  Padding rows copy the last row's value.
+__global__ __launch_bounds__(256) void knn16_research_thr_kernel(const int* __restrict__ rows, long long n_rows, long long q_pad,
+                                                                 long long q_begin, const int* __restrict__ cand_cnt,
+                                                                 const float* __restrict__ cand_d2, int cap, int ksel,
+                                                                 const float* __restrict__ norm2, const float* __restrict__ nmax,
+                                                                 double err_coef, double err_lin, double err3,
+                                                                 const float* __restrict__ scale_info, float* __restrict__ thr) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= q_pad) return;
+  const long long r = rows[i < n_rows ? i : n_rows - 1];
+  const int c = cand_cnt[r];
+  const double tau = (double)cand_d2[r * cap + (c > 0 ? c - 1 : 0)];
+  const double nmx = (double)nmax[0];
+  const double e1 = err_coef * nmx + err_lin * sqrt((double)norm2[q_begin + r] * nmx);
+  const double e3 = err3 * nmx;
+  const double s = (double)scale_info[0];
+  const float b = (float)((tau + e1 + e3) * (s * s) * (1.0 + 1e-5));
+  thr[i] = c >= ksel ? b : INFINITY;
+}
+}  // namespace meld
+
+// thr[q_pad] for meld_knn16_topk(thr_init = thr) over the rows meld_knn16_prepare_rows gathered: see the kernel.
+// cand_cnt / cand_d2 (row stride cap): the first pass's lists; err_coef / err_lin: its error coefficients, err3: the
+// re-search's (meld_knn16_error_coef(3, d)); norm2 is indexed by global row (q_begin + rows[i]).
+extern "C" int meld_knn16_research_thresholds(const int32_t* rows, int64_t n_rows, int64_t q_begin, const int32_t* cand_cnt,
+                                              const float* cand_d2, int cap, int ksel, const float* norm2, const float* norm2_max,
+                                              double err_coef, double err_lin, double err3, const float* scale_info, float* thr,
+                                              meld_stream_t stream) {
+  MELD_CHECK_ARG(rows && cand_cnt && cand_d2 && norm2 && norm2_max && scale_info && thr && n_rows > 0 && cap > 0,
+                 "meld_knn16_research_thresholds: bad arguments");
+  const int64_t q_pad = ceil_div(n_rows, K16_BQ) * K16_BQ;
+  knn16_research_thr_kernel<<<(unsigned)ceil_div(q_pad, 256), 256, 0, S(stream)>>>(rows, n_rows, q_pad, q_begin, cand_cnt, cand_d2, cap, ksel,
+                                                                                   norm2, norm2_max, err_coef, err_lin, err3, scale_info, thr);
+  MELD_LAUNCH_CHECK("meld_knn16_research_thresholds");
+  return MELD_OK;
+}
+
+namespace meld {
 // The bound of (wave w, tile t) is a lower bound on the distance between ANY cell of w and ANY cell of t, and so is the bound
 // of (wave t, tile w) -- the cells of tile w against the sphere of tile t, and the other way round: when the queries are all
 // the cells, the table is symmetrised to the larger of the two (1M cells: the live blocks of the end state fall from 15.8

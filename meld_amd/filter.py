@@ -46,6 +46,19 @@ class IndicatorSignal:
         out[np.arange(self.shape[0]), codes] = 1.0 if self.scale is None else self.scale[codes]
         return out
 
+    def to_device_ordered(self, device, perm, n_pad):
+        """The [n_pad, p] signal on the device with row i = the indicator row of cell perm[i] (perm None: i) and zero rows
+        behind the N cells: ``meld_indicator_signal``, one pass instead of zeros / gather / scatter / index_select / cat."""
+        if isinstance(self.codes, torch.Tensor):
+            codes = self.codes.to(device=device, dtype=torch.int64)
+        else:
+            codes = torch.from_numpy(self.codes.astype(np.int32)).to(device).to(torch.int64)
+        scale = None if self.scale is None else torch.from_numpy(self.scale).to(device)
+        out = torch.empty((int(n_pad), self.n_columns), dtype=torch.float64, device=device)
+        check(get_lib().meld_indicator_signal(ptr(codes.contiguous()), ptr(scale), ptr(perm), self.shape[0], int(n_pad), self.n_columns,
+                                              ptr(out), torch.cuda.current_stream().cuda_stream), "meld_indicator_signal")
+        return out
+
     def to_device(self, device):
         if isinstance(self.codes, torch.Tensor):
             codes = self.codes.to(device=device, dtype=torch.int64)
@@ -581,12 +594,16 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
         if chebyshev_order is None:
             chebyshev_order = 30  # pygsp's default order
         c = chebyshev_coefficients(h, graph.lmax, chebyshev_order)
-        s_dev = sig.to_device(dev) if is_ind else torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
         perm = getattr(graph, "perm", None)
-        if perm is not None:  # device arrays live in the locality order
-            s_dev = s_dev.index_select(0, perm)
-        if graph.n_pad != graph.N:  # sharded graph: isolated padding rows at the end
-            s_dev = torch.cat([s_dev, torch.zeros(graph.n_pad - graph.N, s_dev.shape[1], dtype=s_dev.dtype, device=dev)])
+        if is_ind and dev.type == "cuda":
+            # the scaled one-hot straight in the device's row order, padding rows included (meld_indicator_signal: one pass)
+            s_dev = sig.to_device_ordered(dev, perm, graph.n_pad)
+        else:
+            s_dev = sig.to_device(dev) if is_ind else torch.from_numpy(np.ascontiguousarray(sig)).to(dev)
+            if perm is not None:  # device arrays live in the locality order
+                s_dev = s_dev.index_select(0, perm)
+            if graph.n_pad != graph.N:  # sharded graph: isolated padding rows at the end
+                s_dev = torch.cat([s_dev, torch.zeros(graph.n_pad - graph.N, s_dev.shape[1], dtype=s_dev.dtype, device=dev)])
         r = chebyshev_apply(graph, s_dev, c, graph.lmax)
         comm = getattr(graph, "comm", None)
         if comm is not None:
@@ -596,7 +613,10 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
         r = r[: graph.N]
         if perm is not None:
             r_orig = torch.empty_like(r)
-            r_orig[perm] = r
+            if r.is_cuda and r.dtype == torch.float64 and r.is_contiguous():
+                check(get_lib().meld_scatter_rows_f64(ptr(r), ptr(perm), int(r.shape[0]), int(r.shape[1]), ptr(r_orig), _stream()), "meld_scatter_rows_f64")
+            else:
+                r_orig[perm] = r
             r = r_orig
         # D2H through a pinned staging buffer kept on the graph (pageable copies run at a few GB/s)
         out = _POOL.lend(r) if (r.is_cuda and os.environ.get("MELD_PINNED_RESULT", "1") != "0") else None

@@ -776,18 +776,10 @@ class HipOps:
             # references with approximate d2 <= tau, so the true ksel-th distance is <= tau + E1 and its
             # full-precision approximation <= tau + E1 + E3 -- nothing above that can enter the list.
             # (Without it every slice selects from scratch: 19k appends per query at 1M cells.)
-            r64 = rows2.to(torch.int64)
-            cnt1 = cand_cnt[r64].to(torch.int64)
-            tau = cand_d2[r64 * cap + (cnt1 - 1).clamp_(min=0)].to(torch.float64)
-            nmx = nmax.to(torch.float64)
-            e1 = float(err_coef) * nmx + float(err_lin) * torch.sqrt(norm2[q_begin + r64].to(torch.float64) * nmx)
-            e3 = float(lib.meld_knn16_error_coef(3, d)) * nmx
-            s2 = research["scale_info"][0].to(torch.float64) ** 2
-            bound = ((tau + e1 + e3) * s2 * (1.0 + 1e-5)).to(torch.float32)
-            bound = torch.where(cnt1 >= ksel, bound, torch.full_like(bound, float("inf")))
             thr2 = torch.empty(q2_pad, dtype=torch.float32, device=dev)
-            thr2[:n_flag_h] = bound
-            thr2[n_flag_h:] = bound[-1]
+            check(lib.meld_knn16_research_thresholds(ptr(rows2), n_flag_h, q_begin, ptr(cand_cnt), ptr(cand_d2), cap, ksel, ptr(norm2), ptr(nmax),
+                                                     float(err_coef), float(err_lin), float(lib.meld_knn16_error_coef(3, d)),
+                                                     ptr(research["scale_info"]), ptr(thr2), st), "meld_knn16_research_thresholds")
             c2_idx = torch.empty(n_slices * q2_pad * cap, dtype=torch.int32, device=dev)
             c2_d2 = torch.empty(n_slices * q2_pad * cap, dtype=torch.float32, device=dev)
             c2_cnt = torch.empty(n_slices * q2_pad, dtype=torch.int32, device=dev)

@@ -221,18 +221,20 @@ class MELD(GraphEstimator):
 
     @staticmethod
     def _factorize_device(labels, device):
-        """``_factorize`` on the GPU for fixed-width string / integer labels: the raw label words
-        go over PCIe once, rows are folded into 64-bit keys, ``torch.unique`` groups them, and the
-        grouping is verified word by word against one representative row per group (a key collision
-        falls back to the host path).  Returns (codes as an int64 device tensor, sorted uniques,
-        label counts) or None when the dtype is not eligible."""
+        """``_factorize`` on the GPU for fixed-width string / integer labels: the raw label words go over PCIe once and
+        ``meld_factorize_labels`` groups them (whole labels compared word by word: exact).  Returns (codes as an int64
+        device tensor, sorted uniques, label counts), or None when the dtype is not eligible or there are more distinct
+        labels than the device dictionary holds (the host path then factorises)."""
         return MELD._factorize_device_end(MELD._factorize_device_begin(labels, device))
 
     @staticmethod
     def _factorize_device_begin(labels, device):
         """The device half of ``_factorize_device``: everything up to the first value the host has to read, enqueued on
-        the current stream.  ``fit_transform`` runs it on a side stream while the candidate search occupies the main one
-        and reads the results (``_factorize_device_end``) after the graph is built."""
+        the current stream (``meld_factorize_labels``, csrc/labels.hip: a dictionary of the distinct labels built in LDS,
+        whole labels compared word by word).  ``fit_transform`` runs it on a side stream while the candidate search
+        occupies the main one and reads the results (``_factorize_device_end``) after the graph is built."""
+        from ._lib import check, get_lib, ptr
+
         lab = np.ascontiguousarray(labels)
         if lab.dtype.kind in "US" and lab.dtype.itemsize % 4 == 0 and lab.dtype.itemsize > 0:
             words = lab.view(np.int32).reshape(lab.shape[0], -1)
@@ -240,45 +242,49 @@ class MELD(GraphEstimator):
             words = lab.view(np.int32).reshape(lab.shape[0], -1)
         else:
             return None
+        lib = get_lib()
+        n, w = int(words.shape[0]), int(words.shape[1])
+        if n == 0 or w > lib.meld_factorize_max_words():
+            return None
+        st = torch.cuda.current_stream().cuda_stream
         t = torch.from_numpy(words).to(device)
-        key = t[:, 0].to(torch.int64)
-        for c in range(1, t.shape[1]):
-            key = key * 1000003 + t[:, c].to(torch.int64)  # wraps around; verified below
-        _, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-        # first occurrence of every group: a stable sort of the codes puts each group's smallest index at
-        # the group's start (a scatter-min over N indices into p slots is an atomic pile-up: 21 ms at 1M, p = 2)
-        by_code = torch.argsort(inv, stable=True)
-        first = by_code[torch.cumsum(cnt, 0) - cnt]
-        ok = (t == t[first][inv]).all()
-        # (what the host reads afterwards, in one buffer: one device -> host copy instead of three)
-        packed = torch.cat([ok.reshape(1).to(torch.int64), first, cnt])
+        tb = lib.meld_factorize_temp_bytes(n)
+        temp = torch.empty(tb, dtype=torch.uint8, device=device)
+        G = lib.meld_factorize_max_groups()
+        head = torch.empty(2 + 2 * G, dtype=torch.int64, device=device)
+        check(lib.meld_factorize_labels(ptr(t), n, w, ptr(temp), tb, ptr(head), st), "meld_factorize_labels")
+        head_h = torch.empty(2 + 2 * G, dtype=torch.int64, pin_memory=True)
+        head_h.copy_(head, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(lab=lab, inv=inv, cnt=cnt, first=first, ok=ok, packed=packed, done=done, device=device)
+        return dict(lab=lab, n=n, temp=temp, head=head, head_h=head_h, words=t, done=done, device=device, G=G)
 
     @staticmethod
     def _factorize_device_end(h):
         if h is None:
             return None
+        from ._lib import check, get_lib, ptr
+
         h["done"].synchronize()
         cur = torch.cuda.current_stream()
         cur.wait_event(h["done"])
-        lab, inv, cnt, first, device = h["lab"], h["inv"], h["cnt"], h["first"], h["device"]
-        for t in (inv, cnt, first, h["ok"], h["packed"]):
+        for t in (h["temp"], h["head"], h["words"]):
             # allocated from the side stream's pool, consumed from here on by the current stream: without this the caching
             # allocator may hand their blocks to the next side-stream hook while kernels of this stream still read them
-            if t.is_cuda:
-                t.record_stream(cur)
-        packed = h["packed"].cpu().numpy()  # [ok | first occurrence of every group | group sizes]
-        n_groups = int(first.shape[0])
-        if not bool(packed[0]):
-            return None  # two different labels share a key
-        uniques = lab[packed[1 : 1 + n_groups]]
+            t.record_stream(cur)
+        lab, G, device, n = h["lab"], h["G"], h["device"], h["n"]
+        head = h["head_h"].numpy()  # [status | groups | first row of every group | group sizes]
+        if int(head[0]) != 0:
+            return None  # more distinct labels than the device dictionary holds: the host factorises
+        n_groups = int(head[1])
+        uniques = lab[head[2 : 2 + n_groups]]
         order = np.argsort(uniques, kind="stable")  # the p uniques, ordered as np.unique does
-        rank = np.empty_like(order)
-        rank[order] = np.arange(order.shape[0])
-        codes = torch.from_numpy(rank).to(device)[inv]
-        counts = packed[1 + n_groups :][order]
+        rank = np.empty(n_groups, dtype=np.int32)
+        rank[order] = np.arange(n_groups, dtype=np.int32)
+        codes = torch.empty(n, dtype=torch.int64, device=device)
+        lib = get_lib()
+        check(lib.meld_factorize_codes(ptr(h["temp"]), n, ptr(torch.from_numpy(rank).to(device)), ptr(codes), cur.cuda_stream), "meld_factorize_codes")
+        counts = head[2 + G : 2 + G + n_groups][order].copy()
         return codes, uniques[order], counts
 
     @staticmethod

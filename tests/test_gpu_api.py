@@ -458,6 +458,67 @@ def test_device_label_factorization_matches_the_host_path(kind):
 
 
 @pytest.mark.gpu
+def test_device_label_dictionary_limits_and_edge_cases():
+    """meld_factorize_labels: up to 64 distinct labels of up to 16 words; beyond either the device path declines
+    (None -> the host factorises); a label met only in the last, ragged chunk; labels that differ in their last word only."""
+    import torch
+
+    import meld_amd
+
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(11)
+    n = 250_123
+    # 64 labels that share a long prefix and differ in the last characters (16 words = <U16)
+    pool = np.array(["samplelabel_%04d" % i for i in range(64)], dtype="<U16")
+    labels = pool[rng.integers(0, 64, size=n)]
+    labels[-1] = pool[63]
+    labels[:-1][labels[:-1] == pool[63]] = pool[0]  # label 63 occurs exactly once, in the ragged tail
+    codes_d, uniq_d, counts = meld_amd.MELD._factorize_device(labels, dev)
+    ref_u, ref_inv = np.unique(labels, return_inverse=True)
+    assert np.array_equal(uniq_d, ref_u) and np.array_equal(codes_d.cpu().numpy(), ref_inv)
+    assert np.array_equal(counts, np.bincount(ref_inv)) and counts[list(ref_u).index(pool[63])] == 1
+    # 65 distinct labels: more than the dictionary holds
+    pool65 = np.array(["l%03d" % i for i in range(65)], dtype="<U4")
+    assert meld_amd.MELD._factorize_device(pool65[rng.integers(0, 65, size=n)], dev) is None
+    # labels wider than 16 words
+    wide = np.array(["a" * 20, "b" * 20], dtype="<U20")
+    assert meld_amd.MELD._factorize_device(wide[rng.integers(0, 2, size=n)], dev) is None
+    # one single label (transform's own check reports it): one group
+    codes_d, uniq_d, counts = meld_amd.MELD._factorize_device(np.full(n, "only", dtype="<U4"), dev)
+    assert list(uniq_d) == ["only"] and int(counts[0]) == n and not codes_d.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [1, 2, 3, 7])
+def test_indicator_signal_and_row_scatter_kernels(p):
+    """meld_indicator_signal = zeros / one-hot scatter / index_select(perm) / zero padding in one pass;
+    meld_scatter_rows_f64 = out[perm] = in."""
+    import torch
+
+    from meld_amd import filter as mfilter
+    from meld_amd._lib import check, get_lib, ptr
+
+    rng = np.random.default_rng(p)
+    n, n_pad = 70_001, 70_144
+    codes = rng.integers(0, p, size=n)
+    scale = rng.random(p) + 0.5
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    for sc in (None, scale):
+        sig = mfilter.IndicatorSignal(codes, p, sc)
+        ref = torch.from_numpy(sig.to_dense()).cuda()[perm]
+        out = sig.to_device_ordered(torch.device("cuda"), perm, n_pad)
+        assert out.shape == (n_pad, p) and torch.equal(out[:n], ref) and not out[n:].any()
+        out = mfilter.IndicatorSignal(torch.from_numpy(codes).cuda(), p, sc).to_device_ordered(torch.device("cuda"), None, n)
+        assert torch.equal(out, torch.from_numpy(sig.to_dense()).cuda())
+    r = torch.from_numpy(rng.normal(size=(n, p))).cuda()
+    back = torch.empty_like(r)
+    check(get_lib().meld_scatter_rows_f64(ptr(r), ptr(perm), n, p, ptr(back), torch.cuda.current_stream().cuda_stream), "scatter")
+    ref = torch.empty_like(r)
+    ref[perm] = r
+    assert torch.equal(back, ref)
+
+
+@pytest.mark.gpu
 def test_non_finite_input_is_rejected():
     meld = _meld()
     import torch

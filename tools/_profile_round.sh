@@ -16,7 +16,7 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); d["commit"] = sys.argv[2]
 open(sys.argv[1], "w").write(json.dumps(d) + "\n")
 PY
-  (cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/trace_$n -o t -- python $OLDPWD/bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input > $OLDPWD/$out/trace_${n}_stdout.log 2>&1)
+  (cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$out/trace_$n -o t -- python $OLDPWD/bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input --no-extra > $OLDPWD/$out/trace_${n}_stdout.log 2>&1)
   db=$(ls $out/trace_$n/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && { stamp; echo "# rocprofv3 --kernel-trace --stats -- python bench.py --cells $n --steps 3 --warmup 1 --cpu-sample 0 --no-host-input"; python tools/rocpd_summary.py $db; } > $out/kernel_stats_$n.md
   rm -rf $out/trace_$n $out/trace_${n}_stdout.log   # (the rocpd database is ~50 MB; gpurun_out is capped at 64 MiB)
