@@ -500,6 +500,36 @@ int meld_pt_lanczos_spmv(const meld_pt_layout_t* layout, const int64_t* rowptr, 
                          const double* x_full, int64_t x_row_offset, const double* z_local, double* y_local,
                          const double* state, double* dots, meld_stream_t stream);
 
+/* ---- row-sharded recurrences with the host out of the loop (csrc/sharded.hip) ----------
+ * One process per GPU, cells row-sharded: rank g owns rows [g * rows_pad, (g + 1) * rows_pad) of every full-length vector.
+ * RCCL is reached through dlopen("librccl.so.1") (no link-time dependency: the library loads without it and
+ * meld_rccl_available() says 0); the communicator is the library's own, built from a unique id the ranks share.
+ *   meld_rccl_unique_id: 128 bytes on the HOST (rank 0 calls it, the bytes travel by any means, e.g. torch.distributed);
+ *   meld_rccl_comm_create: collective over the `world` ranks, the calling thread's current device = the rank's GPU;
+ *   meld_rccl_all_gather / _all_reduce_sum_f64: the two collectives of the path, on `stream`. */
+int meld_rccl_available(void);
+int meld_rccl_unique_id(void* id_host);
+int meld_rccl_comm_create(const void* id_host, int world, int rank, void** comm);
+int meld_rccl_comm_destroy(void* comm);
+int meld_rccl_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, meld_stream_t stream);
+int meld_rccl_all_reduce_sum_f64(void* comm, double* buf, size_t count, meld_stream_t stream);
+/* Steps 2 .. n_coef - 1 of the Chebyshev recurrence on a row shard in ONE call (meld_pt_cheby_run's contract with a row
+ * offset and an all-gather behind every step): t_a / t_b are the FULL-length iterates [world * rows_pad, p] holding the
+ * gathered T_0 / T_1, r [rows_pad, p] the local rows of the result.  layout: the shard's panel-tiled layout, or NULL for
+ * the CSR-stream kernel (col / val read only then).  coeffs on the HOST.  Replaces one kernel call + one
+ * torch.distributed all-gather per step issued from Python. */
+int meld_cheby_run_sharded(void* comm, const meld_pt_layout_t* layout, const int64_t* rowptr, const int32_t* col, const double* val,
+                           const double* dw, int64_t n_rows, int64_t nnz, int64_t rows_pad, int64_t row_begin, int p, double* t_a,
+                           double* t_b, double* r, const double* coeffs, int n_coef, double alpha2, double beta2, int* last,
+                           meld_stream_t stream);
+/* Iterations [it_begin, it_begin + n_iter) of the one-reduction Lanczos recurrence (meld_lanczos_spmv with state[3] = 1,
+ * state[4] = 0; ONE all-reduce of acc [3 * meld_spmm_dot_slots()]; meld_lanczos_fold; meld_lanczos_axpy3; all-gather of
+ * the new vector) on a row shard in one call.  v0 / v1 / v2: FULL-length rotating vectors [world * rows_pad]. */
+int meld_lanczos_steps_sharded(void* comm, const meld_pt_layout_t* layout, const int64_t* rowptr, const int32_t* col,
+                               const double* val, const double* dw, int64_t n_rows, int64_t nnz, int64_t rows_pad, int64_t row_begin,
+                               double* v0, double* v1, double* v2, double* state, double* acc, double* alphas, double* betas,
+                               int it_begin, int n_iter, meld_stream_t stream);
+
 /* ---- KMeans step of VertexFrequencyCluster.predict (reference meld/cluster.py:315-345 -> [UPSTREAM
  *      sklearn.cluster.KMeans], Lloyd iteration; csrc/kmeans.hip) ---------------------------------------
  * One pass over X[n, d] (fp64, d <= 32): labels[i] = nearest of the k <= 64 centroids (ties: lowest index),

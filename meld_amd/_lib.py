@@ -127,6 +127,14 @@ SIGNATURES = {
     "meld_order_starts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),
     "meld_order_pick_centroids": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i32, _i32, _ptr, _ptr]),
     "meld_order_update_keys": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _ptr]),
+    "meld_rccl_available": (_i32, []),
+    "meld_rccl_unique_id": (_i32, [_ptr]),
+    "meld_rccl_comm_create": (_i32, [_ptr, _i32, _i32, _ptr]),
+    "meld_rccl_comm_destroy": (_i32, [_ptr]),
+    "meld_rccl_all_gather": (_i32, [_ptr, _ptr, _ptr, _sz, _ptr]),
+    "meld_rccl_all_reduce_sum_f64": (_i32, [_ptr, _ptr, _sz, _ptr]),
+    "meld_cheby_run_sharded": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _i32, _f64, _f64, _ptr, _ptr]),
+    "meld_lanczos_steps_sharded": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "meld_factorize_max_groups": (_i32, []),
     "meld_factorize_max_words": (_i32, []),
     "meld_factorize_temp_bytes": (_sz, [_i64]),

@@ -43,6 +43,41 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
+    _RCCL = {}  # process group -> the library's RCCL communicator on it (created once: ncclCommInitRank is a collective)
+
+    def rccl(self):
+        """Handle of the library's own RCCL communicator over this group (``meld_rccl_comm_create``), for the C-side recurrence
+        loops (``meld_cheby_run_sharded`` / ``meld_lanczos_steps_sharded``: kernel and collective of every step enqueued from
+        one call), or None when the group does not run on RCCL (gloo, the host-staged test collectives) or the loops are
+        switched off (``MELD_SHARDED_C_LOOPS=0``).  The unique id travels through torch.distributed."""
+        key = id(self.group) if self.group is not None else 0
+        if key in Comm._RCCL:
+            return Comm._RCCL[key]
+        handle = None
+        try:
+            eligible = dist.get_backend(self.group) == "nccl" and torch.cuda.is_available() and os.environ.get("MELD_SHARDED_C_LOOPS", "1") != "0"
+        except Exception:
+            eligible = False
+        if eligible:
+            import ctypes as C
+
+            from ._lib import check, get_lib
+
+            lib = get_lib()
+            # (every rank takes the same branch: the library and its RCCL are the same build on all of them)
+            if lib.meld_rccl_available():
+                buf = C.create_string_buffer(128)
+                if self.rank == 0:
+                    check(lib.meld_rccl_unique_id(buf), "meld_rccl_unique_id")
+                box = [bytes(buf.raw)]
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=self.group)
+                h = C.c_void_p()
+                check(lib.meld_rccl_comm_create(box[0], self.world, self.rank, C.byref(h)), "meld_rccl_comm_create")
+                handle = h
+        Comm._RCCL[key] = handle
+        return handle
+
     def all_gather_rows(self, full, local):
         """full[rank*R:(rank+1)*R] <- local, for every rank (in place when local is that slice)."""
         dist.all_gather_into_tensor(full, local.contiguous(), group=self.group)

@@ -216,6 +216,9 @@ def chebyshev_apply(G, signal, coeffs, lmax):
         if comm is None and c.shape[0] > 2 and hasattr(ops, "cheby_run") and os.environ.get("MELD_CHEBY_RUN", "1") != "0" \
                 and ops.cheby_run(G, p, t_old, t_cur, r, c, 2.0 / a1, -2.0 * a2 / a1):
             return r  # (one call for all the steps; r is read and written every other step only)
+        if comm is not None and c.shape[0] > 2 and hasattr(ops, "cheby_run_sharded") and os.environ.get("MELD_CHEBY_RUN", "1") != "0" \
+                and ops.cheby_run_sharded(G, p, t_old, t_cur, r, c, 2.0 / a1, -2.0 * a2 / a1) is not None:
+            return r  # (row shard on RCCL: kernel + all-gather of every step enqueued from one C call)
         for k in range(2, c.shape[0]):
             # T_k overwrites the local rows of T_{k-2} (z and y alias; read-before-write per element)
             loc = _local(G, t_old)
@@ -438,6 +441,10 @@ def _lanczos_lmax_folded(G, ops, comm, u0, tol, max_iter, check_every):
     examined = 0
     target = min(4 * check_every, max_iter)
     while examined < max_iter:
+        n_batch = min(target + 1, max_iter + 1) - it
+        if comm is not None and n_batch > 0 and hasattr(ops, "lanczos_steps_sharded") \
+                and ops.lanczos_steps_sharded(G, V, state, acc, alphas_d, betas_d, it, n_batch):
+            it += n_batch  # (row shard on RCCL: the whole batch enqueued from one C call)
         while it < min(target + 1, max_iter + 1):
             k = it
             u_prev, u, y = V[k % 3], V[(k + 1) % 3], V[(k + 2) % 3]

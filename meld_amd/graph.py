@@ -1216,6 +1216,46 @@ class HipOps:
         )
         return True
 
+    def cheby_run_sharded(self, G, p, t_prev2, t_prev1, r, coeffs, alpha2, beta2):
+        """Steps 2 .. len(coeffs) - 1 on a row shard in one call (``meld_cheby_run_sharded``: the local rows' kernel and the
+        all-gather of the new slice enqueued back to back from C on the library's own RCCL communicator).  Returns None when
+        the graph's communicator offers no RCCL handle (gloo, host-staged test collectives: the caller steps from Python),
+        else 1 / 0: whether ``t_prev1`` / ``t_prev2`` holds the last T."""
+        comm = getattr(G, "comm", None)
+        handle = comm.rccl() if comm is not None and hasattr(comm, "rccl") else None
+        if handle is None:
+            return None
+        import ctypes as C
+
+        pt = self.pt_layout(G)
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        last = C.c_int(1)
+        check(
+            self.lib.meld_cheby_run_sharded(handle, C.byref(pt["struct"]) if pt is not None else None, ptr(G.rowptr), ptr(G.col), ptr(G.val),
+                                            ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, G.row_begin, p, ptr(t_prev2), ptr(t_prev1), ptr(r),
+                                            c.ctypes.data_as(C.c_void_p), int(c.shape[0]), float(alpha2), float(beta2), C.byref(last), _stream()),
+            "meld_cheby_run_sharded",
+        )
+        return int(last.value)
+
+    def lanczos_steps_sharded(self, G, V, state, acc, alphas, betas, it_begin, n_iter):
+        """Iterations of the one-reduction Lanczos recurrence on a row shard in one call (``meld_lanczos_steps_sharded``); False
+        when the communicator offers no RCCL handle (the caller runs the phases from Python)."""
+        comm = getattr(G, "comm", None)
+        handle = comm.rccl() if comm is not None and hasattr(comm, "rccl") else None
+        if handle is None:
+            return False
+        import ctypes as C
+
+        pt = self.pt_layout(G)
+        check(
+            self.lib.meld_lanczos_steps_sharded(handle, C.byref(pt["struct"]) if pt is not None else None, ptr(G.rowptr), ptr(G.col), ptr(G.val),
+                                                ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, G.row_begin, ptr(V[0]), ptr(V[1]), ptr(V[2]),
+                                                ptr(state), ptr(acc), ptr(alphas), ptr(betas), int(it_begin), int(n_iter), _stream()),
+            "meld_lanczos_steps_sharded",
+        )
+        return True
+
     def lanczos_steps(self, G, V, state, alphas, betas, it_begin, n_iter, scratch, stop=None):
         """Iterations [it_begin, it_begin + n_iter) of the device-resident Lanczos recurrence
         (``meld_lanczos_steps``): V is a [3, N] buffer of rotating vectors.  ``stop`` (int32 device tensor, optional): a launch

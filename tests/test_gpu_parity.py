@@ -265,6 +265,63 @@ print("SHARDED_OK")
     assert "SHARDED_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
+@pytest.mark.parametrize("n", [9000, 80000])
+def test_sharded_recurrences_enqueued_from_c_equal_the_python_loops(n):
+    """On an RCCL group the sharded Chebyshev filter and the sharded Lanczos iterations are ONE C call each
+    (meld_cheby_run_sharded / meld_lanczos_steps_sharded on the library's own communicator: kernel + ncclAllGather (+ the one
+    all-reduce) per step, enqueued back to back); MELD_SHARDED_C_LOOPS=0 restores the per-step Python loops over
+    torch.distributed.  Same lmax and densities either way -- on the CSR-stream kernel (9000 cells) and on the panel-tiled
+    layout (80000 cells) -- and the C path is the one that ran."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import meld_amd
+from meld_amd import distributed as mdist, graph as mgraph
+from oracle import meld_oracle as mo
+n = %d
+X, labels = mo.synthetic_cells(n, n_dims=50, seed=4)
+Xd = torch.from_numpy(X).cuda()
+calls = dict(cheby=0, lanczos=0)
+orig_c, orig_l = mgraph.HipOps.cheby_run_sharded, mgraph.HipOps.lanczos_steps_sharded
+def count_c(self, *a, **k):
+    out = orig_c(self, *a, **k); calls["cheby"] += out is not None; return out
+def count_l(self, *a, **k):
+    out = orig_l(self, *a, **k); calls["lanczos"] += bool(out); return out
+mgraph.HipOps.cheby_run_sharded, mgraph.HipOps.lanczos_steps_sharded = count_c, count_l
+a = meld_amd.MELD(knn=15, chebyshev_order=30)
+da = mdist.fit_transform_sharded(a, Xd, labels)
+assert mdist.Comm().rccl() is not None and calls["cheby"] == 1 and calls["lanczos"] >= 1, calls
+assert a.graph.info["spmm"] == ("tiled" if n >= 65536 else "csr"), a.graph.info["spmm"]
+os.environ["MELD_SHARDED_C_LOOPS"] = "0"
+mdist.Comm._RCCL.clear()
+calls.update(cheby=0, lanczos=0)
+b = meld_amd.MELD(knn=15, chebyshev_order=30)
+db = mdist.fit_transform_sharded(b, Xd, labels)
+assert calls == dict(cheby=0, lanczos=0), calls
+assert abs(a.graph.lmax - b.graph.lmax) <= 1e-12 * b.graph.lmax, (a.graph.lmax, b.graph.lmax)
+assert np.abs(da.values - db.values).max() <= 1e-12 * np.abs(db.values).max()
+c = meld_amd.MELD(knn=15, chebyshev_order=31, lmax=b.graph.lmax)   # an odd number of steps on the single-GPU path
+dc = c.fit_transform(X, labels)
+os.environ["MELD_SHARDED_C_LOOPS"] = "1"
+mdist.Comm._RCCL.clear()
+e = meld_amd.MELD(knn=15, chebyshev_order=31, lmax=b.graph.lmax)
+de = mdist.fit_transform_sharded(e, Xd, labels)
+assert np.abs(de.values - dc.values).max() <= 1e-11 * np.abs(dc.values).max()
+dist.destroy_process_group()
+print("SHARDED_C_OK")
+""" % (root, n)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "SHARDED_C_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
 @pytest.mark.parametrize("nprod", [3, 1])
 @pytest.mark.parametrize("n,d", [(3000, 50), (1500, 100), (2000, 3)])
 def test_knn16_candidates_contain_true_neighbours(n, d, nprod):

@@ -48,6 +48,26 @@ class FakeComm:
         r = send.view(self.world, 2, cap)
         return r[:, 0, :].reshape(-1), r[:, 1, :].reshape(-1).view(torch.float64)
 
+    _handle = None
+
+    def rccl(self):
+        """RCCL=1 (rank 0 only: its slice starts at row 0): a REAL one-rank RCCL communicator of the library, so that the
+        recurrences take the C-side loops (meld_cheby_run_sharded / meld_lanczos_steps_sharded) -- kernel + ncclAllGather
+        (+ ncclAllReduce) enqueued per step from one call; the one-rank collectives move nothing, like the stand-ins above,
+        but cost their real issue time."""
+        if os.environ.get("RCCL") != "1" or self.rank != 0:
+            return None
+        if FakeComm._handle is None:
+            import ctypes as C
+            from meld_amd._lib import check, get_lib
+            lib = get_lib()
+            buf = C.create_string_buffer(128)
+            check(lib.meld_rccl_unique_id(buf), "meld_rccl_unique_id")
+            h = C.c_void_p()
+            check(lib.meld_rccl_comm_create(buf.raw, 1, 0, C.byref(h)), "meld_rccl_comm_create")
+            FakeComm._handle = h
+        return FakeComm._handle
+
 
 if os.environ.get("TRACE"):  # name the stage a fault happens in: synchronise and print after every ops call
     from meld_amd.graph import HipOps
@@ -73,6 +93,8 @@ from meld_amd.graph import HipOps as _HipOps
 _HipOps.shards_spheres = False  # (likewise: stand-in spheres of the other ranks' tiles would wreck the pruning; a real rank computes 1 / world of the 0.7 ms)
 _fold = _mf._lanczos_lmax_folded
 _mf._lanczos_lmax_folded = lambda G, ops, comm, u0, tol, max_iter, check_every: _fold(G, ops, comm, u0, tol, 35, check_every)
+if os.environ.get("RCCL") == "1":
+    print("recurrences through the C-side loops on a one-rank RCCL communicator (RCCL=1)")
 
 from meld_amd.graph import HipOps as _HO
 _pr = _HO.partition_remote
