@@ -63,7 +63,9 @@ class Benchmarker(object):
         kwargs.pop("use_pygsp", None)
         # graphtools accepts more graph keywords than the device builder implements: those are rejected here, by name,
         # instead of being stored and silently ignored (the graph would differ from the reference's for the same call)
-        known = {"knn", "decay", "thresh", "ksel", "sample_idx", "n_landmark", "verbose", "distance"}
+        # (n_jobs and lmax do not change the graph: MELD / GraphEstimator take them, graphtools ran fit_graph(data, n_jobs=-1))
+        known = {"knn", "decay", "thresh", "ksel", "sample_idx", "n_landmark", "verbose", "distance", "n_jobs", "lmax",
+                 "bandwidth", "bandwidth_scale"}
         unknown = sorted(k for k in kwargs if k not in known | {"anisotropy"})
         if unknown:
             raise NotImplementedError("graph options {} are not implemented by the MI355X graph builder".format(unknown))

@@ -439,7 +439,12 @@ class VertexFrequencyCluster:
                         comm.all_gather_rows(t_zy[i], y_loc)
 
         def recurrence(Z0, visit):
-            """visit(k, local rows of T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, R columns as R / 2 pairs)."""
+            """visit(k, local rows of T_k(L~) Z0) for k = 0 .. M (the same fused steps as MELD's filter, R columns as R / 2 pairs).
+            CONTRACT: ``visit`` must consume Tk before it returns and must not keep a reference to it -- on the wide path
+            (R > 32) Tk is a live VIEW of a ping-pong buffer that the step after next overwrites (the pair path happens to hand
+            out a copy); both visitors below accumulate from it at once.  The two paths add a row's products in different
+            orders: features agree to rounding (1e-12), not bit for bit, across the R <= 32 / R > 32 switch
+            (tests/test_gpu_cluster.py::test_filterbank_on_the_wide_kernel_equals_the_pair_path)."""
             t_old = to_pairs(Z0)
             if wide and t_old.data_ptr() == Z0.data_ptr():
                 t_old = t_old.clone()  # (the recurrence writes into its buffers)

@@ -131,16 +131,26 @@ __global__ __launch_bounds__(FZ_THREADS) void fz_merge_kernel(const int* __restr
     D.overflow = 0;
   }
   __syncthreads();
-  const int total = n_chunks * FZ_MAXG;
-  for (int b0 = 0; b0 < total; b0 += FZ_THREADS) {
-    const int i = b0 + tid;
-    const int c = i / FZ_MAXG, e = i % FZ_MAXG;
-    const bool valid = i < total && e < d_n[c];
-    int L[FZ_MAXW];
+  // (thread = chunk, round e = the chunks' e-th entries: as many rounds as the longest chunk dictionary -- two for two labels --
+  // instead of one per 256 slots of the n_chunks x FZ_MAXG table: 149 -> a few us at 1M cells)
+  __shared__ int s_more;
+  for (int c0 = 0; c0 < n_chunks; c0 += FZ_THREADS) {
+    const int c = c0 + tid;
+    const int nc = c < n_chunks ? d_n[c] : 0;
+    for (int e = 0; e < FZ_MAXG; ++e) {
+      if (tid == 0) s_more = 0;
+      __syncthreads();
+      const bool valid = e < nc;
+      if (valid) s_more = 1;
+      __syncthreads();
+      if (!s_more) break;  // (uniform; the barrier inside fz_batch separates this read from the next round's reset)
+      const int i = c * FZ_MAXG + e;
+      int L[FZ_MAXW];
 #pragma unroll
-    for (int w = 0; w < FZ_MAXW; ++w) L[w] = (valid && w < W) ? d_words[(size_t)i * FZ_MAXW + w] : 0;
-    const int code = fz_batch(D, valid, L, W, valid ? d_first[i] : 0ull, valid ? d_count[i] : 0ull);
-    if (i < total) remap[i] = code;
+      for (int w = 0; w < FZ_MAXW; ++w) L[w] = (valid && w < W) ? d_words[(size_t)i * FZ_MAXW + w] : 0;
+      const int code = fz_batch(D, valid, L, W, valid ? d_first[i] : 0ull, valid ? d_count[i] : 0ull);
+      if (valid) remap[i] = code;
+    }
   }
   __syncthreads();
   if (tid == 0) {

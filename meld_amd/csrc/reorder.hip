@@ -8,6 +8,8 @@
 // kernel is its only device-side arithmetic: nearest of a small set of centroids for every cell.
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <rocprim/rocprim.hpp>
 
 #include <cstdlib>
@@ -428,16 +430,52 @@ __global__ __launch_bounds__(256) void order_update_keys_kernel(uint32_t* __rest
 
 using namespace meld;
 
+// rocPRIM sorts fewer than 2^20 pairs of 32-bit keys by a block sort + ~10 merge passes (its radix_sort dispatch: 1M cells fall
+// just below the limit -- 23 launches, 165 us per argsort, three per ordering); for keys of at most 16 bits it takes the
+// onesweep radix path from 100k elements on (histogram, scan, one pass per 8 bits).  The ordering's keys are group numbers
+// below 2^16, so they are narrowed to 16 bits for the sort and widened again behind it: ~60 us per argsort at 1M cells.
+namespace meld {
+__global__ __launch_bounds__(256) void narrow_keys_kernel(const uint32_t* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint16_t)in[i];
+}
+__global__ __launch_bounds__(256) void widen_keys_kernel(const uint16_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+constexpr int64_t ARGSORT_NARROW_MIN = 100000;  // rocPRIM's own bound for the 16-bit path
+static size_t argsort_round(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace meld
+
 extern "C" size_t meld_argsort_u32_temp_bytes(int64_t n) {
-  size_t bytes = 0;
+  size_t bytes = 0, bytes16 = 0;
   uint32_t* k = nullptr;
+  uint16_t* k16 = nullptr;
   int64_t* v = nullptr;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, rocprim::make_counting_iterator<int64_t>(0), v, (size_t)n, 0u, 32u);
-  return bytes + 256;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes16, k16, k16, rocprim::make_counting_iterator<int64_t>(0), v, (size_t)n, 0u, 16u);
+  // (the narrow path: two 16-bit key arrays in front of rocPRIM's own scratch)
+  return std::max(bytes, argsort_round(bytes16) + 2 * argsort_round((size_t)n * 2)) + 512;
 }
 extern "C" int meld_argsort_u32(const uint32_t* keys, int64_t n, int end_bit, int64_t* order, uint32_t* keys_sorted, void* temp,
                                 size_t temp_bytes, meld_stream_t stream) {
   MELD_CHECK_ARG(keys && order && keys_sorted && temp && n > 0 && end_bit > 0 && end_bit <= 32, "meld_argsort_u32: bad arguments");
+  MELD_CHECK_ARG(temp_bytes >= meld_argsort_u32_temp_bytes(n), "meld_argsort_u32: temp too small");
+  if (end_bit <= 16 && n >= ARGSORT_NARROW_MIN) {
+    char* p = reinterpret_cast<char*>(temp);
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~(uintptr_t)255);
+    uint16_t* k_in = reinterpret_cast<uint16_t*>(p);
+    uint16_t* k_out = reinterpret_cast<uint16_t*>(p + argsort_round((size_t)n * 2));
+    void* scratch = p + 2 * argsort_round((size_t)n * 2);
+    size_t bytes = temp_bytes - (size_t)(reinterpret_cast<char*>(scratch) - reinterpret_cast<char*>(temp));
+    const unsigned grid = (unsigned)ceil_div(n, 256);
+    hipLaunchKernelGGL(narrow_keys_kernel, dim3(grid), dim3(256), 0, S(stream), keys, k_in, n);
+    MELD_HIP_CALL(rocprim::radix_sort_pairs(scratch, bytes, k_in, k_out, rocprim::make_counting_iterator<int64_t>(0), order, (size_t)n,
+                                            0u, (unsigned)end_bit, S(stream)));
+    hipLaunchKernelGGL(widen_keys_kernel, dim3(grid), dim3(256), 0, S(stream), k_out, keys_sorted, n);
+    MELD_LAUNCH_CHECK("meld_argsort_u32");
+    return MELD_OK;
+  }
   size_t bytes = temp_bytes;
   MELD_HIP_CALL(rocprim::radix_sort_pairs(temp, bytes, keys, keys_sorted, rocprim::make_counting_iterator<int64_t>(0), order, (size_t)n,
                                           0u, (unsigned)end_bit, S(stream)));

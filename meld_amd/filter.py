@@ -285,7 +285,7 @@ class _LanczosHostSide:
     """What the host's half of the device-resident Lanczos loop keeps per device: a side stream that carries the tridiagonal
     entries to a pinned buffer behind every batch of iterations, so that the main stream never waits for a convergence check."""
 
-    _per_device = {}
+    _local = None  # threading.local: one (side stream, pinned buffer) per thread and device, released when the thread ends
 
     def __init__(self, dev, max_iter):
         self.side = torch.cuda.Stream(device=dev)
@@ -295,11 +295,15 @@ class _LanczosHostSide:
     def of(cls, dev, max_iter):
         import threading
 
-        # (per thread as well: two estimates running side by side must not share the pinned buffer)
-        key = (threading.get_ident(), torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
-        h = cls._per_device.get(key)
+        # (per thread: two estimates running side by side must not share the pinned buffer; thread-local storage rather than a
+        # table keyed by thread id -- ids are recycled and a table is never pruned)
+        if cls._local is None:
+            cls._local = threading.local()
+        table = cls._local.__dict__.setdefault("per_device", {})
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        h = table.get(key)
         if h is None or h.ab.shape[1] < max_iter:
-            h = cls._per_device[key] = cls(dev, max_iter)
+            h = table[key] = cls(dev, max_iter)
         return h
 
 
