@@ -252,7 +252,10 @@ int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t 
                     const float* norm2_max, double err_coef,
                     const float* norm2 /* [N] per-row |x~|^2 or NULL */, double err_coef_lin, double* bw,
                     double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
-                    const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream);
+                    const int32_t* rows, int out_cap, int32_t* cand_idx_out,
+                    double bw_scale /* graphtools' bandwidth_scale: the kernel uses max(bw * bw_scale, eps); bw[] records the unscaled value */,
+                    const double* bw_fixed /* [N] graphtools' bandwidth= (a given bandwidth per cell, knn then only sizes the search), or NULL */,
+                    meld_stream_t stream);
 
 /* Exact fp64 radius search for the flagged rows (the analogue of graphtools' re-search /
  * radius_neighbors fallback), rows x reference chunks over the whole device.  mode 0: fb_cnt[f] = number
@@ -262,7 +265,9 @@ int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t 
 int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, const int32_t* flag_rows,
                           int32_t n_flag, const double* bw, int knn, double decay, double thresh,
                           int mode, int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor,
-                          int32_t* fb_col, double* fb_val, int32_t* err_flag, meld_stream_t stream);
+                          int32_t* fb_col, double* fb_val, int32_t* err_flag,
+                          double bw_scale /* as in meld_knn_refine: bw[] is unscaled; with a fixed bandwidth pass knn = INT32_MAX (nothing to verify) */,
+                          meld_stream_t stream);
 /* out[i][c] = |X[rows[i]] - X[cand[i][c]]| (rows, cand: global row numbers; cand [n][kk]) in the summation order of meld_knn_refine
  * and meld_knn_radius_exact: a bandwidth ranked from these is one the sweep confirms (it counts the references strictly closer
  * in this arithmetic; a library norm differs by a few ulps at d ~ 50). */

@@ -2504,10 +2504,12 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && cand_idx && cand_d2 && cand_cnt, "meld_knn16_topk: null pointer");
   MELD_CHECK_ARG(lb2 == nullptr || norm2_max != nullptr, "meld_knn16_topk: pruning needs norm2_max");
   // radius cut (cand_thr != NULL): rows are cut at the kernel radius implied by their knn-th neighbour so far
-  MELD_CHECK_ARG(cand_thr == nullptr || (norm2_max != nullptr && knn >= 1 && knn < ksel && radius_factor >= 1.0),
-                 "meld_knn16_topk: the radius cut needs norm2_max, 1 <= knn < ksel, radius_factor >= 1");
-  const int knn1 = cand_thr ? knn + 1 : 0;
-  const float rf2 = cand_thr ? (float)(radius_factor * radius_factor * (1.0 + 1e-6)) : 0.0f;
+  // (knn == 0 with cand_thr: the final thresholds are published but no row is cut -- a search whose radii are fixed by the
+  // caller's start thresholds, graphtools' `bandwidth=`)
+  MELD_CHECK_ARG(cand_thr == nullptr || (norm2_max != nullptr && knn >= 0 && knn < ksel && radius_factor >= 1.0),
+                 "meld_knn16_topk: the radius cut needs norm2_max, 0 <= knn < ksel, radius_factor >= 1");
+  const int knn1 = (cand_thr && knn >= 1) ? knn + 1 : 0;
+  const float rf2 = knn1 > 0 ? (float)(radius_factor * radius_factor * (1.0 + 1e-6)) : 0.0f;
   const float err_c = (float)meld_knn16_error_coef_const(nprod, d), err_l = (float)meld_knn16_error_coef_lin(nprod);
   MELD_CHECK_ARG(n_ref > 0 && n_ref < (int64_t)1 << 31 && q_count > 0, "meld_knn16_topk: bad sizes");
   const int cap = meld_knn16_row_capacity(ksel);

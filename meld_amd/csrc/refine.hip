@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
     const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, const float* __restrict__ cand_thr, int ksel,
     int cap, int knn, double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
-    const float* __restrict__ norm2, double err_coef_lin,
+    const float* __restrict__ norm2, double err_coef_lin, double bw_scale, const double* __restrict__ bw_fixed,
     double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
     int* __restrict__ flag_rows, int* __restrict__ n_flag, const int* __restrict__ rows, int out_cap,
     int* __restrict__ cand_idx_out) {
@@ -66,8 +66,16 @@ __global__ __launch_bounds__(256) void refine_kernel(
   // d2, the exact (knn+1)-th distance^2 is <= approx[knn] + E, so radius^2 <= rf^2 (approx[knn] + E), and
   // a candidate with approx > rf^2 (approx[knn] + E) + E has exact d2 > radius^2 (>= bandwidth^2): it
   // ranks behind the bandwidth entry and its kernel value is below thresh either way.
+  // (graphtools' `bandwidth_scale` s multiplies the bandwidth, hence the radius: the bound uses max(rf s, 1) so that it never
+  // falls below the bandwidth entry itself; a FIXED bandwidth -- graphtools' `bandwidth=` -- fixes the radius outright)
   double skip_above = INFINITY;
-  if (n > knn) skip_above = radius_factor * radius_factor * ((double)cand_d2[ro + knn] + E) + E;
+  const double skip_factor = fmax(radius_factor * bw_scale, 1.0);
+  if (bw_fixed != nullptr) {
+    const double rfix = fmax(bw_fixed[gi] * bw_scale, DBL_EPSILON) * radius_factor;
+    skip_above = rfix * rfix * (1.0 + 1e-12) + E;
+  } else if (n > knn) {
+    skip_above = skip_factor * skip_factor * ((double)cand_d2[ro + knn] + E) + E;
+  }
 
   double dist[2];
   int idx[2];
@@ -149,17 +157,22 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const unsigned long long b = __ballot((lane + 64 * e) < n && rk[e] == knn);
     if (b) bw = __shfl(dist[e], __ffsll((long long)b) - 1, 64);
   }
-  bw = fmax(bw, DBL_EPSILON);
+  if (bw_fixed != nullptr) bw = bw_fixed[gi];
+  bw = fmax(bw, DBL_EPSILON);       // what is recorded: the k-th neighbour distance (or the given bandwidth), unscaled
+  const double bw_raw = bw;
+  bw = fmax(bw * bw_scale, DBL_EPSILON);  // what the kernel uses [UPSTREAM build_kernel_to_data: bandwidth * bandwidth_scale, then max(., eps)]
 
-  // completeness test in squared-distance space
+  // completeness test in squared-distance space: everything inside the radius -- and, for the adaptive bandwidth, the
+  // bandwidth entry itself (a scale below 1 / rf puts the radius inside it) -- must be certified present
   const double radius = bw * radius_factor;
+  const double reach = bw_fixed != nullptr ? radius : fmax(radius, bw_raw);
   // tau: every reference that is not in the list has approximate d2 >= tau -- the last entry of a full
   // list, or the threshold the search published for a row it cut at the kernel radius (cand_thr)
   double tau = INFINITY;
   if (cand_cnt[q] >= ksel) tau = (double)cand_d2[ro + ksel - 1];
   if (cand_thr != nullptr) tau = fmin(tau, (double)cand_thr[q]);
-  bool complete = (radius * radius + E <= tau);
-  if (n <= knn) complete = false;  // cannot even define the bandwidth from this list
+  bool complete = (reach * reach + E <= tau);
+  if (bw_fixed == nullptr && n <= knn) complete = false;  // cannot even define the bandwidth from this list
 
   int kept = 0;
 #pragma unroll
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     kept += __popcll(__ballot(v > 0.0));
   }
   if (lane == 0) {
-    bw_out[orow] = bw;
+    bw_out[orow] = bw_raw;
     keep_cnt[orow] = complete ? kept : 0;
     if (!complete) {
       const int pos = atomicAdd(n_flag, 1);
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
     int n_flag, const double* __restrict__ bw_all, int knn, double decay, double thresh, int mode,
     int* __restrict__ fb_cnt, const int64_t* __restrict__ fb_off, int* __restrict__ fb_cursor,
     int* __restrict__ fb_col, double* __restrict__ fb_val, int* __restrict__ err_flag, int64_t ref_chunk,
-    double radius_factor) {
+    double radius_factor, double bw_scale) {
   extern __shared__ double xq[];  // [RB_FALL][d]
   __shared__ int s_cnt[RB_FALL];
   __shared__ int s_lt[RB_FALL];
@@ -204,12 +217,13 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
   const int64_t ref_lo = (int64_t)blockIdx.y * ref_chunk;
   const int64_t ref_hi = min(N, ref_lo + ref_chunk);
   int64_t gi[RB_FALL];
-  double bw[RB_FALL], rad[RB_FALL];
+  double bw[RB_FALL], rad[RB_FALL], bw_chk[RB_FALL];
 #pragma unroll
   for (int f = 0; f < RB_FALL; ++f) {
     const int q = flag_rows[f0 + (f < nf ? f : 0)];
     gi[f] = q_begin + q;
-    bw[f] = bw_all[q];
+    bw_chk[f] = bw_all[q];                             // the recorded (unscaled) bandwidth: what the count of closer cells verifies
+    bw[f] = fmax(bw_all[q] * bw_scale, DBL_EPSILON);   // the bandwidth of the kernel (refine_kernel's scaling)
     // beyond this distance the kernel value is certainly below thresh (the radius, with a margin far above the
     // rounding of pow/exp): exp and pow are evaluated for the few references inside it only -- evaluating them
     // for every (row, reference) pair made the sweep 20x slower than its distance arithmetic
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
     for (int f = 0; f < RB_FALL; ++f) {
       if (f < nf) {
         const double dist = sqrt(s[f]);
-        if (dist < bw[f]) lt[f]++;
+        if (dist < bw_chk[f]) lt[f]++;
         if (dist > rad[f]) continue;
         const double v = decay_kernel(dist, bw[f], decay);
         if (v >= thresh && ref != gi[f]) {
@@ -333,7 +347,8 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
                                int cap, int knn, double decay, double thresh, const float* norm2_max, double err_coef,
                                const float* norm2, double err_coef_lin, double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
-                               const int32_t* rows, int out_cap, int32_t* cand_idx_out, meld_stream_t stream) {
+                               const int32_t* rows, int out_cap, int32_t* cand_idx_out, double bw_scale, const double* bw_fixed,
+                               meld_stream_t stream) {
   MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
                  "meld_knn_refine: null pointer");
   MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && d > 0 && (rows != nullptr || q_begin + q_count <= N),
@@ -344,10 +359,11 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(knn >= 0 && decay > 0 && thresh > 0 && thresh <= 1, "meld_knn_refine: bad kernel parameters");
   MELD_CHECK_ARG(cap >= ksel, "meld_knn_refine: row stride cap=%d smaller than ksel=%d", cap, ksel);
   MELD_CHECK_ARG(err_coef >= 0 && err_coef_lin >= 0, "meld_knn_refine: error coefficients must be non-negative");
+  MELD_CHECK_ARG(bw_scale > 0 && bw_scale < INFINITY, "meld_knn_refine: bandwidth_scale must be positive and finite");
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
                      q_count, cand_idx, cand_d2, cand_cnt, cand_thr, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
-                     err_coef, norm2, err_coef_lin, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
+                     err_coef, norm2, err_coef_lin, bw_scale, bw_fixed, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
                      cand_idx_out);
   MELD_LAUNCH_CHECK("refine_kernel");
   return MELD_OK;
@@ -356,8 +372,9 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
 extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, const int32_t* flag_rows,
                                      int32_t n_flag, const double* bw, int knn, double decay, double thresh, int mode,
                                      int32_t* fb_cnt, const int64_t* fb_off, int32_t* fb_cursor, int32_t* fb_col,
-                                     double* fb_val, int32_t* err_flag, meld_stream_t stream) {
+                                     double* fb_val, int32_t* err_flag, double bw_scale, meld_stream_t stream) {
   if (n_flag == 0) return MELD_OK;
+  MELD_CHECK_ARG(bw_scale > 0 && bw_scale < INFINITY, "meld_knn_radius_exact: bandwidth_scale must be positive and finite");
   MELD_CHECK_ARG(X && flag_rows && bw && n_flag > 0 && N > 0 && d > 0, "meld_knn_radius_exact: bad arguments");
   MELD_CHECK_ARG(mode == 0 ? (fb_cnt && err_flag && fb_cursor) : (fb_off && fb_cursor && fb_col && fb_val),
                  "meld_knn_radius_exact: missing output for mode %d", mode);
@@ -374,7 +391,7 @@ extern "C" int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t 
   }
   hipLaunchKernelGGL(radius_exact_kernel, dim3((unsigned)n_groups, (unsigned)n_chunks), dim3(256), lds, st, X, N, d, q_begin,
                      flag_rows, n_flag, bw, knn, decay, thresh, mode, fb_cnt, fb_off, fb_cursor, fb_col, fb_val, err_flag,
-                     ref_chunk, pow(-log(thresh), 1.0 / decay));
+                     ref_chunk, pow(-log(thresh), 1.0 / decay), bw_scale);
   if (mode == 0)
     hipLaunchKernelGGL(radius_check_kernel, dim3((unsigned)ceil_div(n_flag, 256)), dim3(256), 0, st, fb_cursor, n_flag, knn,
                        err_flag, flag_rows, bw, fb_cnt);

@@ -457,14 +457,20 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
-    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None):
+    def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
+                            bw_scale=1.0, bw_fixed=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
         ``n_refs``: search BETWEEN two point sets (the cross blocks of the MNN kernel, ``meld_amd.mnn``): the references
         are the rows [0, n_refs) of X only, the queries lie behind them, there is no self among a row's candidates --
         the caller passes knn - 1 so that the bandwidth is the knn-th nearest reference.  No pruning table, no seeds
-        (both rest on tile = query block)."""
+        (both rest on tile = query block).
+
+        ``bw_scale`` / ``bw_fixed`` ([UPSTREAM graphtools kNNGraph ``bandwidth_scale`` / ``bandwidth``, forwarded by reference
+        ``meld/meld.py:106,117-118``): the kernel uses ``max(bw * bw_scale, eps)``; ``bw_fixed`` (fp64 device tensor [N], in
+        the order of ``X``) replaces the adaptive k-th-neighbour bandwidth -- the kernel radius of every row is then known
+        before the search, which starts its thresholds there and cuts nothing on its own."""
         lib, st, dev = self.lib, _stream(), X.device
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
@@ -565,6 +571,8 @@ class HipOps:
                 # publishes each row's final threshold for refine's completeness test
                 cand_thr = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
                 rfac = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
+                # (the cut keeps everything within max(rf * bandwidth_scale, 1) bandwidths: never less than the bandwidth entry)
+                rfac = max(rfac * float(bw_scale), 1.0)
             lb2 = block_order = step_list = step_cnt = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
@@ -583,7 +591,20 @@ class HipOps:
                     if tail_slices > 1:
                         q_main = (n_blocks - tail_blocks) * BQ
             seeds = None
-            if self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1 and not cross:
+            knn_cut = knn  # the radius cut of the search follows the knn-th neighbour ...
+            if bw_fixed is not None and cand_thr is not None:
+                # ... unless the bandwidth is given: every row's radius is known, the thresholds start there (scaled units, with
+                # the row's search-error allowance on top) and the search cuts nothing itself (knn_cut = 0)
+                knn_cut = 0
+                rf_real = 1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))
+                rad = (bw_fixed[q_begin : q_begin + q_count] * float(bw_scale)).clamp_(min=float(np.finfo(float).eps)) * rf_real
+                nmx = nmax.to(torch.float64)
+                e_row = float(err_coef) * nmx + float(err_lin) * torch.sqrt(norm2[q_begin : q_begin + q_count].to(torch.float64) * nmx)
+                seeds = torch.full((q_pad,), float("inf"), dtype=torch.float32, device=dev)
+                seeds[:q_count] = ((rad * rad + 1.01 * e_row) * scale_info[0].to(torch.float64) ** 2 * (1.0 + 1e-5)).to(torch.float32)
+                if q_pad > q_count:
+                    seeds[q_count:] = seeds[q_count - 1]
+            elif self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1 and not cross:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
                 if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
@@ -674,16 +695,16 @@ class HipOps:
                     s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
                     s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
                     if step_list is not None:
-                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
+                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
                     else:
-                        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
+                        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
                     check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_main, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
                 elif step_list is not None:
-                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
+                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
                 else:
-                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
+                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
                 # until its results are refined: work that does not depend on the graph (fit_transform's label
                 # factorisation: a host-blocking copy + a few small launches on a side stream) is started here
@@ -748,7 +769,7 @@ class HipOps:
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ksel, cap, knn, float(decay),
                 float(thresh), ptr(nmax_used), float(err_coef), ptr(norm2), float(err_lin), ptr(bw), ptr(cand_val), ptr(keep_cnt),
-                ptr(flag_rows), ptr(n_flag), None, 0, None, st,
+                ptr(flag_rows), ptr(n_flag), None, 0, None, float(bw_scale), ptr(bw_fixed), st,
             ),
             "meld_knn_refine",
         )
@@ -796,7 +817,7 @@ class HipOps:
                 lib.meld_knn_refine(
                     ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, ksel, cap, knn, float(decay),
                     float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3, d)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
-                    ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), st,
+                    ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), float(bw_scale), ptr(bw_fixed), st,
                 ),
                 "meld_knn_refine(stage 2)",
             )
@@ -826,12 +847,13 @@ class HipOps:
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
-                                           assemble=assemble)
+                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
 
         # exact sweep for rows the candidate list could not certify
+        knn_chk = knn if bw_fixed is None else 2**31 - 1  # (a given bandwidth is not verified against the neighbour count)
         n_rebandwidth = 0
         fb_total = 0
         fb_off = fb_col = fb_val = None
@@ -842,8 +864,8 @@ class HipOps:
             cursor = torch.zeros(n_flag_h, dtype=torch.int32, device=dev)  # count pass: references closer than bw
             check(
                 lib.meld_knn_radius_exact(
-                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
-                    ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
+                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn_chk, float(decay), float(thresh), 0,
+                    ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), float(bw_scale), st,
                 ),
                 "meld_knn_radius_exact(count)",
             )
@@ -860,8 +882,8 @@ class HipOps:
                 err.zero_()
                 check(
                     lib.meld_knn_radius_exact(
-                        ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 0,
-                        ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), st,
+                        ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn_chk, float(decay), float(thresh), 0,
+                        ptr(fb_cnt), None, ptr(cursor), None, None, ptr(err), float(bw_scale), st,
                     ),
                     "meld_knn_radius_exact(recount)",
                 )
@@ -882,8 +904,8 @@ class HipOps:
             fb_val = torch.empty(max(fb_total, 1), dtype=torch.float64, device=dev)
             check(  # (the count pass left the cursors at zero)
                 lib.meld_knn_radius_exact(
-                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn, float(decay), float(thresh), 1,
-                    None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, st,
+                    ptr(X), NR, d, q_begin, ptr(flag_rows), n_flag_h, ptr(bw), knn_chk, float(decay), float(thresh), 1,
+                    None, ptr(fb_off), ptr(cursor), ptr(fb_col), ptr(fb_val), None, float(bw_scale), st,
                 ),
                 "meld_knn_radius_exact(fill)",
             )
@@ -1381,7 +1403,7 @@ def resolve_graph_params(N, knn, thresh, ksel):
 
 
 def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
-                    reorder=True):
+                    reorder=True, bandwidth=None, bandwidth_scale=1.0):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -1396,6 +1418,23 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     ops = HipOps(X.device)
     tm = _Timer(profile)
     knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
+    # [UPSTREAM graphtools kNNGraph(bandwidth=, bandwidth_scale=)]: a given bandwidth (one number or one per cell) replaces the
+    # distance to the knn-th neighbour; either way it is multiplied by bandwidth_scale and floored at eps
+    bw_scale = float(bandwidth_scale)
+    if not (bw_scale > 0 and math.isfinite(bw_scale)):
+        raise ValueError("bandwidth_scale must be positive and finite, got {!r}".format(bandwidth_scale))
+    bw_fixed = None
+    if bandwidth is not None:
+        if callable(bandwidth):
+            raise NotImplementedError("a callable bandwidth is not implemented by the MI355X graph builder")
+        b = torch.as_tensor(np.asarray(bandwidth, dtype=np.float64)).to(X.device)
+        if b.dim() == 0:
+            b = b.expand(N)
+        if tuple(b.shape) != (N,):
+            raise ValueError("bandwidth must be a number or have one entry per cell ({}), got shape {}".format(N, tuple(b.shape)))
+        if not bool(torch.isfinite(b).all()) or bool((b < 0).any()):
+            raise ValueError("bandwidth must be finite and non-negative")
+        bw_fixed = b.contiguous().clone()
 
     perm = None
     if reorder:
@@ -1405,9 +1444,14 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         perm = locality_permutation(X)
         if perm is not None:
             X = ops.gather_rows(X, perm)
+            if bw_fixed is not None:
+                bw_fixed = bw_fixed.index_select(0, perm).contiguous()
         tm.stop("reorder")
 
-    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True)
+    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
+                                                   bw_scale=bw_scale, bw_fixed=bw_fixed)
+    if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
+        bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:
         raise ValueError("the kernel has no off-diagonal entries; cannot build a graph")
     tm.start()

@@ -130,7 +130,7 @@ class MELD(GraphEstimator):
 
         opts = dict(self.kwargs)
         opts.update(kwargs)
-        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx")]
+        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx", "bandwidth", "bandwidth_scale")]
         if unsupported:
             raise NotImplementedError(
                 "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
@@ -159,6 +159,11 @@ class MELD(GraphEstimator):
 
         # (the metric enters through the data: cosine = the euclidean graph of the unit rows with the decay doubled)
         X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
+        bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale") if opts.get(k) is not None}
+        if bw_opts and (opts.get("sample_idx") is not None or self.thresh == 0 or self.decay is None
+                        or str(self.distance).lower() not in ("euclidean", "l2")):
+            raise NotImplementedError("bandwidth / bandwidth_scale are implemented for the sparse euclidean alpha-decay kNN graph only "
+                                      "(not with sample_idx, thresh=0, decay=None or another distance)")
         if opts.get("sample_idx") is not None:
             # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
             if self.thresh == 0:
@@ -180,7 +185,7 @@ class MELD(GraphEstimator):
         G = build_knn_graph(
             X, knn=self.knn, decay=float("inf") if decay_m is None else decay_m,  # None: unweighted kNN graph
             thresh=self.thresh, anisotropy=self.anisotropy,
-            ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)),
+            ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)), **bw_opts,
         )
         G.bandwidth_to_metric = bw_to_metric
         # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the

@@ -73,8 +73,15 @@ def knn_kernel(
     algorithm="ball_tree",
     return_intermediates=False,
     distance="euclidean",
+    bandwidth=None,
+    bandwidth_scale=1.0,
 ):
     """Directed alpha-decay kernel K (CSR, N x N, includes K_ii = 1).
+
+    ``bandwidth`` / ``bandwidth_scale`` ([UPSTREAM graphtools ``kNNGraph(bandwidth=, bandwidth_scale=)``, forwarded by reference
+    ``meld/meld.py:106,117-118``; ``build_kernel_to_data``: ``if bandwidth is None: bandwidth = distances[:, knn - 1]``, then
+    ``bandwidth = bandwidth * bandwidth_scale`` and ``np.maximum(bandwidth, eps)``]): a number or one value per cell replaces
+    the adaptive bandwidth; the scale multiplies whichever is used.
 
     ``distance``: the metric handed to sklearn's ``NearestNeighbors`` ([UPSTREAM graphtools ``kNNGraph.knn_tree``: the ball tree
     with ``metric=self.distance``, ``algorithm="auto"`` when the tree does not take that metric -- "cosine" is brute force]).
@@ -117,7 +124,11 @@ def knn_kernel(
 
     search_knn = min(k1 * search_multiplier, knn_max)
     distances, indices = tree.kneighbors(X, n_neighbors=search_knn)
-    bandwidth = distances[:, k1 - 1].copy()
+    if bandwidth is None:
+        bandwidth = distances[:, k1 - 1].copy()
+    else:
+        bandwidth = np.broadcast_to(np.asarray(bandwidth, dtype=np.float64), (N,)).copy()
+    bandwidth = bandwidth * bandwidth_scale
     bandwidth = np.maximum(bandwidth, np.finfo(float).eps)
     radius = bandwidth * np.power(-1 * np.log(thresh), 1 / decay)
     update_idx = np.argwhere(np.max(distances, axis=1) < radius).reshape(-1)
@@ -477,7 +488,8 @@ def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, 
     return K
 
 
-def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean"):
+def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean",
+                bandwidth=None, bandwidth_scale=1.0):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
     ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
     ``pca_reduce`` first.  ``sample_idx``: the MNN kernel between samples (``mnn_kernel``)."""
@@ -498,7 +510,8 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         W = weights_from_kernel(K)
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
-    Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True, distance=distance)
+    Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True, distance=distance,
+                          bandwidth=bandwidth, bandwidth_scale=bandwidth_scale)
     K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
     K.sort_indices()
     W = weights_from_kernel(K)

@@ -137,6 +137,56 @@ def test_graph_matches_oracle(n, d, knn):
     np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,d,knn", [(6000, 50, 15), (20000, 10, 5)])
+@pytest.mark.parametrize("opt", ["scale0.6", "scale0.93", "scale1.3", "fixed", "fixed_per_cell", "fixed_scaled"])
+def test_bandwidth_options_match_the_oracle(n, d, knn, opt):
+    """graphtools' ``bandwidth`` / ``bandwidth_scale`` (forwarded by reference meld/meld.py:106,117-118): a scaled adaptive
+    bandwidth -- also below 1 / rf, where the kernel radius lies inside the bandwidth entry -- and a given bandwidth (one
+    number, one per cell, scaled): W, K and the degrees equal the oracle's restatement of ``build_kernel_to_data``; at
+    20000 cells the pruned, list-driven search runs with the start thresholds the options imply."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=6)
+    base = mo.knn_kernel(X, knn=knn, algorithm="brute", return_intermediates=True)[1]["bandwidth"]
+    rng = np.random.default_rng(1)
+    kw = {
+        "scale0.6": dict(bandwidth_scale=0.6), "scale0.93": dict(bandwidth_scale=0.93), "scale1.3": dict(bandwidth_scale=1.3),
+        "fixed": dict(bandwidth=float(np.median(base))),
+        "fixed_per_cell": dict(bandwidth=base * rng.uniform(0.7, 1.2, size=n)),
+        "fixed_scaled": dict(bandwidth=float(np.median(base)), bandwidth_scale=0.8),
+    }[opt]
+    G = mo.build_graph(X, knn=knn, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute", **kw)
+    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=40, thresh=1e-4, anisotropy=1, **kw)
+    _csr_close(DG.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
+    _csr_close(DG.K, G.K, rtol=1e-9)
+    np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
+    if n >= 16384:
+        assert DG.info["prune"] and DG.info["step_lists"]
+    # and through the estimator, as the reference forwards them
+    if n == 6000 and opt in ("scale0.93", "fixed"):
+        samples, dens, Go = mo.fit_transform(X, labels, knn=knn, chebyshev_order=20, return_graph=True, algorithm="brute")  # (lmax only)
+        Gk = mo.build_graph(X, knn=knn, algorithm="brute", **kw)
+        ind = mo.sample_indicators(labels)[1]
+        dens = mo.meld_filter(ind, Gk, chebyshev_order=20)
+        out = meld_amd.MELD(knn=knn, chebyshev_order=20, lmax=Gk.lmax, verbose=0, **kw).fit_transform(X, labels)
+        assert _rel(out.values, dens) < 1e-5
+
+
+def test_bandwidth_options_are_refused_where_they_are_not_built():
+    import meld_amd
+
+    X = np.random.default_rng(0).normal(size=(400, 5))
+    for extra in (dict(thresh=0), dict(decay=None), dict(sample_idx=np.arange(400) % 2), dict(distance="cosine")):
+        with pytest.raises(NotImplementedError):
+            meld_amd.MELD(bandwidth_scale=0.5, verbose=0, **extra).fit(X)
+    with pytest.raises(ValueError):
+        meld_amd.MELD(bandwidth_scale=-1.0, verbose=0).fit(X)
+    with pytest.raises(ValueError):
+        meld_amd.MELD(bandwidth=np.ones(7), verbose=0).fit(X)
+
+
 def test_graph_exact_sweep_path_matches_main_path():
     """Rows sent through the exact fp64 sweep give the same graph as certified candidate rows."""
     mo = _oracle()
