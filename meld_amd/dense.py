@@ -20,23 +20,15 @@ import torch
 
 from .graph import DeviceGraph
 
-__all__ = ["build_dense_graph", "exact_filter", "DENSE_MAX_N"]
+__all__ = ["build_dense_graph", "build_precomputed_graph", "exact_filter", "DENSE_MAX_N"]
 
 DENSE_MAX_N = 16384
 
 
-def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
-    N = int(X.shape[0])
-    if N > DENSE_MAX_N:
-        raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
-    if knn > N - 2:
-        knn = N - 2
-    X = X.to(torch.float64)
-    D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
-    D.fill_diagonal_(0.0)
-    bw = torch.kthvalue(D, knn + 1, dim=1).values
-    K = torch.exp(-torch.pow(D / bw[:, None], decay))
-    K = torch.where(torch.isnan(K), torch.ones_like(K), K)
+def _graph_from_dense_kernel(K, anisotropy, bw, info):
+    """Directed dense kernel K [N, N] (device fp64) -> DeviceGraph: (K + K^T) / 2, anisotropy, zero diagonal
+    [UPSTREAM graphtools ``BaseGraph._build_kernel`` / ``symmetrize_kernel`` / ``apply_anisotropy``]."""
+    N = int(K.shape[0])
     K = (K + K.T) / 2
     if anisotropy != 0:
         dsum = K.sum(1)
@@ -48,17 +40,70 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
     W.fill_diagonal_(0.0)
     nz = W != 0
     counts = nz.sum(1)
-    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=X.device)
+    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=K.device)
     rowptr[1:] = torch.cumsum(counts, 0)
     idx = torch.nonzero(nz)  # row-major order = CSR order with sorted columns
     col = idx[:, 1].to(torch.int32).contiguous()
     val = W[nz].contiguous()
     dw = W.sum(1).contiguous()
-    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy,
-                    info=dict(N=N, knn=int(knn), dense=True, nnz=int(col.shape[0]), n_flagged_rows=0))
+    G = DeviceGraph(rowptr, col, val, dw, ksum=ksum, anisotropy=anisotropy, info=dict(info, N=N, dense=True, nnz=int(col.shape[0]), n_flagged_rows=0))
     G.bandwidth = bw
     G._kdiag = torch.diagonal(K).clone()
     return G
+
+
+def _alpha_decay_dense(D, knn, decay, thresh):
+    """[UPSTREAM graphtools ``TraditionalGraph.build_kernel``]: bandwidth = the (knn+1)-th smallest entry of a row (self
+    counted), K = exp(-(d / bw)^decay), NaN -> 1, K < thresh -> 0."""
+    bw = torch.kthvalue(D, knn + 1, dim=1).values
+    K = torch.exp(-torch.pow(D / bw[:, None], decay))
+    K = torch.where(torch.isnan(K), torch.ones_like(K), K)
+    if thresh > 0:
+        K = torch.where(K < thresh, torch.zeros_like(K), K)
+    return K, bw
+
+
+def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
+    N = int(X.shape[0])
+    if N > DENSE_MAX_N:
+        raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
+    if knn > N - 2:
+        knn = N - 2
+    X = X.to(torch.float64)
+    D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    D.fill_diagonal_(0.0)
+    K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)))
+
+
+def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1):
+    """A graph from a precomputed N x N matrix (``MELD(distance="precomputed" | "precomputed_distance" |
+    "precomputed_affinity").fit(M)``: [UPSTREAM graphtools ``GraphEstimator._parse_input`` -> ``Graph(precomputed=...)`` ->
+    ``TraditionalGraph.build_kernel``], reached from reference ``meld/meld.py:273``).  ``kind``: "distance" (pairwise
+    distances: the alpha-decay kernel with the (knn+1)-th smallest entry of a row as bandwidth, thresholded), "affinity"
+    (the kernel itself) or "adjacency" (the kernel without its diagonal: set to 1).  Dense, like the reference's."""
+    if M.dim() != 2 or M.shape[0] != M.shape[1]:
+        raise ValueError("Precomputed {} must be a square matrix. {} was given".format(kind, tuple(M.shape)))
+    N = int(M.shape[0])
+    if N > DENSE_MAX_N:
+        raise ValueError("a precomputed matrix is handled densely; the limit is N <= {}".format(DENSE_MAX_N))
+    M = M.to(torch.float64)
+    if bool((M < 0).any()):
+        raise ValueError("Precomputed {} should be non-negative".format(kind))
+    bw = None
+    if kind == "distance":
+        k = min(int(knn), N - 2)
+        K, bw = _alpha_decay_dense(M, k, float("inf") if decay is None else decay, thresh)
+    elif kind == "affinity":
+        K = torch.where(M < thresh, torch.zeros_like(M), M) if thresh > 0 else M.clone()
+    elif kind == "adjacency":
+        K = M.clone()
+        K.fill_diagonal_(1.0)
+        if thresh > 0:
+            K = torch.where(K < thresh, torch.zeros_like(K), K)
+    else:
+        raise ValueError("Precomputed value {} not recognized. Choose from ['distance', 'affinity', 'adjacency']".format(kind))
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), precomputed=kind))
 
 
 def exact_filter(graph, sig, kernel_of_lmax):

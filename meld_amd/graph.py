@@ -310,6 +310,8 @@ class DeviceGraph:
         """bandwidths in the units of the graph's metric (``bandwidth`` itself is the euclidean one of the rows the search saw)"""
         if self.bandwidth is None:
             return None
+        if getattr(self, "bandwidth", None) is None:  # (a precomputed affinity has none)
+            return None
         to_metric = getattr(self, "bandwidth_to_metric", None)
         return self._vec_host(self.bandwidth if to_metric is None else to_metric(self.bandwidth))
 

@@ -147,6 +147,19 @@ class MELD(GraphEstimator):
         if not bool(torch.isfinite(X.sum(dim=0)).all()) and not bool(torch.isfinite(X).all()):
             raise ValueError("Input data contains NaN or infinity")
         self.data_nu = None
+        if str(self.distance).lower().startswith("precomputed"):
+            # [UPSTREAM graphtools GraphEstimator._parse_input]: the input IS a square matrix of pairwise distances or
+            # affinities ("precomputed": told apart by its first diagonal entry, 0 = distances); no PCA, dense graph
+            from .dense import build_precomputed_graph
+
+            if opts.get("sample_idx") is not None or opts.get("bandwidth") is not None or opts.get("bandwidth_scale") is not None:
+                raise NotImplementedError("sample_idx / bandwidth options with a precomputed matrix are not implemented")
+            kind = str(self.distance).lower()[len("precomputed"):].lstrip("_")
+            if X.dim() != 2 or X.shape[0] != X.shape[1]:
+                raise ValueError("Precomputed {} must be a square matrix. {} was given".format(kind or "matrix", tuple(X.shape)))
+            if not kind:
+                kind = "distance" if float(X[0, 0]) == 0.0 else "affinity"
+            return build_precomputed_graph(X, kind, knn=self.knn, decay=self.decay, thresh=self.thresh, anisotropy=self.anisotropy)
         if self.n_pca is not None and self.n_pca < min(tuple(X.shape)):
             # graphtools reduces the data with PCA first (Data._reduce_data) and builds the graph on
             # the scores; here: exact top-n_pca subspace on the device (meld_amd/pca.py)

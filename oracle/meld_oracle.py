@@ -196,6 +196,32 @@ def dense_kernel(X, knn=5, decay=40, thresh=0.0):
     return K
 
 
+def precomputed_kernel(M, kind, knn=5, decay=40, thresh=1e-4):
+    """Kernel from a precomputed N x N matrix [UPSTREAM graphtools ``TraditionalGraph.build_kernel`` with
+    ``precomputed="distance" | "affinity" | "adjacency"``; reached through ``GraphEstimator(distance="precomputed_*")``
+    from reference ``meld/meld.py:273``]: distances go through the alpha-decay kernel with the bandwidth of
+    ``dense_kernel`` (max of the knn+1 smallest entries of a row), an affinity is taken as it is, an adjacency gets a unit
+    diagonal; then ``K[K < thresh] = 0``."""
+    M = np.asarray(M, dtype=np.float64)
+    N = M.shape[0]
+    if kind == "distance":
+        k = min(knn, N - 2)
+        knn_dist = np.partition(M, k + 1, axis=1)[:, : k + 1]
+        bandwidth = np.max(knn_dist, axis=1)
+        pdx = (M.T / bandwidth).T
+        K = np.exp(-1 * np.power(pdx, decay))
+        K = np.where(np.isnan(K), 1, K)
+    elif kind == "affinity":
+        K = M.copy()
+    elif kind == "adjacency":
+        K = M.copy()
+        np.fill_diagonal(K, 1)
+    else:
+        raise ValueError(kind)
+    K[K < thresh] = 0
+    return K
+
+
 def semantic_kernel_dense(X, knn=5, decay=40, thresh=1e-4):
     """Brute-force statement of the kernel's *semantics* (small N only, O(N^2) memory).
 

@@ -174,6 +174,37 @@ def test_bandwidth_options_match_the_oracle(n, d, knn, opt):
         assert _rel(out.values, dens) < 1e-5
 
 
+@pytest.mark.parametrize("kind", ["distance", "affinity", "auto_distance", "auto_affinity"])
+def test_precomputed_matrices_match_the_oracle(kind):
+    """``MELD(distance="precomputed_distance" | "precomputed_affinity" | "precomputed").fit_transform(M, labels)``: graphtools'
+    route for a square matrix of pairwise distances / affinities (TraditionalGraph), restated by the oracle."""
+    mo = _oracle()
+    from scipy.spatial.distance import cdist
+
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(900, n_dims=8, seed=8)
+    D = cdist(X, X)
+    if "distance" in kind:
+        M, k = D, "distance"
+    else:
+        M, k = np.exp(-(D / np.median(D)) ** 2), "affinity"   # some symmetric affinity with a unit diagonal
+    Kd = mo.precomputed_kernel(M, k, knn=7, decay=20, thresh=1e-4)
+    K = mo.apply_anisotropy(mo.symmetrize(Kd), 1)
+    W = mo.weights_from_kernel(K)
+    L, dw = mo.laplacian(W)
+    Go = mo.OracleGraph(Kd, K, W, L, dw)
+    ind = mo.sample_indicators(labels)[1]
+    dens = mo.meld_filter(ind, Go, chebyshev_order=20)
+    name = "precomputed" if kind.startswith("auto") else "precomputed_" + k
+    op = meld_amd.MELD(distance=name, knn=7, decay=20, chebyshev_order=20, lmax=Go.lmax, verbose=0)
+    out = op.fit_transform(M, labels)
+    np.testing.assert_allclose(np.asarray(op.graph.W.todense()), np.asarray(W.todense() if hasattr(W, "todense") else W), rtol=1e-10, atol=1e-300)
+    assert _rel(out.values, dens) < 1e-5
+    with pytest.raises(ValueError):
+        meld_amd.MELD(distance=name, verbose=0).fit(M[:, :5])
+
+
 def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 
