@@ -51,6 +51,12 @@ double meld_knn_error_coef(int d);  /* fp32 FMA-chain bound KP * 2^-21 of meld_k
 
 /* column sums of X[N,d] (fp64) -> sums[d] (zeroed by the call).  Used for centring. */
 int meld_col_sums_f64(const double* X, int64_t N, int d, double* sums, meld_stream_t stream);
+/* column sums, minima and maxima of X[N,d] in ONE pass (fixed-order reduction: reproducible bits): the centring mean, the
+ * front end's NaN / infinity check (graphtools rejects such input before building, reached from meld/meld.py:273) and the
+ * extremes meld_knn16_prepare_scaled derives the operand scale from.  temp: meld_col_stats_temp_bytes(d) bytes. */
+size_t meld_col_stats_temp_bytes(int d);
+int meld_col_stats_f64(const double* X, int64_t N, int d, double* sums, double* mins, double* maxs, void* temp, size_t temp_bytes,
+                       meld_stream_t stream);
 
 /* Build the fp32 operands of the distance GEMM from fp64 data (centred by `mean[d]`):
  *   refs:    tile-major augmented reference form  Rt[n_tiles][KP/2][TS][2]  of  [-2x, 1, |x|^2, 0..]
@@ -94,6 +100,11 @@ size_t meld_knn16_query_bytes(int d);    /* bytes of one query row of Q16 */
 int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                        int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
                        float* scale_info, meld_stream_t stream);
+/* meld_knn16_prepare with the operand scale (max |x - mean| over all entries) taken from the columns' extremes
+ * (meld_col_stats_f64) instead of a pass of its own over X; bit-identical operands. */
+int meld_knn16_prepare_scaled(const double* X, int64_t N, int d, const double* mean, const double* col_min, const double* col_max,
+                              int64_t q_begin, int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
+                              float* scale_info, meld_stream_t stream);
 /* Optional exact pruning.  meld_knn16_bounds fills lb2[n_query_waves][n_tiles] (fp16, rounded towards
  * zero) with a lower bound (scaled space) on the squared distance between any query of a wave of the
  * search kernel (64 consecutive cells = one reference tile) and any reference of a tile (TS consecutive

@@ -24,6 +24,8 @@ SIGNATURES = {
     "meld_knn_block_queries": (_i32, []),
     "meld_knn_row_capacity": (_i32, [_i32]),
     "meld_col_sums_f64": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),
+    "meld_col_stats_temp_bytes": (_sz, [_i32]),
+    "meld_col_stats_f64": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "meld_knn_prepare_refs": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn_prepare_queries": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _i64, _i64, _ptr, _ptr]),
     "meld_knn_topk": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
@@ -44,6 +46,7 @@ SIGNATURES = {
     "meld_knn16_tile_bytes": (_sz, [_i32]),
     "meld_knn16_query_bytes": (_sz, [_i32]),
     "meld_knn16_prepare": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_knn16_prepare_scaled": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_cross": (_i32, [_ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_prepare_rows": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr]),
     "meld_knn16_research_thresholds": (_i32, [_ptr, _i64, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _f64, _f64, _f64, _ptr, _ptr, _ptr]),

@@ -356,6 +356,74 @@ extern "C" int meld_knn_row_capacity(int ksel) {
   return ksel + KNN_SLACK;
 }
 
+// column sums, minima and maxima in ONE pass over X (the centring mean, the NaN / infinity check of the front end -- a
+// non-finite value makes its column sum non-finite -- and the scale of the search operands: max_i |x_ic - mean_c| is attained
+// at the column's minimum or maximum).  Per-workgroup partials in `part` [3][grid][d], reduced in a fixed order: the same
+// bits on every run (col_sums_kernel's atomics add in arrival order).
+namespace meld {
+constexpr int COL_STATS_GRID = 1024;
+__global__ __launch_bounds__(256) void col_stats_kernel(const double* __restrict__ X, int64_t N, int d, double* __restrict__ part) {
+  __shared__ double ps[256], pmin[256], pmax[256];
+  const int tid = threadIdx.x;
+  const int rpp = 256 / d;  // rows per pass (d <= 256)
+  const int c = tid % d;
+  const int rl = tid / d;
+  double s = 0.0, mn = INFINITY, mx = -INFINITY;
+  if (rl < rpp) {
+    for (int64_t row = (int64_t)blockIdx.x * rpp + rl; row < N; row += (int64_t)gridDim.x * rpp) {
+      const double v = X[row * d + c];
+      s += v;
+      mn = fmin(mn, v);
+      mx = fmax(mx, v);
+    }
+  }
+  ps[tid] = s;
+  pmin[tid] = mn;
+  pmax[tid] = mx;
+  __syncthreads();
+  if (tid < d) {
+    double ts = 0.0, tmn = INFINITY, tmx = -INFINITY;
+    for (int k = 0; k < rpp; ++k) {
+      ts += ps[k * d + tid];
+      tmn = fmin(tmn, pmin[k * d + tid]);
+      tmx = fmax(tmx, pmax[k * d + tid]);
+    }
+    const size_t g = gridDim.x;
+    part[(0 * g + blockIdx.x) * d + tid] = ts;
+    part[(1 * g + blockIdx.x) * d + tid] = tmn;
+    part[(2 * g + blockIdx.x) * d + tid] = tmx;
+  }
+}
+__global__ __launch_bounds__(256) void col_stats_finish_kernel(const double* __restrict__ part, int grid, int d, double* __restrict__ sums,
+                                                               double* __restrict__ mins, double* __restrict__ maxs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  double ts = 0.0, tmn = INFINITY, tmx = -INFINITY;
+  for (int b = 0; b < grid; ++b) {
+    ts += part[((size_t)0 * grid + b) * d + c];
+    tmn = fmin(tmn, part[((size_t)1 * grid + b) * d + c]);
+    tmx = fmax(tmx, part[((size_t)2 * grid + b) * d + c]);
+  }
+  sums[c] = ts;
+  mins[c] = tmn;
+  maxs[c] = tmx;
+}
+}  // namespace meld
+extern "C" size_t meld_col_stats_temp_bytes(int d) { return sizeof(double) * 3 * (size_t)meld::COL_STATS_GRID * (size_t)(d > 0 ? d : 1); }
+extern "C" int meld_col_stats_f64(const double* X, int64_t N, int d, double* sums, double* mins, double* maxs, void* temp, size_t temp_bytes,
+                                  meld_stream_t stream) {
+  using namespace meld;
+  MELD_CHECK_ARG(X && sums && mins && maxs && temp && N > 0 && d > 0 && d <= 256, "meld_col_stats_f64: bad arguments (d must be <= 256)");
+  MELD_CHECK_ARG(temp_bytes >= meld_col_stats_temp_bytes(d), "meld_col_stats_f64: temp too small");
+  const int rpp = 256 / d;
+  const int grid = (int)std::min<int64_t>(COL_STATS_GRID, ceil_div(N, rpp));
+  hipLaunchKernelGGL(col_stats_kernel, dim3(grid), dim3(256), 0, S(stream), X, N, d, reinterpret_cast<double*>(temp));
+  hipLaunchKernelGGL(col_stats_finish_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, S(stream), reinterpret_cast<const double*>(temp), grid, d,
+                     sums, mins, maxs);
+  MELD_LAUNCH_CHECK("col_stats_kernel");
+  return MELD_OK;
+}
+
 extern "C" int meld_col_sums_f64(const double* X, int64_t N, int d, double* sums, meld_stream_t stream) {
   MELD_CHECK_ARG(X && sums && N > 0 && d > 0 && d <= 256, "meld_col_sums_f64: bad arguments (d must be <= 256)");
   MELD_HIP_CALL(hipMemsetAsync(sums, 0, sizeof(double) * d, S(stream)));

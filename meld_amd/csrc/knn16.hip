@@ -1464,6 +1464,18 @@ __global__ __launch_bounds__(256) void absmax_centered_kernel(const double* __re
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(scale_info + 2), __float_as_int(m));
 }
 
+// absmax from the columns' extremes: x -> (float)(x - mean_c) is monotone, so max_i |(float)(x_ic - mean_c)| is attained at the
+// column's minimum or maximum -- the same bits as absmax_centered_kernel's pass over all of X, from 2 d numbers
+__global__ __launch_bounds__(256) void absmax_from_extremes_kernel(const double* __restrict__ mean, const double* __restrict__ col_min,
+                                                                   const double* __restrict__ col_max, int d, float* __restrict__ scale_info) {
+  float m = 0.0f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    m = fmaxf(m, fmaxf(fabsf((float)(col_min[c] - mean[c])), fabsf((float)(col_max[c] - mean[c]))));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(scale_info + 2), __float_as_int(m));
+}
+
 // scale_info: [0] = s (multiply centred data by s), [1] = 1/s^2, [2] = absmax (input of this kernel)
 __global__ void finish_scale_kernel(float* scale_info) {
   const float a = scale_info[2];
@@ -1852,9 +1864,9 @@ extern "C" double meld_knn16_error_coef(int nprod, int d) {
 extern "C" double meld_knn16_error_coef_const(int nprod, int d) { return k16_const_coef(nprod, d); }
 extern "C" double meld_knn16_error_coef_lin(int nprod) { return nprod == 1 ? 0.001953125 : 0.0; }
 
-extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
+static int k16_prepare_impl(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
                                   int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
-                                  float* scale_info, meld_stream_t stream) {
+                                  float* scale_info, meld_stream_t stream, const double* col_min, const double* col_max) {
   MELD_CHECK_ARG(X && mean && Rt16 && Q16 && Qn && norm2 && norm2_max && scale_info && N > 0,
                  "meld_knn16_prepare: null/empty argument");
   MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && q_begin + q_count <= N, "meld_knn16_prepare: bad query range");
@@ -1863,7 +1875,10 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
   hipStream_t st = S(stream);
   MELD_HIP_CALL(hipMemsetAsync(scale_info, 0, 4 * sizeof(float), st));
   MELD_HIP_CALL(hipMemsetAsync(norm2_max, 0, sizeof(float), st));
-  hipLaunchKernelGGL(absmax_centered_kernel, dim3(2048), dim3(256), 0, st, X, N * (int64_t)d, d, mean, scale_info);
+  if (col_min != nullptr && col_max != nullptr)
+    hipLaunchKernelGGL(absmax_from_extremes_kernel, dim3(1), dim3(256), 0, st, mean, col_min, col_max, d, scale_info);
+  else
+    hipLaunchKernelGGL(absmax_centered_kernel, dim3(2048), dim3(256), 0, st, X, N * (int64_t)d, d, mean, scale_info);
   hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
   const int64_t n_pad = ceil_div(N, K16_TS) * K16_TS;
   hipLaunchKernelGGL((prepare16_kernel<true>), dim3((unsigned)(n_pad / K16_TS)), dim3(256), 0, st, X, N, d, mean, scale_info,
@@ -1873,6 +1888,19 @@ extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const doubl
                      KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
   MELD_LAUNCH_CHECK("meld_knn16_prepare");
   return MELD_OK;
+}
+extern "C" int meld_knn16_prepare(const double* X, int64_t N, int d, const double* mean, int64_t q_begin,
+                                  int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
+                                  float* scale_info, meld_stream_t stream) {
+  return k16_prepare_impl(X, N, d, mean, q_begin, q_count, Rt16, Q16, Qn, norm2, norm2_max, scale_info, stream, nullptr, nullptr);
+}
+// The same with the scale taken from the columns' minima / maxima (meld_col_stats_f64: one pass over X gives the mean, the
+// finite check and these), instead of a pass of its own over all of X; identical operands.
+extern "C" int meld_knn16_prepare_scaled(const double* X, int64_t N, int d, const double* mean, const double* col_min, const double* col_max,
+                                         int64_t q_begin, int64_t q_count, void* Rt16, void* Q16, float* Qn, float* norm2, float* norm2_max,
+                                         float* scale_info, meld_stream_t stream) {
+  MELD_CHECK_ARG(col_min && col_max, "meld_knn16_prepare_scaled: null column extremes");
+  return k16_prepare_impl(X, N, d, mean, q_begin, q_count, Rt16, Q16, Qn, norm2, norm2_max, scale_info, stream, col_min, col_max);
 }
 
 // The same for a search between two point sets (the blocks of graphtools' MNN kernel between two samples): X holds

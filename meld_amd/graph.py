@@ -458,9 +458,18 @@ class HipOps:
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
+    def col_stats(self, X):
+        """(sums, minima, maxima) of the columns of an fp64 [N, d <= 256] matrix in one pass (``meld_col_stats_f64``)."""
+        N, d = int(X.shape[0]), int(X.shape[1])
+        out = torch.empty(3, d, dtype=torch.float64, device=X.device)
+        tb = self.lib.meld_col_stats_temp_bytes(d)
+        tmp = torch.empty(tb, dtype=torch.uint8, device=X.device)
+        check(self.lib.meld_col_stats_f64(ptr(X), N, d, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(tmp), tb, _stream()), "meld_col_stats_f64")
+        return out[0], out[1], out[2]
+
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
-                            bw_scale=1.0, bw_fixed=None):
+                            bw_scale=1.0, bw_fixed=None, col_stats=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -481,9 +490,13 @@ class HipOps:
         if cross and not (0 < NR <= q_begin and q_begin + q_count <= N):
             raise ValueError("cross search: the queries must lie behind the n_refs references")
         tm.start()
-        if d <= 256:
-            sums = torch.empty(d, dtype=torch.float64, device=dev)
-            check(lib.meld_col_sums_f64(ptr(X), N, d, ptr(sums), st), "meld_col_sums_f64")
+        col_min = col_max = None
+        if col_stats is not None:  # (the front end's pass over X -- its NaN / infinity check -- already has them)
+            sums, col_min, col_max = col_stats
+            mean = sums / N
+        elif d <= 256:
+            # one pass: the mean and the columns' extremes (from which the operand scale follows without another pass over X)
+            sums, col_min, col_max = self.col_stats(X)
             mean = sums / N
         else:  # beyond the column-sum kernel's width (only the library search path handles such data)
             mean = X.mean(dim=0)
@@ -563,7 +576,10 @@ class HipOps:
                 norm2[q_begin : q_begin + q_count] = Qn[:q_count]
                 nmax = torch.maximum(nmax, Qn[:q_count].max().reshape(1))
             else:
-                check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
+                if col_min is not None:
+                    check(lib.meld_knn16_prepare_scaled(ptr(X), N, d, ptr(mean), ptr(col_min), ptr(col_max), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare_scaled")
+                else:
+                    check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
             tm.stop("prepare")
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
@@ -849,7 +865,7 @@ class HipOps:
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
-                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed)
+                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -1405,7 +1421,7 @@ def resolve_graph_params(N, knn, thresh, ksel):
 
 
 def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
-                    reorder=True, bandwidth=None, bandwidth_scale=1.0):
+                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -1451,7 +1467,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         tm.stop("reorder")
 
     keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                                   bw_scale=bw_scale, bw_fixed=bw_fixed)
+                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats)
     if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
         bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:

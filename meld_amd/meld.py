@@ -143,8 +143,18 @@ class MELD(GraphEstimator):
             X = data.to(device="cuda", dtype=torch.float64)
         else:
             X = torch.from_numpy(data).to("cuda")
-        # (one pass: a NaN or an infinity anywhere makes its column sum non-finite; isfinite(X).all() is three)
-        if not bool(torch.isfinite(X.sum(dim=0)).all()) and not bool(torch.isfinite(X).all()):
+        X_in = X
+        # (one pass: a NaN or an infinity anywhere makes its column sum non-finite; isfinite(X).all() is three.  The pass is the
+        # builder's own -- sums, minima, maxima of the columns, meld_col_stats_f64 -- and its results are handed on to it)
+        col_stats = None
+        if X.dim() == 2 and X.shape[1] <= 256 and X.shape[0] > 0 and X.is_contiguous():
+            from .graph import HipOps
+
+            col_stats = HipOps(X.device).col_stats(X)
+            finite = bool(torch.isfinite(col_stats[0]).all())
+        else:
+            finite = bool(torch.isfinite(X.sum(dim=0)).all())
+        if not finite and not bool(torch.isfinite(X).all()):
             raise ValueError("Input data contains NaN or infinity")
         self.data_nu = None
         if str(self.distance).lower().startswith("precomputed"):
@@ -199,6 +209,8 @@ class MELD(GraphEstimator):
             X, knn=self.knn, decay=float("inf") if decay_m is None else decay_m,  # None: unweighted kNN graph
             thresh=self.thresh, anisotropy=self.anisotropy,
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)), **bw_opts,
+            # (the column statistics are those of the cells the graph is built on: not after a PCA / a metric front end)
+            col_stats=col_stats if (self.data_nu is None and X is X_in) else None,
         )
         G.bandwidth_to_metric = bw_to_metric
         # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the

@@ -346,6 +346,44 @@ print("SHARDED_OK")
     assert "SHARDED_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
+@pytest.mark.parametrize("n,d", [(70001, 50), (5000, 3), (1000, 141)])
+def test_column_statistics_in_one_pass_and_the_scale_they_imply(n, d):
+    """meld_col_stats_f64 (sums, minima, maxima of the columns in one pass, fixed-order reduction) against torch, and
+    meld_knn16_prepare_scaled -- the operand scale from the columns' extremes -- against meld_knn16_prepare's own pass over
+    X: the same operands, bit for bit."""
+    from meld_amd._lib import check, get_lib, ptr
+    from meld_amd.graph import HipOps
+
+    lib = get_lib()
+    rng = np.random.default_rng(d)
+    X = rng.normal(size=(n, d)) * rng.uniform(0.1, 30.0, size=d)[None, :] + rng.normal(size=d)[None, :] * 5.0
+    Xd = torch.from_numpy(X).cuda()
+    sums, mins, maxs = HipOps().col_stats(Xd)
+    np.testing.assert_allclose(sums.cpu().numpy(), X.sum(0), rtol=1e-12, atol=1e-9)
+    assert torch.equal(mins, Xd.min(0).values) and torch.equal(maxs, Xd.max(0).values)
+    s2 = HipOps().col_stats(Xd)[0]
+    assert torch.equal(sums, s2)  # reproducible bits
+    st = torch.cuda.current_stream().cuda_stream
+    TS, BQ = lib.meld_knn16_tile_refs(), lib.meld_knn16_block_queries()
+    mean = sums / n
+    n_tiles, q_pad = (n + TS - 1) // TS, ((n + BQ - 1) // BQ) * BQ
+    outs = []
+    for scaled in (False, True):
+        Rt = torch.zeros(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device="cuda")
+        Q = torch.zeros(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device="cuda")
+        Qn = torch.zeros(q_pad, dtype=torch.float32, device="cuda")
+        norm2 = torch.zeros(n, dtype=torch.float32, device="cuda")
+        nmax = torch.zeros(1, dtype=torch.float32, device="cuda")
+        sinfo = torch.zeros(4, dtype=torch.float32, device="cuda")
+        if scaled:
+            check(lib.meld_knn16_prepare_scaled(ptr(Xd), n, d, ptr(mean), ptr(mins), ptr(maxs), 0, n, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+        else:
+            check(lib.meld_knn16_prepare(ptr(Xd), n, d, ptr(mean), 0, n, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(sinfo), st))
+        outs.append((Rt, Q, Qn, norm2, nmax, sinfo))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n", [9000, 80000])
 def test_sharded_recurrences_enqueued_from_c_equal_the_python_loops(n):
     """On an RCCL group the sharded Chebyshev filter and the sharded Lanczos iterations are ONE C call each
