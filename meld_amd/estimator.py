@@ -188,7 +188,9 @@ class GraphEstimator(object):
             data = data.toarray()
         if data.ndim != 2:
             raise ValueError("Expected a 2D data matrix, got shape {}".format(data.shape))
-        data = np.ascontiguousarray(data, dtype=np.float64)
+        # (float32 input -- PCA scores usually are -- crosses PCIe as float32, half the bytes, and is widened on the device:
+        # exact; converting 50 M entries on the host first costs more than the whole graph build)
+        data = np.ascontiguousarray(data, dtype=np.float32 if data.dtype == np.float32 else np.float64)
         # (NaN / infinity are rejected by _build_graph once the data is on the device: a host-side
         # np.isfinite pass over 1M x 50 doubles costs ~40 ms, the device one 0.2 ms)
         if self.X is not None and (

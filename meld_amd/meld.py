@@ -143,6 +143,8 @@ class MELD(GraphEstimator):
             X = data.to(device="cuda", dtype=torch.float64)
         else:
             X = torch.from_numpy(data).to("cuda")
+            if X.dtype != torch.float64:
+                X = X.to(torch.float64)  # (float32 input: widened here, after the copy)
         X_in = X
         # (one pass: a NaN or an infinity anywhere makes its column sum non-finite; isfinite(X).all() is three.  The pass is the
         # builder's own -- sums, minima, maxima of the columns, meld_col_stats_f64 -- and its results are handed on to it)

@@ -212,7 +212,7 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         meld.MELD(n_landmark=50, verbose=0).fit(data).graph.landmark_op
     with pytest.raises(NotImplementedError):
-        meld.MELD(verbose=0).fit(data, bandwidth=1.0)  # graph kwargs the builder does not know
+        meld.MELD(verbose=0).fit(data, knn_max=10)  # graph kwargs the builder does not know (bandwidth / bandwidth_scale it does)
     with pytest.raises(NotImplementedError):
         meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
@@ -516,6 +516,25 @@ def test_indicator_signal_and_row_scatter_kernels(p):
     ref = torch.empty_like(r)
     ref[perm] = r
     assert torch.equal(back, ref)
+
+
+@pytest.mark.gpu
+def test_float32_input_is_widened_on_the_device():
+    """float32 data (PCA scores usually are) crosses PCIe as float32 and is widened on the device: the same graph and
+    densities, bit for bit, as the float64 copy of the same values."""
+    meld = _meld()
+    rng = np.random.default_rng(3)
+    X32 = rng.normal(size=(4000, 20)).astype(np.float32)
+    labels = rng.choice(["a", "b"], size=4000)
+    a = meld.MELD(knn=7, verbose=0)
+    da = a.fit_transform(X32, labels)
+    assert a.X.dtype == np.float32
+    b = meld.MELD(knn=7, verbose=0, lmax=a.graph.lmax)
+    db = b.fit_transform(X32.astype(np.float64), labels)
+    import torch
+
+    assert torch.equal(a.graph.val, b.graph.val) and torch.equal(a.graph.col, b.graph.col)
+    np.testing.assert_allclose(da.values, db.values, rtol=1e-12, atol=1e-300)
 
 
 @pytest.mark.gpu
