@@ -266,6 +266,7 @@ int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begin, int64_t 
                     const int32_t* rows, int out_cap, int32_t* cand_idx_out,
                     double bw_scale /* graphtools' bandwidth_scale: the kernel uses max(bw * bw_scale, eps); bw[] records the unscaled value */,
                     const double* bw_fixed /* [N] graphtools' bandwidth= (a given bandwidth per cell, knn then only sizes the search), or NULL */,
+                    int max_rank /* graphtools' knn_max + 1 (self counted): a row keeps its max_rank nearest cells at most; 0 = no limit */,
                     meld_stream_t stream);
 
 /* Exact fp64 radius search for the flagged rows (the analogue of graphtools' re-search /

@@ -32,7 +32,7 @@ SIGNATURES = {
     "meld_knn_refine": (
         _i32,
         [_ptr, _i64, _i32, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _f64, _f64, _ptr, _f64, _ptr, _f64, _ptr, _ptr, _ptr,
-         _ptr, _ptr, _ptr, _i32, _ptr, _f64, _ptr, _ptr],
+         _ptr, _ptr, _ptr, _i32, _ptr, _f64, _ptr, _i32, _ptr],
     ),
     "meld_knn_error_coef": (_f64, [_i32]),
     "meld_knn16_kblocks": (_i32, [_i32]),

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
     const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, const float* __restrict__ cand_thr, int ksel,
     int cap, int knn, double decay, double thresh, double radius_factor, const float* __restrict__ norm2_max, double err_coef,
-    const float* __restrict__ norm2, double err_coef_lin, double bw_scale, const double* __restrict__ bw_fixed,
+    const float* __restrict__ norm2, double err_coef_lin, double bw_scale, const double* __restrict__ bw_fixed, int max_rank,
     double* __restrict__ bw_out, double* __restrict__ cand_val, int* __restrict__ keep_cnt,
     int* __restrict__ flag_rows, int* __restrict__ n_flag, const int* __restrict__ rows, int out_cap,
     int* __restrict__ cand_idx_out) {
@@ -172,6 +172,18 @@ __global__ __launch_bounds__(256) void refine_kernel(
   if (cand_cnt[q] >= ksel) tau = (double)cand_d2[ro + ksel - 1];
   if (cand_thr != nullptr) tau = fmin(tau, (double)cand_thr[q]);
   bool complete = (reach * reach + E <= tau);
+  // graphtools' knn_max (max_rank = knn_max + 1, self counted; 0 = none): a row keeps its max_rank nearest cells at most.  The
+  // list then only has to hold THOSE for sure: if the entry of rank max_rank - 1 is certified (no reference outside the list can
+  // be closer), everything the row keeps is present even where the list does not reach the radius.
+  if (max_rank > 0) {
+    double d_m = INFINITY;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned long long b = __ballot((lane + 64 * e) < n && rk[e] == max_rank - 1 && dist[e] < INFINITY);
+      if (b) d_m = __shfl(dist[e], __ffsll((long long)b) - 1, 64);
+    }
+    if (d_m < INFINITY && d_m * d_m + E <= tau && d_m >= bw_raw) complete = true;
+  }
   if (bw_fixed == nullptr && n <= knn) complete = false;  // cannot even define the bandwidth from this list
 
   int kept = 0;
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     if (c < n && complete) {
       v = decay_kernel(dist[e], bw, decay);
       if (v < thresh || (int64_t)idx[e] == gi) v = 0.0;  // diagonal handled analytically (K_ii = 1)
+      if (max_rank > 0 && rk[e] >= max_rank) v = 0.0;    // beyond the knn_max nearest
     }
     if (c < ksel) {
       cand_val[(size_t)orow * ksel + c] = v;
@@ -348,7 +361,7 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
                                const float* norm2, double err_coef_lin, double* bw,
                                double* cand_val, int32_t* keep_cnt, int32_t* flag_rows, int32_t* n_flag,
                                const int32_t* rows, int out_cap, int32_t* cand_idx_out, double bw_scale, const double* bw_fixed,
-                               meld_stream_t stream) {
+                               int max_rank, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cand_idx && cand_d2 && cand_cnt && norm2_max && bw && cand_val && keep_cnt && flag_rows && n_flag,
                  "meld_knn_refine: null pointer");
   MELD_CHECK_ARG(q_count > 0 && q_begin >= 0 && d > 0 && (rows != nullptr || q_begin + q_count <= N),
@@ -360,10 +373,11 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(cap >= ksel, "meld_knn_refine: row stride cap=%d smaller than ksel=%d", cap, ksel);
   MELD_CHECK_ARG(err_coef >= 0 && err_coef_lin >= 0, "meld_knn_refine: error coefficients must be non-negative");
   MELD_CHECK_ARG(bw_scale > 0 && bw_scale < INFINITY, "meld_knn_refine: bandwidth_scale must be positive and finite");
+  MELD_CHECK_ARG(max_rank == 0 || max_rank > knn, "meld_knn_refine: max_rank=%d must exceed knn=%d (or be 0)", max_rank, knn);
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
   hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
                      q_count, cand_idx, cand_d2, cand_cnt, cand_thr, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
-                     err_coef, norm2, err_coef_lin, bw_scale, bw_fixed, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
+                     err_coef, norm2, err_coef_lin, bw_scale, bw_fixed, max_rank, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
                      cand_idx_out);
   MELD_LAUNCH_CHECK("refine_kernel");
   return MELD_OK;

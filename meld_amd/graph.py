@@ -469,7 +469,7 @@ class HipOps:
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
-                            bw_scale=1.0, bw_fixed=None, col_stats=None):
+                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -481,7 +481,8 @@ class HipOps:
         ``bw_scale`` / ``bw_fixed`` ([UPSTREAM graphtools kNNGraph ``bandwidth_scale`` / ``bandwidth``, forwarded by reference
         ``meld/meld.py:106,117-118``): the kernel uses ``max(bw * bw_scale, eps)``; ``bw_fixed`` (fp64 device tensor [N], in
         the order of ``X``) replaces the adaptive k-th-neighbour bandwidth -- the kernel radius of every row is then known
-        before the search, which starts its thresholds there and cuts nothing on its own."""
+        before the search, which starts its thresholds there and cuts nothing on its own.  ``knn_max`` ([UPSTREAM kNNGraph
+        ``knn_max``]): a row keeps its knn_max nearest cells (besides itself) at most."""
         lib, st, dev = self.lib, _stream(), X.device
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
@@ -775,6 +776,7 @@ class HipOps:
             del Rt
 
         # exact refinement + alpha-decay kernel
+        max_rank = 0 if knn_max is None else int(knn_max) + 1  # (self counted, as graphtools counts it)
         bw = torch.empty(q_count, dtype=torch.float64, device=dev)
         cand_val = torch.empty(q_count * ksel, dtype=torch.float64, device=dev)
         keep_cnt = torch.empty(q_count, dtype=torch.int32, device=dev)
@@ -787,7 +789,7 @@ class HipOps:
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ksel, cap, knn, float(decay),
                 float(thresh), ptr(nmax_used), float(err_coef), ptr(norm2), float(err_lin), ptr(bw), ptr(cand_val), ptr(keep_cnt),
-                ptr(flag_rows), ptr(n_flag), None, 0, None, float(bw_scale), ptr(bw_fixed), st,
+                ptr(flag_rows), ptr(n_flag), None, 0, None, float(bw_scale), ptr(bw_fixed), max_rank, st,
             ),
             "meld_knn_refine",
         )
@@ -835,7 +837,7 @@ class HipOps:
                 lib.meld_knn_refine(
                     ptr(X), N, d, q_begin, n_flag_h, ptr(c2_idx), ptr(c2_d2), ptr(c2_cnt), None, ksel, cap, knn, float(decay),
                     float(thresh), ptr(nmax), float(lib.meld_knn16_error_coef(3, d)), None, 0.0, ptr(bw), ptr(cand_val), ptr(keep_cnt),
-                    ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), float(bw_scale), ptr(bw_fixed), st,
+                    ptr(flag_rows), ptr(n_flag), ptr(rows2), cap, ptr(cand_idx), float(bw_scale), ptr(bw_fixed), max_rank, st,
                 ),
                 "meld_knn_refine(stage 2)",
             )
@@ -865,7 +867,7 @@ class HipOps:
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
-                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats)
+                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -927,6 +929,20 @@ class HipOps:
                 ),
                 "meld_knn_radius_exact(fill)",
             )
+            if knn_max is not None and fb_total > 0 and int(fb_cnt.max()) > int(knn_max):
+                # knn_max on the rows the sweep filled (everything inside the radius, unranked): keep the knn_max largest kernel
+                # values of a row (= its nearest cells; ties by column) -- a rare path, a few library sorts over the swept entries
+                rows_e = torch.repeat_interleave(torch.arange(n_flag_h, device=dev), fb_cnt.to(torch.int64))
+                o = torch.argsort(fb_col[:fb_total].to(torch.int64), stable=True)
+                o = o[torch.argsort(-fb_val[:fb_total][o], stable=True)]
+                o = o[torch.argsort(rows_e[o], stable=True)]
+                rank = torch.arange(fb_total, device=dev) - fb_off[:n_flag_h][rows_e[o]]
+                keep = o[rank < int(knn_max)]
+                keep = keep[torch.argsort(rows_e[keep], stable=True)]
+                fb_col, fb_val = fb_col[keep].contiguous(), fb_val[keep].contiguous()
+                fb_cnt = torch.clamp(fb_cnt, max=int(knn_max))
+                fb_off = _scan_i32(lib, fb_cnt, st)
+                fb_total = int(fb_off[n_flag_h].item())
         tm.stop("radius_exact")
 
         M = m_main + fb_total
@@ -1421,7 +1437,7 @@ def resolve_graph_params(N, knn, thresh, ksel):
 
 
 def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
-                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None):
+                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None, knn_max=None):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -1441,6 +1457,14 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     bw_scale = float(bandwidth_scale)
     if not (bw_scale > 0 and math.isfinite(bw_scale)):
         raise ValueError("bandwidth_scale must be positive and finite, got {!r}".format(bandwidth_scale))
+    if knn_max is not None:
+        knn_max = int(knn_max)
+        if knn_max < knn:  # [UPSTREAM kNNGraph.__init__]
+            raise ValueError("`knn_max` must be greater than or equal to `knn`")
+        if knn_max + 2 > ksel:  # (the candidate list has to hold them)
+            ksel = min(128, ((knn_max + 2 + 31) // 32) * 32)
+            if knn_max + 2 > ksel:
+                raise NotImplementedError("knn_max={} needs a candidate list beyond the 128 entries the search kernel holds".format(knn_max))
     bw_fixed = None
     if bandwidth is not None:
         if callable(bandwidth):
@@ -1467,7 +1491,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         tm.stop("reorder")
 
     keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats)
+                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max)
     if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
         bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:

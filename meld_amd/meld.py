@@ -130,13 +130,11 @@ class MELD(GraphEstimator):
 
         opts = dict(self.kwargs)
         opts.update(kwargs)
-        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx", "bandwidth", "bandwidth_scale")]
+        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx", "bandwidth", "bandwidth_scale", "knn_max")]
         if unsupported:
             raise NotImplementedError(
                 "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
             )
-        if self.decay is None and self.thresh == 0:
-            raise NotImplementedError("decay=None with thresh=0 (dense unweighted graph) is not implemented")
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         if isinstance(data, torch.Tensor):
@@ -164,7 +162,7 @@ class MELD(GraphEstimator):
             # affinities ("precomputed": told apart by its first diagonal entry, 0 = distances); no PCA, dense graph
             from .dense import build_precomputed_graph
 
-            if opts.get("sample_idx") is not None or opts.get("bandwidth") is not None or opts.get("bandwidth_scale") is not None:
+            if any(opts.get(k) is not None for k in ("sample_idx", "bandwidth", "bandwidth_scale", "knn_max")):
                 raise NotImplementedError("sample_idx / bandwidth options with a precomputed matrix are not implemented")
             kind = str(self.distance).lower()[len("precomputed"):].lstrip("_")
             if X.dim() != 2 or X.shape[0] != X.shape[1]:
@@ -184,14 +182,14 @@ class MELD(GraphEstimator):
 
         # (the metric enters through the data: cosine = the euclidean graph of the unit rows with the decay doubled)
         X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
-        bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale") if opts.get(k) is not None}
-        if bw_opts and (opts.get("sample_idx") is not None or self.thresh == 0 or self.decay is None
+        bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale", "knn_max") if opts.get(k) is not None}
+        if bw_opts and (opts.get("sample_idx") is not None or (self.thresh == 0 and self.decay is not None) or self.decay is None
                         or str(self.distance).lower() not in ("euclidean", "l2")):
-            raise NotImplementedError("bandwidth / bandwidth_scale are implemented for the sparse euclidean alpha-decay kNN graph only "
+            raise NotImplementedError("bandwidth / bandwidth_scale / knn_max are implemented for the sparse euclidean alpha-decay kNN graph only "
                                       "(not with sample_idx, thresh=0, decay=None or another distance)")
         if opts.get("sample_idx") is not None:
             # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
-            if self.thresh == 0:
+            if self.thresh == 0 and self.decay is not None:
                 raise NotImplementedError("sample_idx (MNN graph) with thresh=0 is not implemented")
             from .mnn import build_mnn_graph
 
@@ -201,7 +199,9 @@ class MELD(GraphEstimator):
             )
             G.bandwidth_to_metric = bw_to_metric
             return G
-        if self.thresh == 0:
+        # ([UPSTREAM graphtools api.Graph]: decay=None selects the kNN graph -- unweighted connectivity -- BEFORE thresh is looked
+        # at; only an alpha-decay kernel with thresh = 0 is the dense "exact" graph)
+        if self.thresh == 0 and self.decay is not None:
             from .dense import build_dense_graph
 
             G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy)

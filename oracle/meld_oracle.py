@@ -75,8 +75,13 @@ def knn_kernel(
     distance="euclidean",
     bandwidth=None,
     bandwidth_scale=1.0,
+    knn_max=None,
 ):
     """Directed alpha-decay kernel K (CSR, N x N, includes K_ii = 1).
+
+    ``knn_max`` ([UPSTREAM ``kNNGraph.build_kernel``: ``knn_max = self.knn_max + 1 if self.knn_max else None`` handed to
+    ``build_kernel_to_data``, where it caps every ``search_knn`` and ends the re-search with "search out to knn_max"]): a row
+    keeps its knn_max nearest cells (besides itself) at most.
 
     ``bandwidth`` / ``bandwidth_scale`` ([UPSTREAM graphtools ``kNNGraph(bandwidth=, bandwidth_scale=)``, forwarded by reference
     ``meld/meld.py:106,117-118``; ``build_kernel_to_data``: ``if bandwidth is None: bandwidth = distances[:, knn - 1]``, then
@@ -111,7 +116,9 @@ def knn_kernel(
     if knn > N - 2:
         knn = N - 2  # [UPSTREAM kNNGraph.__init__] (warns upstream)
     k1 = knn + 1
-    knn_max = N
+    if knn_max is not None and knn_max < knn:
+        raise ValueError("`knn_max` must be greater than or equal to `knn`")  # [UPSTREAM kNNGraph.__init__]
+    knn_max = N if knn_max is None else min(knn_max + 1, N)
     tree = NearestNeighbors(n_neighbors=k1, algorithm=algorithm if distance == "euclidean" else "auto", metric=distance, n_jobs=n_jobs).fit(X)
     if decay is None or thresh == 1:
         # [UPSTREAM graphtools kNNGraph.build_kernel_to_data]: without alpha decay the kernel is the binary
@@ -515,7 +522,7 @@ def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, 
 
 
 def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean",
-                bandwidth=None, bandwidth_scale=1.0):
+                bandwidth=None, bandwidth_scale=1.0, knn_max=None):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
     ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
     ``pca_reduce`` first.  ``sample_idx``: the MNN kernel between samples (``mnn_kernel``)."""
@@ -530,14 +537,14 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         W = weights_from_kernel(K)
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
-    if thresh == 0:
+    if thresh == 0 and decay is not None:  # ([UPSTREAM graphtools api.Graph]: decay=None picks the kNN graph before thresh is looked at)
         Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
         K = apply_anisotropy(symmetrize(Kd), anisotropy)
         W = weights_from_kernel(K)
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
     Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True, distance=distance,
-                          bandwidth=bandwidth, bandwidth_scale=bandwidth_scale)
+                          bandwidth=bandwidth, bandwidth_scale=bandwidth_scale, knn_max=knn_max)
     K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
     K.sort_indices()
     W = weights_from_kernel(K)

@@ -205,6 +205,34 @@ def test_precomputed_matrices_match_the_oracle(kind):
         meld_amd.MELD(distance=name, verbose=0).fit(M[:, :5])
 
 
+@pytest.mark.parametrize("case", ["mixture", "low_d", "iid_100d", "large_knn_max"])
+def test_knn_max_matches_the_oracle(case):
+    """graphtools' ``knn_max``: a row keeps its knn_max nearest cells (besides itself) at most -- through the candidate lists
+    (ranked in refine) and, on iid 100-d data where the lists cannot certify the radius, through the certified top ranks or the
+    exact sweep; against the oracle's restatement of ``build_kernel_to_data(knn_max=)``."""
+    mo = _oracle()
+    import meld_amd
+
+    rng = np.random.default_rng(4)
+    if case == "mixture":
+        X, knn, kmax = mo.synthetic_cells(6000, n_dims=50, seed=3)[0], 15, 20
+    elif case == "low_d":
+        X, knn, kmax = mo.synthetic_cells(3000, n_dims=5, seed=3)[0], 5, 8
+    elif case == "iid_100d":
+        X, knn, kmax = rng.normal(size=(600, 100)), 5, 9
+    else:
+        X, knn, kmax = mo.synthetic_cells(4000, n_dims=20, seed=3)[0], 10, 100
+    G = mo.build_graph(X, knn=knn, algorithm="brute", knn_max=kmax)
+    assert (np.diff(G.K_directed.indptr) <= kmax + 1).all()
+    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, knn_max=kmax)
+    _csr_close(DG.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
+    full = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn)
+    assert DG.nnz <= full.nnz and (case == "large_knn_max" or DG.nnz < full.nnz)
+    with pytest.raises(ValueError):
+        meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, knn_max=knn - 1)
+
+
 def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 
@@ -574,6 +602,9 @@ def test_unweighted_knn_graph_decay_none(n, d, knn):
     G = mo.build_graph(X, knn=knn, decay=None)
     W = op.graph.W
     assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-12
+    # thresh = 0 with decay=None is still the kNN graph (graphtools' api.Graph looks at decay first): the same W
+    W0 = meld_amd.MELD(knn=knn, decay=None, thresh=0, verbose=0).fit(X).graph.W
+    assert W0.nnz == W.nnz and abs(W0 - W).max() == 0
     lmax = mo.estimate_lmax(G.L, G.dw)
     op.graph.lmax = lmax
     dens = op.transform(labels)
