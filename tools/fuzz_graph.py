@@ -23,12 +23,20 @@ for c in range(n_cases):
     elif kind == "line": X = np.outer(np.linspace(0, 1, N), rng.normal(size=d)) + 1e-4 * rng.normal(size=(N, d))
     else: X = rng.standard_t(2.0, size=(N, d))
     knn = min(knn, N - 2)
-    tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g" % (kind, N, d, knn, decay, thresh, aniso)
+    # graphtools' bandwidth options (FUZZ_OPTIONS=1; drawn after everything else, so the plain cases keep their streams)
+    extra = {}
+    if os.environ.get("FUZZ_OPTIONS"):
+        o = rng.integers(0, 5)
+        if o == 1: extra = dict(bandwidth_scale=float(rng.choice([0.5, 0.8, 0.95, 1.2, 2.0])))
+        elif o == 2: extra = dict(bandwidth=float(np.abs(X).mean() * rng.choice([0.05, 0.3, 1.0])) + 1e-9)
+        elif o == 3: extra = dict(knn_max=int(knn + rng.integers(0, 20)))
+        elif o == 4: extra = dict(knn_max=int(knn + rng.integers(0, 20)), bandwidth_scale=float(rng.choice([0.8, 1.3])))
+    tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g %s" % (kind, N, d, knn, decay, thresh, aniso, extra or "")
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:  # (the generator has been advanced as the full run does)
         continue
     if os.environ.get("FUZZ_NO_ORACLE"):  # product only: does it build, is W symmetric and finite (hundreds of cases a minute)
         try:
-            DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso)
+            DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, **extra)
             A = sparse.csr_matrix(DG.W)
             asym = abs(A - A.T).max() if A.nnz else 0.0
             okv = np.isfinite(A.data).all() and asym <= 1e-15 * max(abs(A.data).max(), 1e-300) * 4
@@ -39,8 +47,8 @@ for c in range(n_cases):
             print("EXC ", tag, type(e).__name__, str(e)[:120], flush=True)
         continue
     try:
-        G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree")
-        DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso)
+        G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree", **extra)
+        DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, **extra)
         A, B = sparse.csr_matrix(DG.W), sparse.csr_matrix(G.W)
         A.sort_indices(); B.sort_indices()
         if A.nnz != B.nnz or not np.array_equal(A.indices, B.indices):
