@@ -348,7 +348,9 @@ int meld_csr_bucket_slots(void);
 int meld_coo_scatter_rows(const uint64_t* keys, const double* vals, int64_t n, int64_t row_begin, int64_t n_rows,
                           int32_t* cursor, int32_t* tcol, double* tval, meld_stream_t stream);
 int meld_csr_rows_sort_merge(const int32_t* cursor, int64_t n_rows, int32_t* tcol, double* tval, int32_t* ucnt,
-                             int32_t* flags, meld_stream_t stream);
+                             int32_t* flags,
+                             int symm /* how K and K^T combine [UPSTREAM graphtools kernel_symm]: 0 "+" (K + K^T) / 2, 1 "*" K o K^T, 2 "mnn" */,
+                             double theta /* symm 2: theta min(K, K^T) + (1 - theta) max(K, K^T) */, meld_stream_t stream);
 int meld_csr_compact_rows(const int64_t* rowptr, int64_t n_rows, const int32_t* tcol, const double* tval,
                           int32_t* col, double* val, meld_stream_t stream);
 /* The same, and sums[r] = diag + the row's sum on the way out: bit for bit what meld_csr_row_sums returns for the compacted rows. */

@@ -86,7 +86,7 @@ SIGNATURES = {
     "meld_coo_scatter_rows": (_i32, [_ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
     "meld_coo_emit_scatter": (_i32, [_i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "meld_coo_partition_remote": (_i32, [_ptr, _ptr, _i64, _i64, _i32, _i32, _i64, _ptr, _ptr, _ptr]),
-    "meld_csr_rows_sort_merge": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "meld_csr_rows_sort_merge": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _f64, _ptr]),
     "meld_csr_compact_rows": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "meld_csr_compact_rows_sums": (_i32, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _f64, _ptr, _ptr]),
     "meld_csr_row_sums": (_i32, [_ptr, _ptr, _i64, _f64, _ptr, _ptr]),

@@ -65,7 +65,7 @@ class Benchmarker(object):
         # instead of being stored and silently ignored (the graph would differ from the reference's for the same call)
         # (n_jobs and lmax do not change the graph: MELD / GraphEstimator take them, graphtools ran fit_graph(data, n_jobs=-1))
         known = {"knn", "decay", "thresh", "ksel", "sample_idx", "n_landmark", "verbose", "distance", "n_jobs", "lmax",
-                 "bandwidth", "bandwidth_scale", "knn_max"}
+                 "bandwidth", "bandwidth_scale", "knn_max", "kernel_symm", "theta"}
         unknown = sorted(k for k in kwargs if k not in known | {"anisotropy"})
         if unknown:
             raise NotImplementedError("graph options {} are not implemented by the MI355X graph builder".format(unknown))

@@ -486,9 +486,14 @@ __device__ __forceinline__ void csr_bitonic_sort(K (&key)[SL], int lane) {
 
 // sorts the bucket [base, base + n) by column in place, sums pairs of equal columns, returns the number of
 // distinct columns; *bad is set when a column occurs more than twice
+// symm: how the two directions of an entry combine [UPSTREAM graphtools BaseGraph.symmetrize_kernel; the bucket holds HALVES]:
+//   0  "+"    (K + K^T) / 2                     = a/2 + b/2 (an entry present in one direction only keeps its half)
+//   1  "*"    K o K^T                           = 4 (a/2)(b/2); one-directional entries vanish
+//   2  "mnn"  theta min(K, K^T) + (1 - theta) max(K, K^T), the missing direction counting as 0
+// All three are symmetric functions of the pair, so W stays bitwise symmetric.
 template <int SL>
 __device__ __forceinline__ int csr_row_merge(int* __restrict__ tcol, double* __restrict__ tval, int64_t base, int n, int lane,
-                                             bool* bad) {
+                                             bool* bad, int symm, double theta) {
   // keys (column : slot), slot < CSR_BUCKET = 2^8.  Columns below 2^24 - 1 -- every graph of fewer than 16.7 M cells -- fit a 32-bit
   // key with the slot: the network then compares and selects single words (the kernel is bound by the vector instructions of
   // its compare-exchanges, not by the exchanges themselves); same order, same result.  Decided per row, wave-uniformly.
@@ -564,10 +569,19 @@ __device__ __forceinline__ int csr_row_merge(int* __restrict__ tcol, double* __r
     const bool pair = valid && (i + 1 < n) && n1 == c[e];
     const bool triple = valid && (i + 2 < n) && n2 == c[e];
     any_bad |= triple;
-    is_head[e] = head;
+    double hv = pair ? v[e] + v1 : v[e];
+    bool keep_head = head;
+    if (symm == 1) {
+      hv = pair ? 4.0 * v[e] * v1 : 0.0;
+      keep_head = head && pair;
+    } else if (symm == 2) {
+      hv = pair ? 2.0 * (theta * fmin(v[e], v1) + (1.0 - theta) * fmax(v[e], v1)) : 2.0 * (1.0 - theta) * v[e];
+      keep_head = head && hv != 0.0;
+    }
+    is_head[e] = keep_head;
     head_col[e] = c[e];
-    head_val[e] = pair ? v[e] + v1 : v[e];
-    const unsigned long long hb = __ballot(head);
+    head_val[e] = hv;
+    const unsigned long long hb = __ballot(keep_head);
     head_pos[e] = total + __popcll(hb & ((1ull << lane) - 1ull));
     total += __popcll(hb);
   }
@@ -585,7 +599,7 @@ __device__ __forceinline__ int csr_row_merge(int* __restrict__ tcol, double* __r
 
 __global__ __launch_bounds__(256) void csr_rows_sort_merge_kernel(const int* __restrict__ cursor, int64_t n_rows,
                                                                   int* __restrict__ tcol, double* __restrict__ tval,
-                                                                  int* __restrict__ ucnt, int* __restrict__ flags) {
+                                                                  int* __restrict__ ucnt, int* __restrict__ flags, int symm, double theta) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
@@ -601,11 +615,11 @@ __global__ __launch_bounds__(256) void csr_rows_sort_merge_kernel(const int* __r
   bool bad = false;
   int total;
   if (n <= 64)
-    total = csr_row_merge<1>(tcol, tval, base, n, lane, &bad);
+    total = csr_row_merge<1>(tcol, tval, base, n, lane, &bad, symm, theta);
   else if (n <= 128)
-    total = csr_row_merge<2>(tcol, tval, base, n, lane, &bad);
+    total = csr_row_merge<2>(tcol, tval, base, n, lane, &bad, symm, theta);
   else
-    total = csr_row_merge<4>(tcol, tval, base, n, lane, &bad);
+    total = csr_row_merge<4>(tcol, tval, base, n, lane, &bad, symm, theta);
   if (lane == 0) {
     ucnt[r] = total;
     if (bad) atomicOr(flags, 2);
@@ -705,11 +719,13 @@ extern "C" int meld_coo_emit_scatter(int64_t q_count, const int32_t* cand_idx, c
 }
 
 extern "C" int meld_csr_rows_sort_merge(const int32_t* cursor, int64_t n_rows, int32_t* tcol, double* tval, int32_t* ucnt,
-                                        int32_t* flags, meld_stream_t stream) {
+                                        int32_t* flags, int symm, double theta, meld_stream_t stream) {
   MELD_CHECK_ARG(cursor && tcol && tval && ucnt && flags && n_rows > 0, "meld_csr_rows_sort_merge: bad arguments");
+  MELD_CHECK_ARG(symm >= 0 && symm <= 2 && (symm != 2 || (theta >= 0.0 && theta <= 1.0)),
+                 "meld_csr_rows_sort_merge: symm must be 0 (+), 1 (*) or 2 (mnn, theta in [0, 1])");
   MELD_HIP_CALL(hipMemsetAsync(flags, 0, sizeof(int32_t), S(stream)));
   hipLaunchKernelGGL(csr_rows_sort_merge_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, S(stream), cursor, n_rows,
-                     tcol, tval, ucnt, flags);
+                     tcol, tval, ucnt, flags, symm, theta);
   MELD_LAUNCH_CHECK("csr_rows_sort_merge_kernel");
   return MELD_OK;
 }

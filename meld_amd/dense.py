@@ -25,11 +25,17 @@ __all__ = ["build_dense_graph", "build_precomputed_graph", "exact_filter", "DENS
 DENSE_MAX_N = 16384
 
 
-def _graph_from_dense_kernel(K, anisotropy, bw, info):
-    """Directed dense kernel K [N, N] (device fp64) -> DeviceGraph: (K + K^T) / 2, anisotropy, zero diagonal
+def _graph_from_dense_kernel(K, anisotropy, bw, info, symm=(0, 0.0)):
+    """Directed dense kernel K [N, N] (device fp64) -> DeviceGraph: symmetrisation ((K + K^T) / 2 by default; ``symm`` as
+    ``graph.symm_code`` returns it), anisotropy, zero diagonal
     [UPSTREAM graphtools ``BaseGraph._build_kernel`` / ``symmetrize_kernel`` / ``apply_anisotropy``]."""
     N = int(K.shape[0])
-    K = (K + K.T) / 2
+    if symm[0] == 1:
+        K = K * K.T
+    elif symm[0] == 2:
+        K = symm[1] * torch.minimum(K, K.T) + (1.0 - symm[1]) * torch.maximum(K, K.T)
+    else:
+        K = (K + K.T) / 2
     if anisotropy != 0:
         dsum = K.sum(1)
         K = K / torch.pow(dsum[:, None] * dsum[None, :], anisotropy)
@@ -63,7 +69,7 @@ def _alpha_decay_dense(D, knn, decay, thresh):
     return K, bw
 
 
-def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
+def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
     N = int(X.shape[0])
     if N > DENSE_MAX_N:
         raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
@@ -73,10 +79,10 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1):
     D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
     D.fill_diagonal_(0.0)
     K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
-    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)))
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)), symm=symm)
 
 
-def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1):
+def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1, symm=(0, 0.0)):
     """A graph from a precomputed N x N matrix (``MELD(distance="precomputed" | "precomputed_distance" |
     "precomputed_affinity").fit(M)``: [UPSTREAM graphtools ``GraphEstimator._parse_input`` -> ``Graph(precomputed=...)`` ->
     ``TraditionalGraph.build_kernel``], reached from reference ``meld/meld.py:273``).  ``kind``: "distance" (pairwise
@@ -103,7 +109,7 @@ def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1)
             K = torch.where(K < thresh, torch.zeros_like(K), K)
     else:
         raise ValueError("Precomputed value {} not recognized. Choose from ['distance', 'affinity', 'adjacency']".format(kind))
-    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), precomputed=kind))
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), precomputed=kind), symm=symm)
 
 
 def exact_filter(graph, sig, kernel_of_lmax):

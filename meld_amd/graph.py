@@ -469,7 +469,7 @@ class HipOps:
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
-                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None):
+                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None, symm=(0, 0.0)):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -867,7 +867,7 @@ class HipOps:
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
-                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max)
+                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -962,7 +962,7 @@ class HipOps:
                                                 ptr(fb_off), ptr(fb_col), ptr(fb_val), fb_total, ptr(cursor), ptr(tcol), ptr(tval), st),
                       "meld_coo_emit_scatter")
                 tm.stop("coo_emit")
-                assembled = self._finish_buckets(cursor, tcol, tval, q_count, sums_diag=1.0)  # None: a bucket overflowed / a column thrice
+                assembled = self._finish_buckets(cursor, tcol, tval, q_count, sums_diag=1.0, symm=symm)  # None: a bucket overflowed / a column thrice
                 if assembled is not None and self.last_row_sums is not None:
                     assembled = assembled + (self.last_row_sums[1],)  # (kernel row sums incl. the unit diagonal)
                 tm.stop("symmetrize")
@@ -1017,7 +1017,7 @@ class HipOps:
                                                  int(cap), ptr(counts), ptr(send), _stream()), "meld_coo_partition_remote")
         return send, counts
 
-    def _finish_buckets(self, cursor, tcol, tval, n_rows, sums_diag=None):
+    def _finish_buckets(self, cursor, tcol, tval, n_rows, sums_diag=None, symm=(0, 0.0)):
         """Row buckets (meld_coo_scatter_rows / meld_coo_emit_scatter) -> CSR: every bucket sorted by column and its pairs
         of equal columns summed inside one wave, then compacted.  None when a bucket overflowed or a column occurs more
         than twice (the caller takes the sort-based path, whose summation order is defined)."""
@@ -1025,7 +1025,7 @@ class HipOps:
         i32 = dict(dtype=torch.int32, device=dev)
         ucnt = torch.empty(n_rows, **i32)
         flags = torch.empty(1, **i32)
-        check(lib.meld_csr_rows_sort_merge(ptr(cursor), n_rows, ptr(tcol), ptr(tval), ptr(ucnt), ptr(flags), st), "meld_csr_rows_sort_merge")
+        check(lib.meld_csr_rows_sort_merge(ptr(cursor), n_rows, ptr(tcol), ptr(tval), ptr(ucnt), ptr(flags), int(symm[0]), float(symm[1]), st), "meld_csr_rows_sort_merge")
         rowptr = _scan_i32(lib, ucnt, st)
         nnz, flag = (int(v) for v in torch.stack([rowptr[n_rows], flags[0].to(torch.int64)]).tolist())  # (one read-back)
         if flag != 0:
@@ -1436,8 +1436,26 @@ def resolve_graph_params(N, knn, thresh, ksel):
     return int(knn), thresh, int(ksel)
 
 
+def symm_code(kernel_symm, theta):
+    """(mode, theta) of ``meld_csr_rows_sort_merge`` for graphtools' ``kernel_symm`` / ``theta``
+    [UPSTREAM ``BaseGraph._check_symmetrization``: "+" | "*" | "mnn" | None; theta in [0, 1], 1 when not given]."""
+    if kernel_symm == "+":
+        return (0, 0.0)
+    if kernel_symm == "*":
+        return (1, 0.0)
+    if kernel_symm == "mnn":
+        if theta is None:
+            theta = 1.0
+        if not isinstance(theta, (int, float)) or theta < 0 or theta > 1:
+            raise ValueError("theta {} not recognized. Expected a float between 0 and 1".format(theta))
+        return (2, float(theta))
+    if kernel_symm is None:
+        raise NotImplementedError("kernel_symm=None (a directed kernel) is not implemented: the filter needs a symmetric Laplacian")
+    raise ValueError("kernel_symm '{}' not recognized. Choose from '+', '*', 'mnn', or 'none'.".format(kernel_symm))
+
+
 def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
-                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None, knn_max=None):
+                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None, knn_max=None, kernel_symm="+", theta=None):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -1457,6 +1475,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     bw_scale = float(bandwidth_scale)
     if not (bw_scale > 0 and math.isfinite(bw_scale)):
         raise ValueError("bandwidth_scale must be positive and finite, got {!r}".format(bandwidth_scale))
+    symm = symm_code(kernel_symm, theta)
     if knn_max is not None:
         knn_max = int(knn_max)
         if knn_max < knn:  # [UPSTREAM kNNGraph.__init__]
@@ -1491,7 +1510,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         tm.stop("reorder")
 
     keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max)
+                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
     if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
         bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:
@@ -1503,6 +1522,8 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         rowptr, col, val = asm[:3]
         ksum = asm[3] if len(asm) > 3 else None  # (the row sums came out of the buckets with the rows)
     else:
+        if symm[0] != 0:  # (the sort-based path -- overfull row buckets, MELD_ASSEMBLE=sort -- sums the two directions only)
+            raise NotImplementedError("kernel_symm={!r} is implemented on the row-bucket symmetrisation only".format(kernel_symm))
         rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
     del keys, vals
     tm.stop("symmetrize")

@@ -130,11 +130,17 @@ class MELD(GraphEstimator):
 
         opts = dict(self.kwargs)
         opts.update(kwargs)
-        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx", "bandwidth", "bandwidth_scale", "knn_max")]
+        unsupported = [k for k in opts if k not in ("ksel", "profile", "sample_idx", "bandwidth", "bandwidth_scale", "knn_max", "kernel_symm", "theta")]
         if unsupported:
             raise NotImplementedError(
                 "graph options {} are not implemented by the MI355X graph builder".format(sorted(unsupported))
             )
+        # graphtools' kernel_symm / theta (how K and K^T combine; "+" = (K + K^T) / 2 is the default the reference runs with)
+        from .graph import symm_code
+
+        symm = symm_code(opts.get("kernel_symm", "+"), opts.get("theta"))
+        if symm[0] != 0 and opts.get("sample_idx") is not None:
+            raise NotImplementedError("kernel_symm other than '+' with sample_idx (MNN graph) is not implemented")
         if not torch.cuda.is_available():
             raise RuntimeError("meld_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
         if isinstance(data, torch.Tensor):
@@ -169,7 +175,7 @@ class MELD(GraphEstimator):
                 raise ValueError("Precomputed {} must be a square matrix. {} was given".format(kind or "matrix", tuple(X.shape)))
             if not kind:
                 kind = "distance" if float(X[0, 0]) == 0.0 else "affinity"
-            return build_precomputed_graph(X, kind, knn=self.knn, decay=self.decay, thresh=self.thresh, anisotropy=self.anisotropy)
+            return build_precomputed_graph(X, kind, knn=self.knn, decay=self.decay, thresh=self.thresh, anisotropy=self.anisotropy, symm=symm)
         if self.n_pca is not None and self.n_pca < min(tuple(X.shape)):
             # graphtools reduces the data with PCA first (Data._reduce_data) and builds the graph on
             # the scores; here: exact top-n_pca subspace on the device (meld_amd/pca.py)
@@ -204,7 +210,7 @@ class MELD(GraphEstimator):
         if self.thresh == 0 and self.decay is not None:
             from .dense import build_dense_graph
 
-            G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy)
+            G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy, symm=symm)
             G.bandwidth_to_metric = bw_to_metric
             return G
         G = build_knn_graph(
@@ -213,6 +219,7 @@ class MELD(GraphEstimator):
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)), **bw_opts,
             # (the column statistics are those of the cells the graph is built on: not after a PCA / a metric front end)
             col_stats=col_stats if (self.data_nu is None and X is X_in) else None,
+            kernel_symm=opts.get("kernel_symm", "+"), theta=opts.get("theta"),
         )
         G.bandwidth_to_metric = bw_to_metric
         # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the

@@ -252,10 +252,19 @@ def semantic_kernel_dense(X, knn=5, decay=40, thresh=1e-4):
 # --------------------------------------------------------------------------------------------
 # A4  symmetrise, anisotropy, weights      A5  Laplacian
 # --------------------------------------------------------------------------------------------
-def symmetrize(K):
-    """[UPSTREAM graphtools ``BaseGraph.symmetrize_kernel`` with the default kernel_symm="+"]:
-    ``K <- (K + K^T) / 2``."""
-    return (K + K.T) / 2
+def symmetrize(K, kernel_symm="+", theta=None):
+    """[UPSTREAM graphtools ``BaseGraph.symmetrize_kernel``]: ``K <- (K + K^T) / 2`` with the default kernel_symm="+";
+    "*": ``K.multiply(K.T)``; "mnn": ``theta * min(K, K^T) + (1 - theta) * max(K, K^T)`` (theta = 1 when not given)."""
+    if kernel_symm == "+":
+        return (K + K.T) / 2
+    if kernel_symm == "*":
+        return K.multiply(K.T) if sparse.issparse(K) else K * K.T
+    if kernel_symm == "mnn":
+        theta = 1.0 if theta is None else theta
+        if sparse.issparse(K):
+            return theta * K.minimum(K.T) + (1 - theta) * K.maximum(K.T)
+        return theta * np.minimum(K, K.T) + (1 - theta) * np.maximum(K, K.T)
+    raise ValueError(kernel_symm)
 
 
 def apply_anisotropy(K, anisotropy=1):
@@ -522,7 +531,7 @@ def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, 
 
 
 def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean",
-                bandwidth=None, bandwidth_scale=1.0, knn_max=None):
+                bandwidth=None, bandwidth_scale=1.0, knn_max=None, kernel_symm="+", theta=None):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
     ``n_pca < min(X.shape)`` [UPSTREAM], which none of the BASELINE configs trigger) runs
     ``pca_reduce`` first.  ``sample_idx``: the MNN kernel between samples (``mnn_kernel``)."""
@@ -539,13 +548,14 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         return OracleGraph(Kd, K, W, L, dw)
     if thresh == 0 and decay is not None:  # ([UPSTREAM graphtools api.Graph]: decay=None picks the kNN graph before thresh is looked at)
         Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
-        K = apply_anisotropy(symmetrize(Kd), anisotropy)
+        K = apply_anisotropy(symmetrize(Kd, kernel_symm, theta), anisotropy)
         W = weights_from_kernel(K)
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
     Kd, info = knn_kernel(X, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm, return_intermediates=True, distance=distance,
                           bandwidth=bandwidth, bandwidth_scale=bandwidth_scale, knn_max=knn_max)
-    K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()
+    K = apply_anisotropy(symmetrize(Kd, kernel_symm, theta).tocsr(), anisotropy).tocsr()
+    K.eliminate_zeros()
     K.sort_indices()
     W = weights_from_kernel(K)
     L, dw = laplacian(W)

@@ -233,6 +233,31 @@ def test_knn_max_matches_the_oracle(case):
         meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, knn_max=knn - 1)
 
 
+@pytest.mark.parametrize("symm", [("*", None), ("mnn", None), ("mnn", 0.3), ("mnn", 0.0)])
+def test_kernel_symmetrisation_modes_match_the_oracle(symm):
+    """graphtools' ``kernel_symm`` / ``theta`` (reference meld/meld.py:106,117-118 forwards them): K o K^T and
+    theta min + (1 - theta) max instead of the default (K + K^T) / 2 -- in the row-bucket merge of the sparse builder and in
+    the dense builder -- against the oracle; W stays bitwise symmetric (the folded recurrence layout relies on it)."""
+    mo = _oracle()
+    import meld_amd
+
+    ks, th = symm
+    X, labels = mo.synthetic_cells(7000, n_dims=30, seed=12)
+    G = mo.build_graph(X, knn=9, algorithm="brute", kernel_symm=ks, theta=th)
+    op = meld_amd.MELD(knn=9, kernel_symm=ks, theta=th, verbose=0).fit(X)
+    _csr_close(op.graph.W, G.W, rtol=1e-9)
+    W = op.graph.W
+    assert abs(W - W.T).max() == 0
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+    Gd = mo.build_graph(X[:900], knn=9, thresh=0, decay=20, kernel_symm=ks, theta=th)
+    Wd = meld_amd.MELD(knn=9, thresh=0, decay=20, kernel_symm=ks, theta=th, verbose=0).fit(X[:900]).graph.W
+    np.testing.assert_allclose(np.asarray(Wd.todense()), np.asarray(Gd.W), rtol=1e-10, atol=1e-300)
+    with pytest.raises(ValueError):
+        meld_amd.MELD(kernel_symm="mnn", theta=1.5, verbose=0).fit(X[:500])
+    with pytest.raises(NotImplementedError):
+        meld_amd.MELD(kernel_symm=None, verbose=0).fit(X[:500])
+
+
 def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 

@@ -4,7 +4,7 @@
 # bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3), fabric traffic (PMC) of the hot kernels,
 # PMC passes over the search and the recurrence kernels, the per-wave timeline of a recurrence step, and the full-oracle
 # parity runs at 1M and 500k, the VertexFrequencyCluster line at 1M and the per-rank compute of the sharded driver.  Every file carries the commit; copy gpurun_out/prof_<tag>/* to profiles/.
-tag=${1:-r03}; commit=${2:-unknown}; quick=${3:-}
+tag=${1:-r05}; commit=${2:-unknown}; quick=${3:-}
 out=gpurun_out/prof_$tag; mkdir -p $out/pmc; export TMPDIR=/tmp
 stamp() { echo "# commit $commit, $(date -u +%Y-%m-%dT%H:%MZ), $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"; }
 cpu=""; [ "$quick" = "cpufull" ] && cpu="--cpu-full"   # (the 27-minute CPU protocol only when asked for)
@@ -63,6 +63,25 @@ print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1)
   CMD="python tools/time_wide.py 1000000 64" bash tools/pmc_kernel.sh cheby_step_wide 2>&1 | tail -15
   echo "# where the neighbours lie in the device order (tools/row_locality.py): the share of the nonzeros inside a window of rows"
   python tools/row_locality.py 2>&1 | grep -v amdgpu.ids | tail -8; } > $out/wide_spmm.txt
+# the wide kernel's fabric reads / L2 hit rate ride in traffic.json (per launch)
+python - $out/wide_spmm.txt $out/pmc/traffic.json $commit <<'PY'
+import json, re, sys
+vals, n = {}, 1
+for line in open(sys.argv[1]):
+    m = re.match(r"(\w+)\s+total ([0-9.e+]+) over (\d+) dispatches", line)
+    if m:
+        vals[m.group(1)] = float(m.group(2)); n = int(m.group(3))
+if vals.get("TCC_EA0_RDREQ_sum"):
+    d = json.load(open(sys.argv[2]))
+    rec = {"commit": sys.argv[3], "launches_averaged": n, "rdreq_per_launch": vals["TCC_EA0_RDREQ_sum"] / n,
+           "wrreq_per_launch": vals.get("TCC_EA0_WRREQ_sum", 0.0) / n,
+           "bytes_per_launch": (vals["TCC_EA0_RDREQ_sum"] * 128 + vals.get("TCC_EA0_WRREQ_sum", 0.0) * 64) / n,
+           "note": "tools/pmc_kernel.sh cheby_step_wide over tools/time_wide.py 1000000 64: RDREQ x 128 B + WRREQ x 64 B per 64-column product"}
+    if vals.get("TCC_HIT_sum") is not None and vals.get("TCC_MISS_sum"):
+        rec["tcc_hit_rate"] = vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])
+    d["cheby_step_wide@1000000x64cols"] = rec
+    json.dump(d, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
 { stamp; echo "# search ablations (-DK16_PROFILING build of knn16.hip; list-driven kernel) + what perfect seeds would be worth + list statistics"
   # (meld_amd/libmeld_hip_prof.so: built BEFORE the call, on the build host -- `bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING
   # -DK16_DEV_KB4`; the object files it links against do not travel to the GPU box)
@@ -71,5 +90,15 @@ print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1)
   MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats" | head -2
   } > $out/knn_ablation.txt
 { stamp; echo "# per-rank compute of the sharded driver on ONE GPU (stand-in collectives, results wrong by construction): tools/shard_emulate.py"
-  for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done; } > $out/shard_emulation.txt
+  for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done
+  echo "# rank 0 with the recurrences enqueued from C on a REAL one-rank RCCL communicator (RCCL=1: meld_cheby_run_sharded / meld_lanczos_steps_sharded), and the per-step Python loops beside it (RCCL=0)"
+  for g in 2 4 8; do for r in 1 0; do echo "## world $g, RCCL=$r"; RCCL=$r python tools/shard_emulate.py 1000000 $g 0 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done; done; } > $out/shard_emulation.txt
+{ stamp; echo "# stop rules of the lmax estimate on recorded Lanczos runs (tools/lmax_rule.py): residual rule of the product vs an eigenvalue-error rule"
+  python tools/lmax_rule.py 1000000 500000 200000 2>&1 | grep -v amdgpu.ids | grep -v "e+2[0-9][0-9]"; } > $out/lmax_rule.txt
+{ stamp; echo "# what a finer pruning granularity than 64 queries x 64 references would compute (tools/sim_granularity.py, the kernel's own rule per piece)"
+  python tools/sim_granularity.py 1000000 96 2>&1 | grep -v amdgpu.ids | tail -20; } > $out/knn_granularity.txt
+{ stamp; echo "# fuzz of the graph builder against the oracle, graphtools' bandwidth / knn_max options drawn (tools/fuzz_graph.py)"
+  FUZZ_OPTIONS=1 FUZZ_N_MAX=8000 timeout 900 python tools/fuzz_graph.py 80 7 2>&1 | grep -v amdgpu.ids | tail -85
+  echo "# product only (builds, symmetry, finiteness)"
+  FUZZ_OPTIONS=1 FUZZ_NO_ORACLE=1 timeout 400 python tools/fuzz_graph.py 300 11 2>&1 | grep -v amdgpu.ids | grep -v "^ok" | tail -12; } > $out/fuzz.txt
 ls -la $out $out/pmc

@@ -31,6 +31,10 @@ for c in range(n_cases):
         elif o == 2: extra = dict(bandwidth=float(np.abs(X).mean() * rng.choice([0.05, 0.3, 1.0])) + 1e-9)
         elif o == 3: extra = dict(knn_max=int(knn + rng.integers(0, 20)))
         elif o == 4: extra = dict(knn_max=int(knn + rng.integers(0, 20)), bandwidth_scale=float(rng.choice([0.8, 1.3])))
+        if "knn_max" in extra and kind in ("grid", "duplicates"):
+            # (which of several cells at exactly the cut distance a row keeps is the neighbour search's tie order -- sklearn's
+            # partition on one side, (distance, index) on the other: not comparable on data made of ties)
+            extra.pop("knn_max")
     tag = "%-10s N=%5d d=%2d knn=%2d decay=%g thresh=%g a=%g %s" % (kind, N, d, knn, decay, thresh, aniso, extra or "")
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:  # (the generator has been advanced as the full run does)
         continue
@@ -43,12 +47,22 @@ for c in range(n_cases):
             bad += not okv
             print("ok  " if okv else "BAD ", tag, "nnz %d asym %.1e flagged %d rebw %d" % (A.nnz, asym, DG.info["n_flagged_rows"], DG.info["n_rows_bandwidth_recomputed"]), flush=True)
         except Exception as e:
+            if isinstance(e, ValueError) and "no off-diagonal" in str(e) and ("bandwidth" in extra or "bandwidth_scale" in extra):
+                print("ok  ", tag, "no edges (bandwidth option)", flush=True)
+                continue
             bad += 1
             print("EXC ", tag, type(e).__name__, str(e)[:120], flush=True)
         continue
     try:
         G = mo.build_graph(X, knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, algorithm="kd_tree" if d <= 20 else "ball_tree", **extra)
-        DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, **extra)
+        try:
+            DG = meld_amd.build_knn_graph(torch.from_numpy(np.ascontiguousarray(X)).cuda(), knn=knn, decay=decay, thresh=thresh, anisotropy=aniso, **extra)
+        except ValueError as e:
+            # a bandwidth so small that no cell has a neighbour inside its radius: the oracle's graph has no edge, the product says so
+            if "no off-diagonal" in str(e) and sparse.csr_matrix(G.W).nnz == 0:
+                print("ok  ", tag, "no edges on either side", flush=True)
+                continue
+            raise
         A, B = sparse.csr_matrix(DG.W), sparse.csr_matrix(G.W)
         A.sort_indices(); B.sort_indices()
         if A.nnz != B.nnz or not np.array_equal(A.indices, B.indices):
