@@ -242,3 +242,22 @@ def test_metric_front_end_reduces_to_the_euclidean_search_or_refuses():
         metric_front_end(X, "manhattan", 40)
     with pytest.raises(ValueError):
         meld.MELD(distance="manhattan")
+
+
+def test_graph_option_validation_on_the_host():
+    """kernel_symm / theta codes of the merge kernel and the precomputed distance names are checked before any device work."""
+    import meld_amd
+    from meld_amd.graph import symm_code
+
+    assert symm_code("+", None) == (0, 0.0) and symm_code("*", None) == (1, 0.0)
+    assert symm_code("mnn", None) == (2, 1.0) and symm_code("mnn", 0.25) == (2, 0.25)
+    with pytest.raises(ValueError):
+        symm_code("mnn", 2.0)
+    with pytest.raises(ValueError):
+        symm_code("x", None)
+    with pytest.raises(NotImplementedError):
+        symm_code(None, None)
+    for name in ("precomputed", "precomputed_distance", "precomputed_affinity", "cosine", "euclidean"):
+        assert meld_amd.MELD(distance=name, verbose=0).distance == name
+    with pytest.raises(ValueError):
+        meld_amd.MELD(distance="precomputed_nonsense")
