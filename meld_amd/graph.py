@@ -446,10 +446,6 @@ class HipOps:
         self.block_order = os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0"
         # the first pass walks precomputed step lists (meld_knn16_step_lists) instead of testing the pruning table step by step
         self.step_lists = os.environ.get("MELD_KNN_STEP_LISTS", "1") != "0"
-        # hand a nearly empty last wave of search workgroups to a sliced launch (see directed_kernel_coo);
-        # measured at 1M cells: 154.8 ms with vs 148.2 ms without -- workgroups drift apart over the five
-        # waves and the sliced launch costs more than the idle tail, so it is off
-        self.split_tail = os.environ.get("MELD_KNN_SPLIT_TAIL", "0") != "0"
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
         self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
@@ -595,20 +591,7 @@ class HipOps:
             lb2 = block_order = step_list = step_cnt = None
             tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
-            # Workgroups run in waves of `resident` (occupancy x CUs).  A last wave that would leave most
-            # of the chip idle is searched separately with the references cut into slices, so that its
-            # few query blocks x slices fill the chip again.
             n_blocks = q_pad // BQ
-            q_main, tail_slices = q_count, 1
-            if not will_prune and self.split_tail:
-                resident = lib.meld_knn16_resident_blocks(d, nprod)
-                if resident < 0:
-                    check(resident, "meld_knn16_resident_blocks")
-                tail_blocks = n_blocks % resident if resident > 0 else 0
-                if n_blocks > resident and 0 < tail_blocks <= resident // 2:
-                    tail_slices = int(max(1, min(lib.meld_knn16_max_slices(ksel), resident // tail_blocks, n_tiles)))
-                    if tail_slices > 1:
-                        q_main = (n_blocks - tail_blocks) * BQ
             seeds = None
             knn_cut = knn  # the radius cut of the search follows the knn-th neighbour ...
             if bw_fixed is not None and cand_thr is not None:
@@ -623,7 +606,7 @@ class HipOps:
                 seeds[:q_count] = ((rad * rad + 1.01 * e_row) * scale_info[0].to(torch.float64) ** 2 * (1.0 + 1e-5)).to(torch.float32)
                 if q_pad > q_count:
                     seeds[q_count:] = seeds[q_count - 1]
-            elif self.seed and cand_thr is not None and q_begin % BQ == 0 and tail_slices == 1 and not cross:
+            elif self.seed and cand_thr is not None and q_begin % BQ == 0 and not cross:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
                 if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
@@ -661,7 +644,7 @@ class HipOps:
                 # launch walks every S-th entry of the block's list, MELD_KNN_LIST_SLICES=0 sends them to the table-driven kernel)
                 resident_all = lib.meld_knn16_resident_blocks(d, nprod)
                 few_blocks = resident_all > 0 and n_blocks < 2 * resident_all
-                want_lists = self.step_lists and seeds is not None and q_main == q_count and cand_thr is not None and nprod == 1 \
+                want_lists = self.step_lists and seeds is not None and cand_thr is not None and nprod == 1 \
                     and not (few_blocks and os.environ.get("MELD_KNN_LIST_SLICES", "1") == "0")
                 direct = want_lists and seeded_bounds and not spheres_shared and q_begin == 0 and q_count == N and not cross \
                     and os.environ.get("MELD_KNN_LIST_DIRECT", "1") != "0" and not os.environ.get("MELD_KNN_SYMMETRIC_BOUNDS_OFF")
@@ -687,7 +670,7 @@ class HipOps:
                     check(lib.meld_knn16_step_lists(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), 0 if cross else q_begin,
                                                     ptr(step_list), n_tiles, ptr(step_cnt), st), "meld_knn16_step_lists")
                     work = step_cnt
-                elif self.block_order and q_main == q_count and n_blocks > 1:
+                elif self.block_order and n_blocks > 1:
                     # longest query blocks first (the dispatch follows the block index): see meld_knn16_block_work
                     work = torch.empty(n_blocks, dtype=torch.int32, device=dev)
                     check(lib.meld_knn16_block_work(ptr(lb2), ptr(seeds), N, d, q_count, nprod, ptr(nmax), ptr(scale_info), ptr(work), st), "meld_knn16_block_work")
@@ -701,7 +684,7 @@ class HipOps:
             # 7-10 ms instead of 26 / 8).  The references are then cut into slices -- blocks x slices workgroups, each
             # with its own candidate rows, merged afterwards -- so that the heavy blocks are shared out.
             main_slices = 1
-            if will_prune and q_main == q_count and cand_thr is not None:
+            if will_prune and cand_thr is not None:
                 resident = lib.meld_knn16_resident_blocks(d, nprod)
                 if os.environ.get("MELD_KNN_MAIN_SLICES"):
                     main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
@@ -714,31 +697,21 @@ class HipOps:
                     s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
                     s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
                     if step_list is not None:
-                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
+                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
                     else:
-                        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
-                    check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_main, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
+                        check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
+                    check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_count, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
                 elif step_list is not None:
-                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
+                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
                 else:
-                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_main, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
+                    check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
                 # until its results are refined: work that does not depend on the graph (fit_transform's label
                 # factorisation: a host-blocking copy + a few small launches on a side stream) is started here
                 while _WHILE_SEARCHING:
                     _WHILE_SEARCHING.pop()()
-                if q_main < q_count:
-                    q_tail = q_count - q_main
-                    qt_pad = q_pad - q_main
-                    qb = lib.meld_knn16_query_bytes(d)
-                    t_idx = torch.empty(tail_slices * qt_pad * cap, dtype=torch.int32, device=dev)
-                    t_d2 = torch.empty(tail_slices * qt_pad * cap, dtype=torch.float32, device=dev)
-                    t_cnt = torch.empty(tail_slices * qt_pad, dtype=torch.int32, device=dev)
-                    check(lib.meld_knn16_topk(ptr(Q[q_main * qb:]), ptr(Qn[q_main:]), ptr(Rt), ptr(scale_info), NR, d, q_tail, ksel, nprod, tail_slices, None, ptr(nmax), 0 if cross else q_begin + q_main, None, 0, 1.0, ptr(t_idx), ptr(t_d2), ptr(t_cnt), None, ptr(tiles_done), None, st), "meld_knn16_topk(tail)")
-                    check(lib.meld_knn16_merge_slices(ptr(t_idx), ptr(t_d2), ptr(t_cnt), q_tail, ksel, tail_slices, ptr(cand_idx[q_main * cap:]), ptr(cand_d2[q_main * cap:]), ptr(cand_cnt[q_main:]), st), "meld_knn16_merge_slices(tail)")
-                    del t_idx, t_d2, t_cnt
             used_prune, used_seed = lb2 is not None or step_list is not None, seeds is not None
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             used_block_order = block_order is not None
@@ -983,7 +956,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), split_tail=bool(self.split_tail),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
