@@ -394,19 +394,35 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const double* __restrict
     part[(2 * g + blockIdx.x) * d + tid] = tmx;
   }
 }
+// one workgroup per column: 256 threads fold the per-workgroup partials (thread t: partials t, t + 256, ...), then a fixed tree
+// (a single workgroup walking all 3 x 1024 x d partials took 0.3 ms: more than the pass over X it finishes)
 __global__ __launch_bounds__(256) void col_stats_finish_kernel(const double* __restrict__ part, int grid, int d, double* __restrict__ sums,
                                                                double* __restrict__ mins, double* __restrict__ maxs) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+  __shared__ double ps[256], pmin[256], pmax[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
   double ts = 0.0, tmn = INFINITY, tmx = -INFINITY;
-  for (int b = 0; b < grid; ++b) {
+  for (int b = tid; b < grid; b += 256) {
     ts += part[((size_t)0 * grid + b) * d + c];
     tmn = fmin(tmn, part[((size_t)1 * grid + b) * d + c]);
     tmx = fmax(tmx, part[((size_t)2 * grid + b) * d + c]);
   }
-  sums[c] = ts;
-  mins[c] = tmn;
-  maxs[c] = tmx;
+  ps[tid] = ts;
+  pmin[tid] = tmn;
+  pmax[tid] = tmx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+      ps[tid] += ps[tid + w];
+      pmin[tid] = fmin(pmin[tid], pmin[tid + w]);
+      pmax[tid] = fmax(pmax[tid], pmax[tid + w]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sums[c] = ps[0];
+    mins[c] = pmin[0];
+    maxs[c] = pmax[0];
+  }
 }
 }  // namespace meld
 extern "C" size_t meld_col_stats_temp_bytes(int d) { return sizeof(double) * 3 * (size_t)meld::COL_STATS_GRID * (size_t)(d > 0 ? d : 1); }
@@ -418,7 +434,7 @@ extern "C" int meld_col_stats_f64(const double* X, int64_t N, int d, double* sum
   const int rpp = 256 / d;
   const int grid = (int)std::min<int64_t>(COL_STATS_GRID, ceil_div(N, rpp));
   hipLaunchKernelGGL(col_stats_kernel, dim3(grid), dim3(256), 0, S(stream), X, N, d, reinterpret_cast<double*>(temp));
-  hipLaunchKernelGGL(col_stats_finish_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, S(stream), reinterpret_cast<const double*>(temp), grid, d,
+  hipLaunchKernelGGL(col_stats_finish_kernel, dim3((unsigned)d), dim3(256), 0, S(stream), reinterpret_cast<const double*>(temp), grid, d,
                      sums, mins, maxs);
   MELD_LAUNCH_CHECK("col_stats_kernel");
   return MELD_OK;

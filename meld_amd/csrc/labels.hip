@@ -19,7 +19,8 @@ namespace meld {
 constexpr int FZ_MAXG = 64;     // dictionary entries (distinct labels)
 constexpr int FZ_MAXW = 16;     // words per label (64 bytes: numpy <U16 / S64)
 constexpr int FZ_THREADS = 256;
-constexpr int FZ_ROWS = 16;     // rows per thread and chunk
+constexpr int FZ_ROWS = 4;      // rows per thread and chunk (1024-row chunks: ~1000 workgroups at 1M cells; with 16 the 245 workgroups
+                                // walked 16 batches each, 0.2 ms beside the search)
 constexpr int FZ_CHUNK = FZ_THREADS * FZ_ROWS;
 
 struct FzDict {

@@ -18,6 +18,8 @@
 // registers.  HBM-bound: 12 B/nonzero streamed + vector traffic (roofline section).
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace meld {
@@ -530,7 +532,14 @@ extern "C" int meld_cheby_step_wide(const int64_t* rowptr, const int32_t* col, c
   if (n_rows == 0) return MELD_OK;
   const int64_t nblk = ceil_div(n_rows, 4 * WIDE_ROWS);
   const unsigned grid = (unsigned)(ceil_div(nblk, 8) * 8);
-  hipLaunchKernelGGL(cheby_step_wide_kernel, dim3(grid), dim3(256), 0, S(stream), rowptr, col, val, dw, n_rows, p, x_full, x_row_offset, z,
+  // (profiling hook, never set in production: MELD_WIDE_PADLDS=<bytes> of unused dynamic LDS lowers the workgroups per CU, i.e. the
+  // rows in flight per XCD -- the window of the iterate its L2 has to hold)
+  static const size_t pad_lds = [] { const char* e = getenv("MELD_WIDE_PADLDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+  if (pad_lds > 65536) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cheby_step_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds); done = true; }
+  }
+  hipLaunchKernelGGL(cheby_step_wide_kernel, dim3(grid), dim3(256), pad_lds, S(stream), rowptr, col, val, dw, n_rows, p, x_full, x_row_offset, z,
                      y, alpha, beta, gamma);
   MELD_LAUNCH_CHECK("cheby_step_wide_kernel");
   return MELD_OK;

@@ -20,7 +20,7 @@ import torch
 
 from .graph import DeviceGraph
 
-__all__ = ["build_dense_graph", "build_precomputed_graph", "exact_filter", "DENSE_MAX_N"]
+__all__ = ["build_dense_graph", "build_dense_knn_graph", "build_precomputed_graph", "exact_filter", "DENSE_MAX_N"]
 
 DENSE_MAX_N = 16384
 
@@ -62,6 +62,8 @@ def _alpha_decay_dense(D, knn, decay, thresh):
     """[UPSTREAM graphtools ``TraditionalGraph.build_kernel``]: bandwidth = the (knn+1)-th smallest entry of a row (self
     counted), K = exp(-(d / bw)^decay), NaN -> 1, K < thresh -> 0."""
     bw = torch.kthvalue(D, knn + 1, dim=1).values
+    if decay is None or decay == float("inf"):  # the unweighted kNN graph: connectivity of the knn + 1 nearest cells
+        return (D <= bw[:, None]).to(torch.float64), bw
     K = torch.exp(-torch.pow(D / bw[:, None], decay))
     K = torch.where(torch.isnan(K), torch.ones_like(K), K)
     if thresh > 0:
@@ -80,6 +82,22 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
     D.fill_diagonal_(0.0)
     K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
     return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)), symm=symm)
+
+
+def build_dense_knn_graph(X, knn, decay, thresh, anisotropy=1, symm=(0, 0.0)):
+    """The SPARSE kernel's semantics -- K_ij = exp(-(d_ij / bw_i)^decay) wherever that is >= thresh, bw_i = distance to the
+    knn-th neighbour [UPSTREAM kNNGraph.build_kernel_to_data] -- evaluated densely: the route for ``knn`` beyond the 126 the
+    candidate lists of the search kernel hold (graphtools has no such limit), up to ``DENSE_MAX_N`` cells."""
+    N = int(X.shape[0])
+    if N > DENSE_MAX_N:
+        raise NotImplementedError("knn={} needs a candidate list beyond the 128 entries the search kernel holds; the dense route "
+                                  "that serves such graphs is limited to N <= {}".format(knn, DENSE_MAX_N))
+    knn = min(int(knn), N - 2)
+    X = X.to(torch.float64)
+    D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    D.fill_diagonal_(0.0)
+    K, bw = _alpha_decay_dense(D, knn, decay, max(float(thresh), float(np.finfo(float).eps)))
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), dense_knn=True), symm=symm)
 
 
 def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1, symm=(0, 0.0)):

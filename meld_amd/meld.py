@@ -213,6 +213,13 @@ class MELD(GraphEstimator):
             G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy, symm=symm)
             G.bandwidth_to_metric = bw_to_metric
             return G
+        if min(int(self.knn), int(X.shape[0]) - 2) > 126 and not bw_opts:
+            # beyond the candidate lists of the search kernel (128 entries): the same kernel evaluated densely, small N only
+            from .dense import build_dense_knn_graph
+
+            G = build_dense_knn_graph(X, self.knn, decay_m, self.thresh, anisotropy=self.anisotropy, symm=symm)
+            G.bandwidth_to_metric = bw_to_metric
+            return G
         G = build_knn_graph(
             X, knn=self.knn, decay=float("inf") if decay_m is None else decay_m,  # None: unweighted kNN graph
             thresh=self.thresh, anisotropy=self.anisotropy,

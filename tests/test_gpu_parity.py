@@ -258,6 +258,19 @@ def test_kernel_symmetrisation_modes_match_the_oracle(symm):
         meld_amd.MELD(kernel_symm=None, verbose=0).fit(X[:500])
 
 
+def test_knn_beyond_the_candidate_lists_takes_the_dense_route():
+    """knn = 150 (the search kernel's lists hold 128): the same kernel semantics evaluated densely, against the oracle."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(1500, n_dims=10, seed=2)
+    G = mo.build_graph(X, knn=150, algorithm="brute")
+    op = meld_amd.MELD(knn=150, verbose=0).fit(X)
+    assert op.graph.info.get("dense_knn")
+    _csr_close(op.graph.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+
+
 def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 
