@@ -54,7 +54,7 @@ rm -rf gpurun_out/pmc_knn_$tag gpurun_out/pmc_spmm_$tag
 { stamp; echo "# the lmax estimate: wall time, serial convergence checks (MELD_LANCZOS_SPECULATE=0) against checks overlapped with the next batch: tools/time_lmax_sizes.py"
   for sp in 0 1; do MELD_LANCZOS_SPECULATE=$sp python tools/time_lmax_sizes.py 1000000 500000 200000 2>&1 | grep "^N="; done; } > $out/lmax.txt
 { stamp; for n in 1000000 500000; do echo "## N = $n"; MELD_COMMIT=$commit MELD_CPU_FULL_JSON=$out/cpu_full_size.json python tools/parity_200k.py $n 2>&1 | grep -v amdgpu.ids; done; } > $out/full_oracle_parity.txt
-{ stamp; python bench.py --cells 1000000 --steps 2 --warmup 1 --cpu-sample 0 --no-host-input --vfc 2>/dev/null | python -c "
+{ stamp; python bench.py --cells 1000000 --steps 2 --warmup 1 --cpu-sample 0 --no-host-input --no-extra --vfc 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({k: d[k] for k in ('vfc', 'roofline_vfc') if k in d}, indent=1))"; } > $out/vfc_1M.txt

@@ -20,7 +20,7 @@ args = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix="pmc_traffic_", dir="/tmp")
 env = dict(os.environ, TMPDIR="/tmp")
 cmd = ["rocprofv3", "--kernel-trace", "--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
-       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-host-input",
+       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-host-input", "--no-extra",
        "--cells", str(args.cells), "--dims", str(args.dims)]
 subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL)
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
