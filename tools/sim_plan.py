@@ -15,6 +15,9 @@ N = int(d["N"]); nnz = col.numel(); NB = 256
 deg = (rowptr[1:] - rowptr[:-1]).double()
 rows = torch.repeat_interleave(torch.arange(N, device="cuda"), rowptr[1:] - rowptr[:-1])
 A, B, C, T0 = 0.361e-3, 1.077e-3, 2.840e-3, 2.2
+if os.environ.get("MODEL"):  # "a,b,c,t0" of a newer fit (us per 1000 entries / distinct columns / rows, constant)
+    a_, b_, c_, t_ = (float(v) for v in os.environ["MODEL"].split(","))
+    A, B, C, T0 = a_ * 1e-3, b_ * 1e-3, c_ * 1e-3, t_
 
 
 def cuts_from_weights(w, rmax):
@@ -46,6 +49,28 @@ def evaluate(cuts, label):
     return t, E, D, R
 
 
+if os.environ.get("GRID"):  # planner weights (per entry, per far entry, per row) scored under the model, RMAX = 4080
+    far = {}
+    for win in (1000, 2000, 3000):
+        f = torch.zeros(N, device="cuda", dtype=torch.float64)
+        f.index_add_(0, rows, ((col - rows).abs() > win).double())
+        far[win] = f
+    evaluate(cuts_from_weights(0.361 * deg + 0.754 * far[2000] + 2.84, 4080), "product weights 0.361 deg + 0.754 far(>2000) + 2.84")
+    res = []
+    for win in far:
+        for wf in (0.4, 0.6, 0.8, 1.0, 1.3):
+            for wr in (2.0, 3.5, 5.0, 7.0):
+                w = A * 1e3 * deg + wf * far[win] + wr
+                cuts = cuts_from_weights(w, 4080)
+                blk = torch.bucketize(rows, cuts[1:], right=True); cblk = torch.bucketize(col, cuts[1:], right=True)
+                E = torch.bincount(blk, minlength=NB).double(); out = blk != cblk
+                D = torch.bincount(torch.unique(blk[out] * N + col[out]) // N, minlength=NB).double()
+                R = (cuts[1:] - cuts[:-1]).double()
+                t = T0 + A * E + B * D + C * R
+                res.append((float(t.max()), float(t.quantile(0.9)), win, wf, wr))
+    for r in sorted(res)[:12]:
+        print("max %.1f p90 %.1f   win %d  w_far %.2f  w_row %.1f  (w_entry %.3f)" % (r + (A * 1e3,)))
+    sys.exit(0)
 for rmax in (4080, 4608, 5120):
     c0 = cuts_from_weights(deg, rmax)
     t, E, D, R = evaluate(c0, "RMAX %d: equal entries (product)" % rmax)
