@@ -1017,7 +1017,7 @@ class HipOps:
         self.last_assemble = "bucket"
         return rowptr, col, val
 
-    def assemble_rows(self, keys, vals, row_begin, n_rows, N, foreign=False):
+    def assemble_rows(self, keys, vals, row_begin, n_rows, N, foreign=False, symm=(0, 0.0)):
         """Sum duplicate keys, build the CSR (sorted rows) of the local rows: by row buckets sorted inside one wave
         each (include/meld_hip.h, meld_coo_row_counts ...), or -- for the inputs that path refuses, and with
         ``MELD_ASSEMBLE=sort`` -- by a global radix sort + reduce-by-key.  ``foreign``: the input may hold entries of
@@ -1036,10 +1036,12 @@ class HipOps:
             tcol = torch.empty(n_rows * B, **i32)
             tval = torch.empty(n_rows * B, dtype=torch.float64, device=dev)
             check(lib.meld_coo_scatter_rows(ptr(keys), ptr(vals), n, row_begin, n_rows, ptr(cursor), ptr(tcol), ptr(tval), st), "meld_coo_scatter_rows")
-            done = self._finish_buckets(cursor, tcol, tval, n_rows)
+            done = self._finish_buckets(cursor, tcol, tval, n_rows, symm=symm)
             if done is not None:
                 return done
             del cursor, tcol, tval
+        if symm[0] != 0:  # (the sort path sums the two directions: graphtools' default only)
+            raise NotImplementedError("kernel_symm other than '+' is implemented on the row-bucket symmetrisation only")
         self.last_assemble = "sort" if n > 0 else "empty"
         if foreign and n > 0:
             rows = keys >> 32  # (the sentinel ~0 is -1 as int64: its row is negative)

@@ -187,3 +187,35 @@ def test_row_sums_out_of_the_compaction_equal_the_row_sum_kernel():
     s1 = HipOps().row_sums(rp, v1, n, 1.0)
     torch.cuda.synchronize()
     assert torch.equal(c1, c2) and torch.equal(v1, v2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("mode,theta", [(1, 0.0), (2, 1.0), (2, 0.35), (2, 0.0)])
+def test_symmetrisation_modes_of_the_bucket_merge(mode, theta):
+    """meld_csr_rows_sort_merge with symm = 1 ("*": K o K^T) and 2 ("mnn": theta min + (1 - theta) max, a missing direction
+    counting as 0) against the same formulas on scipy matrices; the result stays bitwise symmetric."""
+    from meld_amd.graph import HipOps
+
+    rng = np.random.default_rng(7)
+    N = 9000
+    i = np.repeat(np.arange(N), 15)
+    j = rng.integers(0, N, size=i.shape[0])
+    j[: N * 5] = (i[: N * 5] + rng.integers(1, 6, size=N * 5)) % N  # plenty of mutual pairs
+    keep = i != j
+    i, j = i[keep], j[keep]
+    _, first = np.unique(i.astype(np.int64) << 32 | j, return_index=True)
+    i, j = i[first], j[first]
+    v = rng.random(i.shape[0]) + 0.01
+    K = sparse.coo_matrix((v, (i, j)), shape=(N, N)).tocsr()
+    keys = np.concatenate([(i.astype(np.int64) << 32) | j, (j.astype(np.int64) << 32) | i])
+    vals = np.concatenate([0.5 * v, 0.5 * v])
+    rp, col, val = HipOps().assemble_rows(torch.from_numpy(keys).cuda(), torch.from_numpy(vals).cuda(), 0, N, N, symm=(mode, theta))
+    got = sparse.csr_matrix((val.cpu().numpy(), col.cpu().numpy(), rp.cpu().numpy()), shape=(N, N))
+    if mode == 1:
+        ref = K.multiply(K.T).tocsr()
+    else:
+        ref = (theta * K.minimum(K.T) + (1 - theta) * K.maximum(K.T)).tocsr()
+    ref.eliminate_zeros()
+    ref.sort_indices()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    np.testing.assert_allclose(got.data, ref.data, rtol=1e-14)
+    assert abs(got - got.T).max() == 0
