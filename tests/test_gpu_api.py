@@ -212,7 +212,9 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         meld.MELD(n_landmark=50, verbose=0).fit(data).graph.landmark_op
     with pytest.raises(NotImplementedError):
-        meld.MELD(verbose=0).fit(data, knn_max=10)  # graph kwargs the builder does not know (bandwidth / bandwidth_scale it does)
+        meld.MELD(verbose=0).fit(data, search_multiplier=3)  # a graph keyword the builder does not know (bandwidth, knn_max, kernel_symm ... it does)
+    with pytest.raises(NotImplementedError):
+        meld.MELD(verbose=0).fit(data, kernel_symm=None)  # a directed kernel
     with pytest.raises(NotImplementedError):
         meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
