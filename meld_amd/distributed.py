@@ -73,8 +73,33 @@ class Comm:
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 dist.broadcast_object_list(box, src=src, group=self.group)
                 h = C.c_void_p()
-                check(lib.meld_rccl_comm_create(box[0], self.world, self.rank, C.byref(h)), "meld_rccl_comm_create")
-                handle = h
+                ok = 0
+                try:
+                    check(lib.meld_rccl_comm_create(box[0], self.world, self.rank, C.byref(h)), "meld_rccl_comm_create")
+                    # one all-reduce and one in-place all-gather through the new communicator before it is trusted with the filter
+                    st = torch.cuda.current_stream().cuda_stream
+                    probe = torch.ones(4, dtype=torch.float64, device="cuda")
+                    check(lib.meld_rccl_all_reduce_sum_f64(h, C.c_void_p(probe.data_ptr()), 4, st), "meld_rccl_all_reduce_sum_f64")
+                    full = torch.full((self.world, 2), -1.0, dtype=torch.float64, device="cuda")
+                    full[self.rank] = float(self.rank)
+                    mine = full[self.rank]
+                    check(lib.meld_rccl_all_gather(h, C.c_void_p(mine.data_ptr()), C.c_void_p(full.data_ptr()), 16, st), "meld_rccl_all_gather")
+                    want = torch.arange(self.world, dtype=torch.float64, device="cuda")[:, None].expand(-1, 2)
+                    ok = int(bool((probe == float(self.world)).all()) and bool((full == want).all()))
+                except Exception:
+                    ok = 0
+                # every rank takes the same path: the C loops only if the communicator works on ALL of them
+                agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.group)
+                if int(agree.item()) == 1:
+                    handle = h
+                else:
+                    if h.value:
+                        lib.meld_rccl_comm_destroy(h)
+                    import warnings
+
+                    warnings.warn("meld_amd: the library's own RCCL communicator failed its self-check; the sharded recurrences run their "
+                                  "per-step loops over torch.distributed", RuntimeWarning)
         Comm._RCCL[key] = handle
         return handle
 

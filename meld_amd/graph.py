@@ -1247,6 +1247,14 @@ class HipOps:
         )
         return True
 
+    @staticmethod
+    def _slice_begin(G, comm):
+        """First row of this rank's slice of the full-length vectors: rank * rows_pad -- also for a rank beyond the last cell
+        (``G.row_begin`` is clipped to N there; it owns no rows but still takes part in every collective)."""
+        begin = int(comm.rank) * int(G.rows_pad)
+        assert G.n_rows == 0 or begin == G.row_begin, (begin, G.row_begin)
+        return begin
+
     def cheby_run_sharded(self, G, p, t_prev2, t_prev1, r, coeffs, alpha2, beta2):
         """Steps 2 .. len(coeffs) - 1 on a row shard in one call (``meld_cheby_run_sharded``: the local rows' kernel and the
         all-gather of the new slice enqueued back to back from C on the library's own RCCL communicator).  Returns None when
@@ -1263,7 +1271,7 @@ class HipOps:
         last = C.c_int(1)
         check(
             self.lib.meld_cheby_run_sharded(handle, C.byref(pt["struct"]) if pt is not None else None, ptr(G.rowptr), ptr(G.col), ptr(G.val),
-                                            ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, G.row_begin, p, ptr(t_prev2), ptr(t_prev1), ptr(r),
+                                            ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, self._slice_begin(G, comm), p, ptr(t_prev2), ptr(t_prev1), ptr(r),
                                             c.ctypes.data_as(C.c_void_p), int(c.shape[0]), float(alpha2), float(beta2), C.byref(last), _stream()),
             "meld_cheby_run_sharded",
         )
@@ -1281,7 +1289,7 @@ class HipOps:
         pt = self.pt_layout(G)
         check(
             self.lib.meld_lanczos_steps_sharded(handle, C.byref(pt["struct"]) if pt is not None else None, ptr(G.rowptr), ptr(G.col), ptr(G.val),
-                                                ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, G.row_begin, ptr(V[0]), ptr(V[1]), ptr(V[2]),
+                                                ptr(G.dw_dev), G.n_rows, G.nnz, G.rows_pad, self._slice_begin(G, comm), ptr(V[0]), ptr(V[1]), ptr(V[2]),
                                                 ptr(state), ptr(acc), ptr(alphas), ptr(betas), int(it_begin), int(n_iter), _stream()),
             "meld_lanczos_steps_sharded",
         )
