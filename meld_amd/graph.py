@@ -1438,7 +1438,7 @@ def symm_code(kernel_symm, theta):
 
 
 def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, profile=False, force_fallback=False,
-                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None, knn_max=None, kernel_symm="+", theta=None):
+                    reorder=True, bandwidth=None, bandwidth_scale=1.0, col_stats=None, knn_max=None, kernel_symm="+", theta=None, ops=None):
     """Data [N, d] -> DeviceGraph on one GPU.  Rows A2-A5 of SURVEY.md section 8(a).
 
     ``X`` is a CUDA fp64 tensor [N, d] (row-major).  Stages: centre + fp32 operands, MFMA
@@ -1450,7 +1450,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         raise TypeError("build_knn_graph expects a CUDA float64 tensor [N, d]")
     X = X.contiguous()
     N, d = int(X.shape[0]), int(X.shape[1])
-    ops = HipOps(X.device)
+    ops = ops if ops is not None else HipOps(X.device)
     tm = _Timer(profile)
     knn, thresh, ksel = resolve_graph_params(N, knn, thresh, ksel)
     # [UPSTREAM graphtools kNNGraph(bandwidth=, bandwidth_scale=)]: a given bandwidth (one number or one per cell) replaces the

@@ -152,11 +152,12 @@ class MELD(GraphEstimator):
         X_in = X
         # (one pass: a NaN or an infinity anywhere makes its column sum non-finite; isfinite(X).all() is three.  The pass is the
         # builder's own -- sums, minima, maxima of the columns, meld_col_stats_f64 -- and its results are handed on to it)
-        col_stats = None
+        col_stats = ops0 = None
         if X.dim() == 2 and X.shape[1] <= 256 and X.shape[0] > 0 and X.is_contiguous():
             from .graph import HipOps
 
-            col_stats = HipOps(X.device).col_stats(X)
+            ops0 = HipOps(X.device)
+            col_stats = ops0.col_stats(X)
             finite = bool(torch.isfinite(col_stats[0]).all())
         else:
             finite = bool(torch.isfinite(X.sum(dim=0)).all())
@@ -226,7 +227,7 @@ class MELD(GraphEstimator):
             ksel=opts.get("ksel"), profile=bool(opts.get("profile", False)), **bw_opts,
             # (the column statistics are those of the cells the graph is built on: not after a PCA / a metric front end)
             col_stats=col_stats if (self.data_nu is None and X is X_in) else None,
-            kernel_symm=opts.get("kernel_symm", "+"), theta=opts.get("theta"),
+            kernel_symm=opts.get("kernel_symm", "+"), theta=opts.get("theta"), ops=ops0,
         )
         G.bandwidth_to_metric = bw_to_metric
         # n_landmark (reference meld/meld.py:105,118 forwards it to graphtools): a graphtools LandmarkGraph has the
