@@ -51,6 +51,38 @@ def graph_summary(G):
     return dict(nnz=np.int64(G.W.nnz), dw=G.dw, rowptr=G.W.indptr.astype(np.int64), lmax=np.float64(G.lmax))
 
 
+G7_OPTIONS = [
+    ("scale", dict(bandwidth_scale=0.8)),
+    ("fixed", dict(bandwidth=2.9)),
+    ("knnmax", dict(knn_max=8)),
+    ("mnn", dict(kernel_symm="mnn", theta=0.3)),
+    ("prod", dict(kernel_symm="*")),
+]
+
+
+def g7_inputs():
+    return mo.synthetic_cells(1000, n_dims=8, seed=9)
+
+
+def make_g7():
+    """G7: the graph keywords the reference forwards to graphtools (meld/meld.py:106,117-118) -- bandwidth_scale, bandwidth,
+    knn_max, kernel_symm / theta -- on one small data set, knn = 7: per option the symmetrised weights, degrees, lmax and
+    densities (Chebyshev order 30).  The keyword names are graphtools' own, so tools/regen_golden_from_reference.py hands the
+    same dictionaries to the real stack."""
+    X, lab = g7_inputs()
+    store = dict(x_sha=sha(X), labels=lab)
+    for tag, kw in G7_OPTIONS:
+        G = mo.build_graph(X, knn=7, algorithm="brute", **kw)
+        samples, ind = mo.sample_indicators(lab)
+        dens = mo.meld_filter(ind, G, beta=60, chebyshev_order=30)
+        W = G.W.tocsr()
+        W.sort_indices()
+        store.update({tag + "_dens": dens, tag + "_dw": G.dw, tag + "_lmax": np.float64(G.lmax), tag + "_nnz": np.int64(W.nnz),
+                      tag + "_rowptr": W.indptr.astype(np.int64), tag + "_W_indices": W.indices.astype(np.int32), tag + "_W_data": W.data})
+    store["samples"] = samples
+    np.savez_compressed(os.path.join(HERE, "g7_graph_options_1000x8.npz"), **store)
+
+
 def main():
     out = {}
     # G1: exact solver on the dense thresh=0 graph (the reference's only known-answer test)
@@ -97,6 +129,7 @@ def main():
     samples, dens, G = mo.fit_transform(X, lab, knn=15, beta=60, chebyshev_order=30, return_graph=True, algorithm="brute")
     np.savez_compressed(os.path.join(HERE, "g6_c2mini_5000x50.npz"), x_sha=sha(X), labels_sha=sha(lab.astype("U4")),
                         samples=samples, dens=dens, bandwidth=G.info["bandwidth"], **graph_summary(G))
+    make_g7()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -355,6 +355,26 @@ def test_golden_small(fixture, kw):
         np.testing.assert_allclose(op.graph.bandwidth_host, g["bandwidth"], rtol=1e-12)
 
 
+@pytest.mark.gpu
+def test_golden_graph_options():
+    """G7: graphtools' bandwidth_scale / bandwidth / knn_max / kernel_symm through the estimator against the committed
+    fixture (oracle-derived; tools/regen_golden_from_reference.py hands the same keywords to the real stack)."""
+    meld = _meld()
+    from tests.golden import make_golden as mg
+
+    g = load("g7_graph_options_1000x8.npz")
+    X, labels = mg.g7_inputs()
+    assert mg.sha(X) == str(g["x_sha"])
+    for tag, kw in mg.G7_OPTIONS:
+        op = meld.MELD(knn=7, chebyshev_order=30, lmax=float(g[tag + "_lmax"]), verbose=0, **kw)
+        out = op.fit_transform(X, labels)
+        W = op.graph.W
+        assert W.nnz == int(g[tag + "_nnz"]) and np.array_equal(W.indptr, g[tag + "_rowptr"]) and np.array_equal(W.indices, g[tag + "_W_indices"]), tag
+        np.testing.assert_allclose(W.data, g[tag + "_W_data"], rtol=1e-9)
+        np.testing.assert_allclose(op.graph.dw, g[tag + "_dw"], rtol=1e-9)
+        _close(out.values, g[tag + "_dens"])
+
+
 def test_golden_readme_toy():
     meld = _meld()
     from tests.golden.make_golden import sha

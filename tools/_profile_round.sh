@@ -101,4 +101,11 @@ PY
   FUZZ_OPTIONS=1 FUZZ_N_MAX=8000 timeout 900 python tools/fuzz_graph.py 80 7 2>&1 | grep -v amdgpu.ids | tail -85
   echo "# product only (builds, symmetry, finiteness)"
   FUZZ_OPTIONS=1 FUZZ_NO_ORACLE=1 timeout 400 python tools/fuzz_graph.py 300 11 2>&1 | grep -v amdgpu.ids | grep -v "^ok" | tail -12; } > $out/fuzz.txt
+{ stamp; echo "# whole path against the whole oracle (brute-force kNN on all host cores) at other shapes and with graphtools' graph keywords: tools/parity_200k.py"
+  DIMS=20 KNN=5 SEED=3 python tools/parity_200k.py 300000 2>&1 | grep -v amdgpu.ids
+  DIMS=100 KNN=30 SEED=4 python tools/parity_200k.py 150000 2>&1 | grep -v amdgpu.ids
+  DIMS=10 KNN=10 SEED=5 OPTS='{"bandwidth_scale": 0.9}' python tools/parity_200k.py 250000 2>&1 | grep -v amdgpu.ids
+  DIMS=50 KNN=15 SEED=6 OPTS='{"knn_max": 20}' python tools/parity_200k.py 200000 2>&1 | grep -v amdgpu.ids
+  DIMS=30 KNN=12 SEED=7 OPTS='{"kernel_symm": "mnn", "theta": 0.4}' python tools/parity_200k.py 200000 2>&1 | grep -v amdgpu.ids
+  DIMS=3 KNN=15 SEED=8 python tools/parity_200k.py 400000 2>&1 | grep -v amdgpu.ids; } > $out/parity_shapes.txt
 ls -la $out $out/pmc

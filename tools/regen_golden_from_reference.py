@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Re-derive the golden fixtures G1-G6 from the REAL reference stack and diff them against
+"""Re-derive the golden fixtures G1-G7 from the REAL reference stack and diff them against
 tests/golden/*.npz (last sentence).
 
     python tools/regen_golden_from_reference.py [--reference /root/reference] [--write DIR]
@@ -154,6 +154,20 @@ def main(argv=None):
     assert mg.sha(X) == str(g["x_sha"])
     results["g6"] = _run_case(meld, pygsp, X, lab, g["lmax"], dict(knn=15, beta=60, chebyshev_order=30), 30)
     _compare("g6", results["g6"], g, report)
+
+    # G7: the graph keywords MELD forwards to graphtools (bandwidth_scale, bandwidth, knn_max, kernel_symm / theta)
+    g = load("g7_graph_options_1000x8.npz")
+    X, lab = mg.g7_inputs()
+    assert mg.sha(X) == str(g["x_sha"])
+    for tag, kw in mg.G7_OPTIONS:
+        r = _run_case(meld, pygsp, X, lab, g[tag + "_lmax"], dict(knn=7, beta=60, chebyshev_order=30, **kw), 30)
+        results["g7_" + tag] = r
+        for key, tol in (("dens", TOL_DENS), ("dw", TOL_W), ("W_data", TOL_W)):
+            e = _rel(r[key], g[tag + "_" + key])
+            report.append(("g7_" + tag, key, e, tol, e <= tol))
+        for key in ("nnz", "rowptr", "W_indices"):
+            same = np.array_equal(np.asarray(r[key]), np.asarray(g[tag + "_" + key]))
+            report.append(("g7_" + tag, key, 0.0 if same else np.inf, 0.0, bool(same)))
 
     bad = 0
     for name, key, err, tol, ok in report:
