@@ -84,20 +84,28 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
     return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)), symm=symm)
 
 
-def build_dense_knn_graph(X, knn, decay, thresh, anisotropy=1, symm=(0, 0.0)):
+# metrics that do not reduce to the euclidean search: pairwise distances by the library (torch.cdist), then the same kernel
+_CDIST_P = {"manhattan": 1.0, "cityblock": 1.0, "l1": 1.0, "chebyshev": float("inf")}
+
+
+def build_dense_knn_graph(X, knn, decay, thresh, anisotropy=1, symm=(0, 0.0), metric="euclidean"):
     """The SPARSE kernel's semantics -- K_ij = exp(-(d_ij / bw_i)^decay) wherever that is >= thresh, bw_i = distance to the
     knn-th neighbour [UPSTREAM kNNGraph.build_kernel_to_data] -- evaluated densely: the route for ``knn`` beyond the 126 the
     candidate lists of the search kernel hold (graphtools has no such limit), up to ``DENSE_MAX_N`` cells."""
     N = int(X.shape[0])
     if N > DENSE_MAX_N:
-        raise NotImplementedError("knn={} needs a candidate list beyond the 128 entries the search kernel holds; the dense route "
-                                  "that serves such graphs is limited to N <= {}".format(knn, DENSE_MAX_N))
+        raise NotImplementedError("knn={} beyond the 128 entries the search kernel's candidate lists hold, or a metric that does not "
+                                  "reduce to the euclidean search ({}): the dense route that serves such graphs is limited to "
+                                  "N <= {}".format(knn, metric, DENSE_MAX_N))
     knn = min(int(knn), N - 2)
     X = X.to(torch.float64)
-    D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    if metric in ("euclidean", "l2"):
+        D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    else:
+        D = torch.cdist(X, X, p=_CDIST_P[metric])
     D.fill_diagonal_(0.0)
     K, bw = _alpha_decay_dense(D, knn, decay, max(float(thresh), float(np.finfo(float).eps)))
-    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), dense_knn=True), symm=symm)
+    return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn), dense_knn=True, metric=metric), symm=symm)
 
 
 def build_precomputed_graph(M, kind, knn=5, decay=40, thresh=1e-4, anisotropy=1, symm=(0, 0.0)):

@@ -72,7 +72,8 @@ class GraphEstimator(object):
     random_state = attribute("random_state")
     knn = attribute("knn", default=5, on_set=[check_positive, check_int])
     decay = attribute("decay", default=40, on_set=partial(check_if_not, None, check_positive))
-    distance = attribute("distance", default="euclidean", on_set=partial(check_in, ["euclidean", "l2", "sqeuclidean", "cosine", "correlation", "precomputed", "precomputed_distance", "precomputed_affinity"]))
+    distance = attribute("distance", default="euclidean", on_set=partial(check_in, ["euclidean", "l2", "sqeuclidean", "cosine", "correlation", "manhattan", "cityblock", "l1", "chebyshev",
+                                                                           "precomputed", "precomputed_distance", "precomputed_affinity"]))
     n_jobs = attribute("n_jobs", default=1, on_set=check_int)
     verbose = attribute("verbose", default=0)
     thresh = attribute("thresh", default=1e-4, on_set=partial(check_if_not, 0, check_positive))

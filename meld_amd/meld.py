@@ -187,6 +187,14 @@ class MELD(GraphEstimator):
             self.data_nu = X
         from .graph import metric_front_end
 
+        if str(self.distance).lower() in ("manhattan", "cityblock", "l1", "chebyshev"):
+            # metrics that are no function of the euclidean distance of transformed rows: the matrix pipe's search does not apply;
+            # the same kernel on library pairwise distances, densely, up to DENSE_MAX_N cells
+            from .dense import build_dense_knn_graph
+
+            if any(opts.get(k) is not None for k in ("sample_idx", "bandwidth", "bandwidth_scale", "knn_max")) or (self.thresh == 0 and self.decay is not None):
+                raise NotImplementedError("distance={!r} is implemented for the plain alpha-decay / unweighted kNN graph only".format(self.distance))
+            return build_dense_knn_graph(X, self.knn, self.decay, self.thresh, anisotropy=self.anisotropy, symm=symm, metric=str(self.distance).lower())
         # (the metric enters through the data: cosine = the euclidean graph of the unit rows with the decay doubled)
         X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
         bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale", "knn_max") if opts.get(k) is not None}

@@ -218,7 +218,24 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
-        meld.MELD(distance="manhattan")  # (euclidean and cosine are built)
+        meld.MELD(distance="mahalanobis")  # (euclidean-reducible metrics on the search kernel, manhattan / chebyshev densely)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["manhattan", "chebyshev"])
+def test_metrics_outside_the_euclidean_search_take_the_dense_route(metric):
+    """manhattan / chebyshev: no function of the euclidean distance, so the matrix-pipe search does not apply; the same kernel on
+    library pairwise distances (small N), against the oracle, which hands the metric to sklearn."""
+    meld = _meld()
+    mo = _oracle()
+    X, labels = mo.synthetic_cells(1800, n_dims=6, seed=21)
+    G = mo.build_graph(X, knn=7, algorithm="brute", distance=metric)
+    op = meld.MELD(knn=7, distance=metric, verbose=0).fit(X)
+    W = op.graph.W
+    assert W.nnz == G.W.nnz and abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+    big = np.zeros((20000, 3))
+    with pytest.raises(NotImplementedError):
+        meld.MELD(distance=metric, verbose=0).fit(big)
 
 
 @pytest.mark.gpu

@@ -240,8 +240,9 @@ def test_metric_front_end_reduces_to_the_euclidean_search_or_refuses():
         metric_front_end(Z, "correlation", 40)
     with pytest.raises(NotImplementedError, match="manhattan"):
         metric_front_end(X, "manhattan", 40)
+    assert meld.MELD(distance="manhattan", verbose=0).distance == "manhattan"  # (served densely at small N, meld_amd/dense.py)
     with pytest.raises(ValueError):
-        meld.MELD(distance="manhattan")
+        meld.MELD(distance="mahalanobis")
 
 
 def test_graph_option_validation_on_the_host():
