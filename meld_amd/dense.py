@@ -20,7 +20,7 @@ import torch
 
 from .graph import DeviceGraph
 
-__all__ = ["build_dense_graph", "build_dense_knn_graph", "build_precomputed_graph", "exact_filter", "DENSE_MAX_N"]
+__all__ = ["build_dense_graph", "build_dense_mnn_graph", "build_dense_knn_graph", "build_precomputed_graph", "exact_filter", "DENSE_MAX_N"]
 
 DENSE_MAX_N = 16384
 
@@ -82,6 +82,46 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
     D.fill_diagonal_(0.0)
     K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
     return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)), symm=symm)
+
+
+def build_dense_mnn_graph(X, sample_idx, knn=5, decay=40, anisotropy=1, beta=1.0):
+    """``sample_idx`` with ``thresh=0``: graphtools' MNN kernel over "exact" per-sample subgraphs
+    [UPSTREAM ``MNNGraph.build_kernel`` -> ``TraditionalGraph.build_kernel`` / ``build_kernel_to_data``] -- the block of a
+    sample with itself is its symmetrised dense alpha-decay kernel, the block from sample i to sample j uses the distance
+    to the knn-th cell of j as bandwidth and has its rows scaled by min(1, within_i / between_ij) * beta; nothing dropped."""
+    N = int(X.shape[0])
+    if N > DENSE_MAX_N:
+        raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
+    sample_idx = np.asarray(sample_idx)
+    if sample_idx.ndim != 1 or sample_idx.shape[0] != N:
+        raise ValueError("sample_idx ({}) must be the same length as data ({})".format(sample_idx.shape[0], N))
+    samples, codes = np.unique(sample_idx, return_inverse=True)
+    if len(samples) == 1:
+        raise ValueError("sample_idx must contain more than one unique value")
+    X = X.to(torch.float64)
+    members = [torch.from_numpy(np.nonzero(codes == s)[0]).to(X.device) for s in range(len(samples))]
+    for s, m in zip(samples, members):
+        if m.shape[0] < 3:
+            raise ValueError("sample {!r} has {} cells; every sample needs at least 3".format(s, int(m.shape[0])))
+    parts = [X.index_select(0, m) for m in members]
+    K = torch.zeros(N, N, dtype=torch.float64, device=X.device)
+    for i, (mi, Xi) in enumerate(zip(members, parts)):
+        D = torch.cdist(Xi, Xi, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+        D.fill_diagonal_(0.0)
+        Kii, _ = _alpha_decay_dense(D, min(int(knn), int(Xi.shape[0]) - 2), decay, 0.0)
+        Kii = (Kii + Kii.T) / 2
+        K[mi[:, None], mi[None, :]] = Kii
+        within = Kii.sum(1)
+        for j, (mj, Xj) in enumerate(zip(members, parts)):
+            if i == j:
+                continue
+            D = torch.cdist(Xi, Xj, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+            bw = torch.kthvalue(D, min(int(knn), int(Xj.shape[0]) - 1), dim=1).values
+            Kij = torch.exp(-torch.pow(D / bw[:, None], decay))
+            Kij = torch.where(torch.isnan(Kij), torch.ones_like(Kij), Kij)
+            scale = torch.clamp(within / Kij.sum(1), max=1.0) * float(beta)
+            K[mi[:, None], mj[None, :]] = Kij * scale[:, None]
+    return _graph_from_dense_kernel(K, anisotropy, None, dict(knn=int(knn), graph="mnn", n_samples=len(samples)))
 
 
 # metrics that do not reduce to the euclidean search: pairwise distances by the library (torch.cdist), then the same kernel

@@ -204,8 +204,12 @@ class MELD(GraphEstimator):
                                       "(not with sample_idx, thresh=0, decay=None or another distance)")
         if opts.get("sample_idx") is not None:
             # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
-            if self.thresh == 0 and self.decay is not None:
-                raise NotImplementedError("sample_idx (MNN graph) with thresh=0 is not implemented")
+            if self.thresh == 0 and self.decay is not None:  # "exact" subgraphs: the dense route
+                from .dense import build_dense_mnn_graph
+
+                G = build_dense_mnn_graph(X, opts["sample_idx"], knn=self.knn, decay=decay_m, anisotropy=self.anisotropy)
+                G.bandwidth_to_metric = bw_to_metric
+                return G
             from .mnn import build_mnn_graph
 
             G = build_mnn_graph(

@@ -530,6 +530,43 @@ def mnn_kernel(X, sample_idx, knn=5, decay=40, thresh=1e-4, beta=1.0, n_jobs=1, 
     return K
 
 
+def mnn_kernel_dense(X, sample_idx, knn=5, decay=40, beta=1.0):
+    """The MNN kernel with ``thresh == 0`` (dense N x N).
+
+    [UPSTREAM graphtools 1.5.x ``MNNGraph.build_kernel``]: with ``thresh = 0`` and a decay every per-sample subgraph is the
+    "exact" ``TraditionalGraph`` (``dense_kernel``, symmetrised with '+'), and the block from sample i to sample j is
+    ``TraditionalGraph.build_kernel_to_data(X_i, knn)`` of subgraph j: ``cdist``, bandwidth = the largest of the ``knn``
+    smallest entries of a row (no self among the references), ``exp(-(d / bw)^decay)``, NaN -> 1, nothing dropped; rows
+    scaled by ``min(1, within_i / between_ij) * beta`` as in ``mnn_kernel``.  PARITY: unpinned."""
+    from scipy.spatial.distance import cdist
+
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    sample_idx = np.asarray(sample_idx)
+    if sample_idx.shape[0] != X.shape[0]:
+        raise ValueError("sample_idx ({}) must be the same length as data ({})".format(sample_idx.shape[0], X.shape[0]))
+    samples = np.unique(sample_idx)
+    if len(samples) == 1:
+        raise ValueError("sample_idx must contain more than one unique value")
+    N = X.shape[0]
+    members = [np.nonzero(sample_idx == s)[0] for s in samples]
+    K = np.zeros((N, N))
+    for i, mi in enumerate(members):
+        Kii = symmetrize(dense_kernel(X[mi], knn=knn, decay=decay, thresh=0.0))
+        K[np.ix_(mi, mi)] = Kii
+        within = Kii.sum(1)
+        for j, mj in enumerate(members):
+            if i == j:
+                continue
+            pdx = cdist(X[mi], X[mj], metric="euclidean")
+            kk = min(knn, len(mj) - 1)  # (np.partition needs knn < len(row); upstream fails beyond that)
+            bandwidth = np.max(np.partition(pdx, kk, axis=1)[:, :kk], axis=1)
+            Kij = np.exp(-1 * np.power((pdx.T / bandwidth).T, decay))
+            Kij = np.where(np.isnan(Kij), 1, Kij)
+            scale = np.minimum(1, within / Kij.sum(1)) * beta
+            K[np.ix_(mi, mj)] = Kij * scale[:, None]
+    return K
+
+
 def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorithm="ball_tree", n_pca=None, sample_idx=None, distance="euclidean",
                 bandwidth=None, bandwidth_scale=1.0, knn_max=None, kernel_symm="+", theta=None):
     """A1-A5: data -> OracleGraph.  ``n_pca`` (None = off; graphtools only reduces when
@@ -539,6 +576,12 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         X = pca_reduce(X, n_pca)
     if distance != "euclidean" and (sample_idx is not None or thresh == 0):
         raise NotImplementedError("the oracle restates non-euclidean distances for the kNN graph only")
+    if sample_idx is not None and thresh == 0 and decay is not None:
+        Kd = mnn_kernel_dense(X, sample_idx, knn=knn, decay=decay)
+        K = apply_anisotropy(symmetrize(Kd), anisotropy)
+        W = weights_from_kernel(K)
+        L, dw = laplacian(W)
+        return OracleGraph(Kd, K, W, L, dw)
     if sample_idx is not None:
         Kd = mnn_kernel(X, sample_idx, knn=knn, decay=decay, thresh=thresh, n_jobs=n_jobs, algorithm=algorithm)
         K = apply_anisotropy(symmetrize(Kd), anisotropy).tocsr()

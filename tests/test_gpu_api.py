@@ -215,8 +215,6 @@ def test_unsupported_options_fail_loudly():
         meld.MELD(verbose=0).fit(data, search_multiplier=3)  # a graph keyword the builder does not know (bandwidth, knn_max, kernel_symm ... it does)
     with pytest.raises(NotImplementedError):
         meld.MELD(verbose=0).fit(data, kernel_symm=None)  # a directed kernel
-    with pytest.raises(NotImplementedError):
-        meld.MELD(thresh=0, verbose=0).fit(data, sample_idx=labels)
     with pytest.raises(ValueError):
         meld.MELD(distance="mahalanobis")  # (euclidean-reducible metrics on the search kernel, manhattan / chebyshev densely)
 
@@ -646,6 +644,32 @@ def test_mnn_graph_matches_the_oracle(decay):
     dens = op.transform(labels)
     ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
     assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_mnn_graph_with_exact_subgraphs_matches_the_oracle():
+    """sample_idx with thresh=0: graphtools builds the MNN kernel over dense "exact" subgraphs; same weights (1e-9) and
+    densities (1e-5 rel) as the oracle's restatement."""
+    import meld_amd
+    from oracle import meld_oracle as mo
+
+    X, batch = _two_batches()
+    X, batch = X[:900], batch[:900]
+    labels = np.random.default_rng(6).choice(["ctrl", "expt"], size=X.shape[0])
+    op = meld_amd.MELD(knn=6, thresh=0, chebyshev_order=30, verbose=0)
+    dens = op.fit_transform(X, labels, sample_idx=batch)
+    assert op.graph.info["graph"] == "mnn" and op.graph.info["dense"]
+    G = mo.build_graph(X, knn=6, thresh=0, sample_idx=batch)
+    W = op.graph.W.toarray()
+    assert abs(W - G.W).max() <= 1e-9 * abs(G.W).max()
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-9)
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    op.graph.lmax = lmax
+    dens = op.transform(labels)
+    ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
+    assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(ValueError, match="more than one unique"):
+        meld_amd.MELD(thresh=0, verbose=0).fit(X, sample_idx=np.zeros(900))
 
 
 @pytest.mark.gpu
