@@ -24,12 +24,6 @@
 namespace meld {
 
 constexpr int RB_FALL = 8;  // flagged rows per workgroup in the exact sweep
-#ifndef RF_STAGED
-#define RF_STAGED 1  // candidate rows through LDS (d even); 0 = every lane walks its own candidate's row
-#endif
-#ifndef RF_KS
-#define RF_KS 13     // 16-byte chunks of a row per staged slab: 64 x RF_KS x 16 B of LDS per wave (odd: conflict-free reads)
-#endif
 #ifndef RF_U
 #define RF_U 5  // 16-byte loads of a candidate row in flight per lane in refine_kernel (measured at d = 50: 5 -> 3.3 ms,
                // 8 -> 4.1 ms, 12 -> 5.7 ms: more registers per lane cost more occupancy than they add in flight)
@@ -85,62 +79,6 @@ __global__ __launch_bounds__(256) void refine_kernel(
 
   double dist[2];
   int idx[2];
-#if RF_STAGED
-  // d even (rows 16-byte aligned): the candidate rows of a wave come in through LDS.  A lane walking its own candidate's row
-  // (the loop below) makes every load instruction touch 64 cache lines, one per lane, and with a few waves per SIMD the
-  // lines are evicted from the vector L1 between two of a lane's loads: measured 3.3 ms at 1M x 50.  Here the wave copies a
-  // slab of RF_KS 16-byte chunks of each gathered row with FLAT indexing -- consecutive lanes take consecutive chunks of
-  // one row, an instruction touches ~10 lines and consumes them whole -- and each lane then reads its candidate's slab
-  // from LDS (stride RF_KS chunks, odd: conflict-free) in the SAME summation order as before: bit-identical distances.
-  __shared__ double2 stage[4][64 * RF_KS];
-  if ((d & 1) == 0) {
-    double2* st = stage[threadIdx.x >> 6];
-    const double2* X2 = reinterpret_cast<const double2*>(X);
-    const double2* xi2 = reinterpret_cast<const double2*>(xi);
-    const int nk = d / 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int c = lane + 64 * e;
-      const bool want = c < n && (double)cand_d2[ro + c] <= skip_above;
-      idx[e] = c < n ? cand_idx[ro + c] : 0x7fffffff;
-      const unsigned long long wm = __ballot(want);
-      const int m_e = wm ? 64 - __clzll((long long)wm) : 0;  // (the list is sorted by approximate d2: a prefix)
-      double s = 0.0, s1 = 0.0;
-      if (m_e) {
-        const int total = m_e * RF_KS;
-        for (int k0 = 0; k0 < nk; k0 += RF_KS) {
-          const int ks = min(RF_KS, nk - k0);
-          double2 b[RF_KS];
-#pragma unroll
-          for (int i = 0; i < RF_KS; ++i) {
-            const int f = lane + 64 * i;
-            const int cc = f / RF_KS, k = f - cc * RF_KS;
-            const int j = __shfl(idx[e], cc, 64);
-            b[i] = make_double2(0.0, 0.0);
-            if (f < total && k < ks) b[i] = X2[(int64_t)j * nk + k0 + k];
-          }
-#pragma unroll
-          for (int i = 0; i < RF_KS; ++i) {
-            const int f = lane + 64 * i;
-            if (f < total) st[f] = b[i];
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < m_e) {
-            for (int k = 0; k < ks; ++k) {
-              const double2 a = xi2[k0 + k], bb = st[lane * RF_KS + k];
-              const double t0 = a.x - bb.x, t1 = a.y - bb.y;
-              s = fma(t0, t0, s);
-              s1 = fma(t1, t1, s1);
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      dist[e] = want ? sqrt(s + s1) : INFINITY;
-    }
-  } else
-#endif
-  {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int c = lane + 64 * e;
@@ -194,8 +132,6 @@ __global__ __launch_bounds__(256) void refine_kernel(
       if (c >= n) idx[e] = 0x7fffffff;
       dist[e] = INFINITY;
     }
-  }
-
   }
 
   // rank of each candidate by (dist, idx); the entry with rank == knn is the bandwidth.  The list is sorted by

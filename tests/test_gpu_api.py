@@ -654,7 +654,6 @@ def test_mnn_graph_with_exact_subgraphs_matches_the_oracle():
     from oracle import meld_oracle as mo
 
     X, batch = _two_batches()
-    X, batch = X[:900], batch[:900]
     labels = np.random.default_rng(6).choice(["ctrl", "expt"], size=X.shape[0])
     op = meld_amd.MELD(knn=6, thresh=0, chebyshev_order=30, verbose=0)
     dens = op.fit_transform(X, labels, sample_idx=batch)
@@ -669,7 +668,7 @@ def test_mnn_graph_with_exact_subgraphs_matches_the_oracle():
     ref = mo.meld_filter(mo.sample_indicators(labels)[1], G, beta=60, chebyshev_order=30, lmax=lmax)
     assert np.abs(dens.values - ref).max() <= 1e-5 * np.abs(ref).max()
     with pytest.raises(ValueError, match="more than one unique"):
-        meld_amd.MELD(thresh=0, verbose=0).fit(X, sample_idx=np.zeros(900))
+        meld_amd.MELD(thresh=0, verbose=0).fit(X, sample_idx=np.zeros(X.shape[0]))
 
 
 @pytest.mark.gpu
