@@ -89,6 +89,25 @@ int meld_knn_topk(const float* Q, const float* Rt, int64_t n_ref, int KP, int64_
  *   meld_knn16_error_coef: E / max|x~|^2 to pass to meld_knn_refine for this search. */
 int meld_knn16_kblocks(int d);           /* KB = ceil((d+3)/16); <0 if d unsupported (d <= 141) */
 int meld_knn16_tile_refs(void);          /* TS */
+/* SPLIT operand layout (wherever d > 13 and d + 6 K slots fit the K blocks of d + 3): K block 0 holds the first
+ * meld_knn16_split_dims(d) = 13 coordinates and the pieces of |r_A|^2 (less a margin that the second set of pieces,
+ * behind the other coordinates, gives back), so that the list-driven first pass (meld_knn16_topk_listed) can test a block of 32
+ * references on its accumulators behind K block 0 -- a distance over some of the coordinates never exceeds the distance -- and
+ * skip the other K blocks where no partial value is within reach of its row.  Results are the same in any orthonormal frame;
+ * the test prunes when the leading coordinates carry the distances (the Python host rotates the cells to principal
+ * coordinates for the search; PCA-reduced input, the reference's default, already is such a frame).  0: plain layout.
+ * meld_knn16_debug_split(0 / 1) switches the layout of operands prepared afterwards (development; -1 only reads); returns
+ * the previous setting.  Operands, spheres and searches must be made under one setting. */
+int meld_knn16_split_dims(int d);
+int meld_knn16_debug_split(int on);
+/* The cells' principal frame for that search (frame.hip; no reference counterpart -- graphtools searches the data as given):
+ *   meld_cov_sample_f64:  cov[d*d] (row-major, upper triangle; zeroed by the caller) += the scatter matrix about mean[d] of
+ *                         the rows 0, stride, 2 stride, ... of X[N][d]
+ *   meld_rotate_rows_f64: out[N][d] = (X - mean) V, V[d][d] row-major with the new axes as columns; out != X
+ * d <= meld_frame_max_dims().  The eigenvectors are the caller's business (a d x d problem: host LAPACK). */
+int meld_frame_max_dims(void);
+int meld_cov_sample_f64(const double* X, int64_t N, int d, const double* mean, int64_t stride, double* cov, meld_stream_t stream);
+int meld_rotate_rows_f64(const double* X, int64_t N, int d, const double* mean, const double* V, double* out, meld_stream_t stream);
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
 double meld_knn16_error_coef(int nprod, int d);       /* worst case: E <= coef * max|x~|^2 (depends on the dimension:
@@ -223,6 +242,14 @@ int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, c
                            int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr, uint64_t* tiles_done,
                            const int32_t* block_order, int n_slices /* as meld_knn16_topk: slice y walks the entries y, y + S, ... of a
                            block's list into its own candidate rows; merge with meld_knn16_merge_slices */, meld_stream_t stream);
+/* ... with the partial test of the SPLIT layout: partial_test != 0 lets the pass drop a block of 32 references behind its first K
+ * block when no partial value is within reach of its row (same rows, counts and thresholds; see meld_knn16_split_dims) */
+int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
+                                   int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
+                                   int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                                   double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
+                                   uint64_t* tiles_done, const int32_t* block_order, int n_slices, int partial_test,
+                                   meld_stream_t stream);
 /* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
  * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
  * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2

@@ -37,6 +37,8 @@ SIGNATURES = {
     "meld_knn_error_coef": (_f64, [_i32]),
     "meld_knn16_kblocks": (_i32, [_i32]),
     "meld_knn16_tile_refs": (_i32, []),
+    "meld_knn16_split_dims": (_i32, [_i32]),
+    "meld_knn16_debug_split": (_i32, [_i32]),
     "meld_knn16_block_queries": (_i32, []),
     "meld_knn16_row_capacity": (_i32, [_i32]),
     "meld_knn16_error_coef": (_f64, [_i32, _i32]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "meld_knn16_list_scratch_bytes": (_sz, [_i64]),
     "meld_knn16_step_lists_direct": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr]),
     "meld_knn16_topk_listed": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    "meld_knn16_topk_listed_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "meld_knn16_seed_thresholds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),
     "meld_knn16_seed_thresholds_mfma": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i64, _i32, _f64, _i32, _i32, _ptr, _ptr]),
     "meld_knn16_max_slices": (_i32, [_i32]),
@@ -125,6 +128,9 @@ SIGNATURES = {
     "meld_assign_nearest": (_i32, [_ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_chain_order": (_i32, [_ptr, _i64, _i32, _i32, _ptr, _ptr]),
     "meld_gather_rows_f64": (_i32, [_ptr, _ptr, _i64, _i32, _ptr, _ptr]),
+    "meld_frame_max_dims": (_i32, []),
+    "meld_cov_sample_f64": (_i32, [_ptr, _i64, _i32, _ptr, _i64, _ptr, _ptr]),
+    "meld_rotate_rows_f64": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr]),
     "meld_argsort_u32_temp_bytes": (_sz, [_i64]),
     "meld_argsort_u32": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _sz, _ptr]),
     "meld_order_starts": (_i32, [_ptr, _i64, _i32, _ptr, _ptr]),

@@ -8,7 +8,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "knn.hip", "knn16.hip", "refine.hip", "assemble.hip", "spmm.hip", "spmm_tiled.hip", "reorder.hip", "kmeans.hip", "labels.hip", "sharded.hip"]
+SOURCES = ["api.hip", "knn.hip", "knn16.hip", "refine.hip", "assemble.hip", "spmm.hip", "spmm_tiled.hip", "reorder.hip", "kmeans.hip", "labels.hip", "sharded.hip", "frame.hip"]
 OUT = os.path.join(_HERE, "libmeld_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-file additions.  knn16.hip: the minima over MFMA accumulators (tile bounds, seeds) are fmin chains on values the compiler

@@ -59,6 +59,35 @@ constexpr int K16_BOUNDS_THREADS = 1024;  // (512 from 5 K blocks on: the centro
 constexpr int K16_SLOTS = K16_CAPMAX / 64;  // row entries per lane in the compaction routines
 constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 
+// K-slot layout of the operands.  PLAIN (dA = 0): coordinates 0 .. d-1, then the three fp16 pieces of |r|^2 (1.0 on the query
+// side).  SPLIT (dA = 13, whenever d > 13 and d + 6 fits the K blocks d + 3 needs): K block 0 = coordinates 0 .. 12 and three
+// pieces of N_A = |r_A|^2 - m_r; from slot 16 on the other coordinates and three pieces of N_B = |r_B|^2 + m_r.  Every kernel
+// that sums all K blocks sees |r|^2 - 2 q.r as before; the list-driven first pass (EE) looks at its accumulators after K block
+// 0 -- a distance over a subset of the coordinates never exceeds the distance -- and drops the other K blocks of a block of
+// references in which no partial value is below its row's threshold (+ |q_B|^2: the most the other blocks can take away, m_r
+// covering the fp16 rounding of r_B: see prepare16_kernel).  It pays when the leading coordinates carry the distances (principal
+// coordinates: the host rotates the cells for the search, meld_amd/graph.py; any orthonormal frame is valid).
+constexpr int K16_SPLIT_DA = 13;
+__host__ __device__ inline int k16_split_dims_of(int d, int KB, int enabled) {
+  return (enabled && d > K16_SPLIT_DA && d + 6 <= 16 * KB) ? K16_SPLIT_DA : 0;
+}
+// content of physical K slot c: *coord >= 0 a coordinate; *piece 0..2 the pieces of N_A, 3..5 of N_B (PLAIN: of |r|^2); both -1: zero
+__host__ __device__ inline void k16_slot(int c, int d, int dA, int* coord, int* piece) {
+  *coord = -1;
+  *piece = -1;
+  if (dA == 0) {
+    if (c < d) *coord = c;
+    else if (c < d + 3) *piece = 3 + (c - d);
+    return;
+  }
+  const int nb = d - dA;  // coordinates behind K block 0
+  if (c < dA) *coord = c;
+  else if (c < dA + 3) *piece = c - dA;
+  else if (c < 16) return;
+  else if (c < 16 + nb) *coord = dA + (c - 16);
+  else if (c < 16 + nb + 3) *piece = 3 + (c - 16 - nb);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -287,6 +316,7 @@ struct K16Args {
   const unsigned* step_list;
   const int* step_cnt;
   long long list_stride;
+  int ee_hi;  // EE kernels (SPLIT layout): physical K slots [16, ee_hi) hold the coordinates behind K block 0
 };
 #define K16_COLD(FIELD) \
   (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
@@ -301,11 +331,13 @@ __host__ __device__ constexpr int k16_waves(int KB, int ABL, int NPROD) {
   return (NPROD == 1 && KB <= 4 && ABL != 6) ? 3 : ((KB <= 5 || (NPROD == 1 && KB <= 8)) ? 2 : 1);
 }
 
-template <int KB, int ABL, int NPROD, bool LIST = false>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
+template <int KB, int ABL, int NPROD, bool LIST = false, bool EE = false>  // 16 KB >= d + 3; ABL: 0 = product, 2 = product + selection counters, 1 / 3 = profiling ablations (no selection / MFMAs
                                       // only), 6 = product at two waves per SIMD where three are the default;
                                       // NPROD: split products (1 = hi.hi only, 3 = hi.hi + hi.lo + lo.hi)
                                       // LIST: the steps of a query block (tile + the waves that need it) come from a precomputed list
                                       // (meld_knn16_step_lists) instead of the pruning table: no per-step masks, ballots or window logic
+                                      // EE (with LIST, NPROD = 1, KB >= 2, operands in the SPLIT layout): a block of 32 references is tested
+                                      // on its accumulators behind K block 0 and dropped when no partial value is within reach of its row
 __global__ __launch_bounds__(K16_THREADS)
 __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(const K16Args a) {
   // Arguments the scan loop needs stay in SGPRs; the cold ones (K16_COLD: compaction parameters, the outputs
@@ -400,6 +432,31 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // (only thrp = thr - |q|^2 lives in registers: the kernel is compiled for a fixed register budget)
   auto thr_start = [&](int g) __attribute__((always_inline)) { return a.thr_init ? a.thr_init[q_base + g * 32 + jq] : INFINITY; };
   float thrp[2] = {thr_start(0) - wave_qn[jq], thr_start(1) - wave_qn[32 + jq]};
+  // EE: what the K blocks behind the first can take away from an accumulator at most, per query: |q_hiB|^2 (the fp16 values the
+  // MFMAs multiply, summed here from the fragments in registers: the two half-lanes of a query hold the two halves of every K
+  // block) rounded up, plus the fp32 rounding of the three later accumulations (<= 2^-18 n_max with room to spare: the partial
+  // sums stay below 3 n_max).  A block is dropped when every partial value is >= thrp + ee_c: v_full < thrp implies
+  // v_partial = v_full - (rest) < thrp + |q_hiB|^2 + rounding.
+  float ee_c[2] = {0.0f, 0.0f};
+  if constexpr (EE) {
+    const int ee_hi = a.ee_hi;
+    const float s_ = a.scale_info[0];
+    const float delta = 3.814697265625e-06f * (a.norm2_max[0] * s_ * s_) + 1e-30f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float qb = 0.0f;
+#pragma unroll
+      for (int kb = 1; kb < KB; ++kb) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (16 * kb + 8 * h + e < ee_hi) ? (float)bhi[g][kb][e] : 0.0f;
+          qb = fmaf(v, v, qb);
+        }
+      }
+      qb += __shfl_xor(qb, 32, 64);
+      ee_c[g] = qb * 1.0001f + delta;
+    }
+  }
   float wmax = INFINITY;  // max threshold over this wave's 64 queries (wave-uniform)
   if (a.thr_init) {  // seeded thresholds also seed the pruning bound (and let the timing ablations prune realistically)
     float w = fmaxf(thr_start(0), thr_start(1));
@@ -407,6 +464,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off, 64));
     wmax = w;
   }
+  unsigned st_go = 0;  // (EE, ABL == 2: blocks of 32 references that went on past K block 0)
   unsigned st_slow = 0, st_app = 0, st_sq = 0;  // profiling (ABL == 2 only): slow-path entries, appends (per lane), compactions
   // ... and where a wave's cycles go (s_memtime stamps at points where the LDS / scalar counter is drained anyway): MFMA segments
   // of a live step, slow path, control tail up to the tile wait, the tile wait, the tile barrier; steps sat out
@@ -834,7 +892,34 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       if (s_nn_top < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane(t_nn_top), wr_b);
     }
 #endif
-    if (live_cur) {
+    if (EE && live_cur) {
+      // Per sub-tile (32 references): K block 0 (2 MFMAs), the partial test, and only a block that passes it goes on: the other
+      // K blocks, the vote and -- if some value is below its row's threshold -- the slow path.  No block is left pending across
+      // tiles; both A fragments of K block 0 are requested before the first MFMA.
+      const f16x8* a8 = reinterpret_cast<const f16x8*>(tile_r) + jq;
+      const f16x8 aA = a8[h * K16_TS], aB = a8[32 + h * K16_TS];
+      const float tA0 = thrp[0] + ee_c[0], tA1 = thrp[1] + ee_c[1];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = 0.0f;
+        accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[0][0], accA0, 0, 0, 0);
+        accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[1][0], accA1, 0, 0, 0);
+        if (__any(min16(accA0) < tA0 || min16(accA1) < tA1)) {
+          const f16x8* as = a8 + sub * 32;
+#pragma unroll
+          for (int kb = 1; kb < KB; ++kb) {
+            const f16x8 ahi = as[(kb * 2 + h) * K16_TS];
+            accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], accA0, 0, 0, 0);
+            accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], accA1, 0, 0, 0);
+          }
+          const float m0 = min16(accA0), m1 = min16(accA1);
+          if (__any(m0 < thrp[0] || m1 < thrp[1])) select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
+          if (ABL == 2) ++st_go;
+        }
+      }
+      ++n_done;
+    } else if (live_cur) {
 #ifdef K16_SETPRIO
       __builtin_amdgcn_s_setprio(K16_SETPRIO);
 #endif
@@ -958,6 +1043,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
       atomicAdd(stats + 9, (unsigned long long)tm_bar);
       atomicAdd(stats + 10, (unsigned long long)tm_idle);
       atomicAdd(stats + 11, (unsigned long long)it);
+      if (EE) atomicAdd(stats + 12, (unsigned long long)st_go);
     }
   }
   // final: sort every row, convert back to input units, publish its length and its threshold (the row
@@ -1132,7 +1218,7 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
                                                            const double* __restrict__ mean,
                                                            const float* __restrict__ scale_info, int KB,
                                                            _Float16* __restrict__ cent16, float* __restrict__ cent_n,
-                                                           float* __restrict__ cent_r, int tile0) {
+                                                           float* __restrict__ cent_r, int tile0, int dA) {
   // the tile's cells, row stride ld = d | 1 floats (odd: conflict-free column walks; sized by d, not by the largest d the
   // library takes -- 13 KB instead of 37 at d = 50, three times the workgroups per CU of a kernel that is all latency)
   extern __shared__ float xs_dyn[];
@@ -1237,12 +1323,13 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = g * 8 + e;
+      int cc, pc;
+      k16_slot(g * 8 + e, d, dA, &cc, &pc);
       _Float16 h16 = (_Float16)0.0f, l16 = (_Float16)0.0f;
-      if (c < d) {
-        h16 = (_Float16)cs[c];
-        l16 = (_Float16)(cs[c] - (float)h16);
-      } else if (c < d + 3) {
+      if (cc >= 0) {
+        h16 = (_Float16)cs[cc];
+        l16 = (_Float16)(cs[cc] - (float)h16);
+      } else if (pc >= 0) {
         h16 = (_Float16)1.0f;
       }
       hi[e] = h16;
@@ -1500,7 +1587,7 @@ __global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict
                                                         const float* __restrict__ scale_info, int KB, int64_t q_begin,
                                                         int64_t n_rows, const int* __restrict__ rows,
                                                         _Float16* __restrict__ out16, float* __restrict__ out_norm,
-                                                        float* __restrict__ norm2_max) {
+                                                        float* __restrict__ norm2_max, int dA) {
   __shared__ float xs[K16_TS][K16_DMAX + 4];  // row stride 145 floats: odd, conflict-free column walks
   const int tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * K16_TS;
@@ -1527,24 +1614,53 @@ __global__ __launch_bounds__(256) void prepare16_kernel(const double* __restrict
   if (!real) n = INFINITY;  // padding references are infinitely far
   // |r|^2 = n1 + n2 + n3 (fp16 pieces; residual <= 2^-33 n, or 2^-25 absolute once n3 is subnormal);
   // a padding row is (+inf, 0, 0): inf * 1.0 accumulates to +inf, which never passes `< thr`
-  const _Float16 n1 = (_Float16)n;
-  const float r1 = real ? n - (float)n1 : 0.0f;
-  const _Float16 n2 = (_Float16)r1;
-  const _Float16 n3 = (_Float16)(r1 - (float)n2);
+  // SPLIT layout (dA > 0): the norm rides in two groups of pieces, N_A = |r_A|^2 - m_r in K block 0 and N_B = |r_B|^2 + m_r behind
+  // the other coordinates (r_A = the first dA coordinates).  With m_r >= (|fp16(r_B)|^2 - |r_B|^2)^+ the K blocks behind the
+  // first contribute N_B - 2 q_hi.r_hi >= |r_hiB|^2 - 2 q_hiB.r_hiB >= -|q_hiB|^2 to an accumulator whatever r is, which is what
+  // the partial test of the list-driven first pass rests on: fp16 rounding is 2^-11 relative (|fp16(x)|^2 <= x^2 (1 + 2^-10 +
+  // 2^-22)) or 2^-25 absolute below the normal range (<= 2^-24 |x| + 2^-50 on the square, |x| <= 1), the fp32 sums carry
+  // d 2^-24 relative: m_r = 1.03 2^-10 |r_B|^2 + d 2^-22.  The two sums differ from the one chain by <= 2^-22 n (budgeted in
+  // k16_const_coef).  PLAIN layout: N_B = |r|^2, no N_A.
+  float nA = 0.0f, nB = n;
+  if (IS_REF && dA > 0) {
+    nB = 0.0f;
+    for (int k = 0; k < dA; ++k) nA = fmaf(xs[r][k], xs[r][k], nA);
+    for (int k = dA; k < d; ++k) nB = fmaf(xs[r][k], xs[r][k], nB);
+    const float m_r = 1.03f * 0.0009765625f * nB + (float)d * 2.384185791015625e-07f;
+    nA -= m_r;
+    nB += m_r;
+    if (!real) {  // (+inf rides in K block 0: a padding reference fails the partial test too)
+      nA = INFINITY;
+      nB = 0.0f;
+    }
+  }
+  _Float16 npc[6];
+  {
+    const float src2[2] = {nA, nB};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float nn = src2[q];
+      const _Float16 n1 = (_Float16)nn;
+      const float r1 = isinf(nn) ? 0.0f : nn - (float)n1;
+      const _Float16 n2 = (_Float16)r1;
+      npc[3 * q + 0] = n1;
+      npc[3 * q + 1] = n2;
+      npc[3 * q + 2] = (_Float16)(r1 - (float)n2);
+    }
+  }
   for (int g = part; g < KB * 2; g += 4) {
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = g * 8 + e;
-      _Float16 h16, l16 = (_Float16)0.0f;
-      if (c < d) {
-        const float v = IS_REF ? -2.0f * xs[r][c] : xs[r][c];
+      int cc, pc;
+      k16_slot(g * 8 + e, d, dA, &cc, &pc);
+      _Float16 h16 = (_Float16)0.0f, l16 = (_Float16)0.0f;
+      if (cc >= 0) {
+        const float v = IS_REF ? -2.0f * xs[r][cc] : xs[r][cc];
         h16 = (_Float16)v;
         l16 = (_Float16)(v - (float)h16);
-      } else if (c < d + 3) {
-        h16 = IS_REF ? (c == d ? n1 : (c == d + 1 ? n2 : n3)) : (_Float16)1.0f;  // exact against 1.0: hi plane only
-      } else {
-        h16 = (_Float16)0.0f;
+      } else if (pc >= 0) {
+        h16 = IS_REF ? npc[pc] : (_Float16)1.0f;  // exact against 1.0: hi plane only
       }
       hi[e] = h16;
       lo[e] = l16;
@@ -1801,6 +1917,22 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
 
 using namespace meld;
 
+// SPLIT operand layout (k16_slot): on by default wherever it fits; meld_knn16_debug_split(0) restores the plain layout for
+// every operand prepared afterwards (development / A-B measurements: operands and searches must be made under one setting).
+static int g_k16_split = 1;
+static int k16_dA(int d, int KB) { return k16_split_dims_of(d, KB, g_k16_split); }
+extern "C" int meld_knn16_debug_split(int on) {
+  const int was = g_k16_split;
+  if (on >= 0) g_k16_split = on ? 1 : 0;
+  return was;
+}
+extern "C" int meld_knn16_kblocks(int d);
+// coordinates K block 0 holds under the SPLIT layout (the list-driven first pass tests its accumulators behind that block: the
+// caller does well to hand the cells over in a frame whose leading coordinates carry the distances); 0: plain layout
+extern "C" int meld_knn16_split_dims(int d) {
+  const int kb = meld_knn16_kblocks(d);
+  return kb < 0 ? 0 : k16_dA(d, kb);
+}
 extern "C" int meld_knn16_kblocks(int d) {
   if (d < 1) return MELD_ERR_INVALID;
   const int kb = (d + 3 + 15) / 16;  // d coordinates + three K slots for the reference norm
@@ -1847,11 +1979,12 @@ extern "C" int meld_knn16_row_capacity(int ksel) {
 // be certified (neighbour distances^2 ~ 1e-5 n_max) instead of going through the exact sweep row by row.
 // Measured worst error: 7.6e-7 n_max (nprod 3), 5.4e-4 n_max (nprod 1) at d = 50.
 static double k16_const_coef(int nprod, int d) {
-  const double T = (double)(nprod == 3 ? 3 * d : d) + 3.0;
+  const double T = (double)(nprod == 3 ? 3 * d : d) + 6.0;  // (+ the norm pieces: six under the SPLIT layout)
   double c = 1.01 * T * 1.1920928955078125e-07 * 3.0  // accumulation, u = 2^-23
              + 4.76837158203125e-07                    // 2^-21: fp32 rounding of the scaled points
              + (double)(d + 2) * 5.9604644775390625e-08  // (d + 2) 2^-24
-             + 5.9604644775390625e-08;                 // 2^-24: norm pieces
+             + 5.9604644775390625e-08                  // 2^-24: norm pieces
+             + 2.98023223876953125e-07;                // 2^-22 + 2^-24: SPLIT layout -- |r_A|^2 and |r_B|^2 summed apart, two sets of pieces
   if (nprod == 3) c += 9.5367431640625e-07 + 3.0 * 2.98023223876953125e-08 * sqrt((double)d) + 4.76837158203125e-07;
   return c;
 }
@@ -1882,10 +2015,10 @@ static int k16_prepare_impl(const double* X, int64_t N, int d, const double* mea
   hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
   const int64_t n_pad = ceil_div(N, K16_TS) * K16_TS;
   hipLaunchKernelGGL((prepare16_kernel<true>), dim3((unsigned)(n_pad / K16_TS)), dim3(256), 0, st, X, N, d, mean, scale_info,
-                     KB, (int64_t)0, N, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
+                     KB, (int64_t)0, N, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max, k16_dA(d, KB));
   const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, st, X, N, d, mean, scale_info,
-                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
+                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr, k16_dA(d, KB));
   MELD_LAUNCH_CHECK("meld_knn16_prepare");
   return MELD_OK;
 }
@@ -1922,10 +2055,10 @@ extern "C" int meld_knn16_prepare_cross(const double* X, int64_t n_refs, int64_t
   hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(1), 0, st, scale_info);
   const int64_t n_pad = ceil_div(n_refs, K16_TS) * K16_TS;
   hipLaunchKernelGGL((prepare16_kernel<true>), dim3((unsigned)(n_pad / K16_TS)), dim3(256), 0, st, X, n_refs, d, mean, scale_info,
-                     KB, (int64_t)0, n_refs, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max);
+                     KB, (int64_t)0, n_refs, (const int*)nullptr, reinterpret_cast<_Float16*>(Rt16), norm2, norm2_max, k16_dA(d, KB));
   const int64_t q_pad = ceil_div(q_count, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, st, X, n_total, d, mean, scale_info,
-                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
+                     KB, q_begin, q_count, (const int*)nullptr, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr, k16_dA(d, KB));
   MELD_LAUNCH_CHECK("meld_knn16_prepare_cross");
   return MELD_OK;
 }
@@ -1941,7 +2074,7 @@ extern "C" int meld_knn16_prepare_rows(const double* X, int64_t N, int d, const 
   if (KB < 0) return KB;
   const int64_t q_pad = ceil_div(n_rows, K16_BQ) * K16_BQ;
   hipLaunchKernelGGL((prepare16_kernel<false>), dim3((unsigned)(q_pad / K16_TS)), dim3(256), 0, S(stream), X, N, d, mean,
-                     scale_info, KB, q_begin, n_rows, rows, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr);
+                     scale_info, KB, q_begin, n_rows, rows, reinterpret_cast<_Float16*>(Q16), Qn, (float*)nullptr, k16_dA(d, KB));
   MELD_LAUNCH_CHECK("meld_knn16_prepare_rows");
   return MELD_OK;
 }
@@ -2052,7 +2185,7 @@ extern "C" int meld_knn16_tile_spheres(const double* X, int64_t N, int d, const 
   float* cn = reinterpret_cast<float*>(reinterpret_cast<char*>(temp) + n_c * (size_t)KB * 64);
   float* cr = cn + n_c;
   hipLaunchKernelGGL(tile_spheres_kernel, dim3((unsigned)tile_count), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), S(stream), X, N, d, mean, scale_info, KB, c16, cn, cr,
-                     (int)tile_begin);
+                     (int)tile_begin, k16_dA(d, KB));
   MELD_LAUNCH_CHECK("tile_spheres_kernel");
   return MELD_OK;
 }
@@ -2086,7 +2219,7 @@ static int k16_bounds_impl(const double* X, int64_t N, int d, const double* mean
   float* cr = cn + n_c;
   if (!spheres_ready) {
     MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
-    hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+    hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0, k16_dA(d, KB));
   }
   const int bt = KB <= 4 ? K16_BOUNDS_THREADS : K16_BOUNDS_THREADS / 2;
   const int gx = (int)(n_c / bt);
@@ -2356,7 +2489,7 @@ extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, c
   unsigned long long* bits_b = bits_a + (size_t)n_q * wpr;
   unsigned long long* live = bits_b + (size_t)n_q * wpr;
   MELD_HIP_CALL(hipMemsetAsync(temp, 0, n_c * ((size_t)KB * 64 + 2 * sizeof(float)), st));
-  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0);
+  hipLaunchKernelGGL(tile_spheres_kernel, dim3(n_t), dim3(256), sizeof(float) * K16_TS * (size_t)(d | 1), st, X, N, d, mean, scale_info, KB, c16, cn, cr, 0, k16_dA(d, KB));
   const float es = (float)meld_knn16_error_coef(nprod, d);
   hipLaunchKernelGGL(knn16_wave_thresholds_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, st, thr_seed, N, n_q, es, norm2_max,
                      scale_info, wthr);
@@ -2520,7 +2653,7 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
                          const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
                          double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
                          float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, const uint32_t* step_list,
-                         const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream) {
+                         const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream, int partial_test = 0) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(step_list == nullptr || (step_cnt != nullptr && nprod == 1 && lb2 == nullptr && thr_init != nullptr),
                  "meld_knn16_topk_listed: step lists go with the hi-only pass, start thresholds and no table");
@@ -2607,6 +2740,13 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   ka.step_list = step_list;
   ka.step_cnt = step_cnt;
   ka.list_stride = (long long)list_stride;
+  // the list-driven first pass tests its blocks behind K block 0 where the operands carry the SPLIT layout and the caller asks
+  // for it (`partial_test`: it knows whether the leading coordinates carry the distances -- where they do not, the test drops
+  // nothing and costs 15 %); MELD_KNN16_EE=0 / 1 overrides the caller, for A-B measurements
+  const int dA = k16_dA(d, KB);
+  const char* ee_env = getenv("MELD_KNN16_EE");
+  const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
+  ka.ee_hi = 16 + d - dA;
 #ifndef K16_PROFILING
   MELD_CHECK_ARG(abl == 0, "MELD_KNN16_ABLATION needs a library built with -DK16_PROFILING");
 #endif
@@ -2625,7 +2765,12 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   do {                               \
     if (step_list != nullptr) {      \
       K16_DEV_LIST_ABL(KBV)          \
-      if (stats != nullptr)          \
+      if (ee && KBV >= 2) {          \
+        if (stats != nullptr)        \
+          hipLaunchKernelGGL((knn16_topk_kernel<(KBV >= 2 ? KBV : 2), 2, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+        else                         \
+          hipLaunchKernelGGL((knn16_topk_kernel<(KBV >= 2 ? KBV : 2), 0, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+      } else if (stats != nullptr)   \
         hipLaunchKernelGGL((knn16_topk_kernel<KBV, 2, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
       else                           \
         hipLaunchKernelGGL((knn16_topk_kernel<KBV, 0, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
@@ -2698,12 +2843,15 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
     MELD_LAUNCH_CHECK("knn16_finish_rows_kernel");
   }
   if (stats) {
-    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     MELD_HIP_CALL(hipStreamSynchronize(S(stream)));
     MELD_HIP_CALL(hipMemcpy(st, stats, sizeof(st), hipMemcpyDeviceToHost));
     fprintf(stderr, "[knn16 stats] wave-blocks %llu  slow-path entries %llu (%.1f %%)  appends %llu (%.1f per query)  compactions %llu  tiles staged %llu (%.1f %% of workgroups x tiles)\n",
             st[0], st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], (double)st[2] / (double)q_count, st[3], st[4],
             100.0 * (double)st[4] / ((double)grid.y * (double)n_tiles));
+    if (ee)
+      fprintf(stderr, "[knn16 stats] blocks of 32 references that went on past K block 0: %llu of %llu (%.1f %%)\n", st[12], st[0],
+              st[0] ? 100.0 * (double)st[12] / (double)st[0] : 0.0);
     {
       const double tot = (double)(st[5] + st[6] + st[7] + st[8] + st[9] + st[10]);
       fprintf(stderr, "[knn16 stats] wave cycles (s_memtime units, summed over waves; %% of the scan loop): MFMA segments of live steps %.1f  slow path %.1f  "
@@ -2737,6 +2885,21 @@ extern "C" int meld_knn16_topk_listed(const void* Q16, const float* Qn, const vo
   return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, n_slices, nullptr, norm2_max, q_begin, thr_init, knn,
                        radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, step_list, step_cnt, list_stride,
                        stream);
+}
+
+// The same with the partial test of the SPLIT layout (meld_knn16_split_dims(d) > 0): partial_test != 0 lets the pass drop a block
+// of 32 references behind its first K block when no partial value is within reach of its row -- same rows, counts and
+// thresholds; worth asking for when the leading coordinates of the operands carry the distances (principal coordinates).
+extern "C" int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
+                                              int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
+                                              int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
+                                              double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
+                                              uint64_t* tiles_done, const int32_t* block_order, int n_slices, int partial_test,
+                                              meld_stream_t stream) {
+  MELD_CHECK_ARG(step_list && step_cnt && list_stride > 0, "meld_knn16_topk_listed_partial: null step lists");
+  return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, n_slices, nullptr, norm2_max, q_begin, thr_init, knn,
+                       radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, step_list, step_cnt, list_stride,
+                       stream, partial_test);
 }
 
 // Workgroups of the search kernel that are resident on the device at once (occupancy x CUs): the

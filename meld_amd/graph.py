@@ -446,6 +446,9 @@ class HipOps:
         self.block_order = os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0"
         # the first pass walks precomputed step lists (meld_knn16_step_lists) instead of testing the pruning table step by step
         self.step_lists = os.environ.get("MELD_KNN_STEP_LISTS", "1") != "0"
+        # the search runs in the cells' principal frame where that concentrates the distances in the leading coordinates (the
+        # list-driven first pass tests a block behind its first K block: principal_frame)
+        self.rotate = os.environ.get("MELD_KNN_ROTATE", "1") != "0"
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
         self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
@@ -462,6 +465,28 @@ class HipOps:
         tmp = torch.empty(tb, dtype=torch.uint8, device=X.device)
         check(self.lib.meld_col_stats_f64(ptr(X), N, d, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(tmp), tb, _stream()), "meld_col_stats_f64")
         return out[0], out[1], out[2]
+
+    def principal_frame(self, X, mean, lead):
+        """The cells in their principal frame, ``(X - mean) V`` with the eigenvectors of the covariance (of at most 32768 evenly
+        spaced rows, ``meld_cov_sample_f64``) in descending order of variance (``meld_rotate_rows_f64``) -- or None when the
+        ``lead`` leading coordinates would carry less than half of the variance (the search's partial test would seldom drop a
+        block; any frame is valid, the graph is the same) or d is beyond the kernels' width.  Distances are those of ``X`` to
+        rounding (V is orthonormal to 1e-15): the search only nominates candidates, their distances are evaluated in fp64 on
+        ``X`` itself.  The d x d eigenproblem is solved on the host (one read-back of d x d numbers)."""
+        lib, st = self.lib, _stream()
+        N, d = int(X.shape[0]), int(X.shape[1])
+        if d > int(lib.meld_frame_max_dims()):
+            return None
+        cov = torch.zeros(d, d, dtype=torch.float64, device=X.device)
+        check(lib.meld_cov_sample_f64(ptr(X), N, d, ptr(mean), max(1, N // 32768), ptr(cov), st), "meld_cov_sample_f64")
+        evals, evecs = np.linalg.eigh(cov.cpu().numpy(), UPLO="U")  # (row-major upper triangle)
+        tot = float(evals.sum())
+        if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
+            return None
+        V = torch.from_numpy(np.ascontiguousarray(evecs[:, ::-1])).to(X.device)
+        out = torch.empty_like(X)
+        check(lib.meld_rotate_rows_f64(ptr(X), N, d, ptr(mean), ptr(V), ptr(out), st), "meld_rotate_rows_f64")
+        return out
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
@@ -499,6 +524,7 @@ class HipOps:
             mean = X.mean(dim=0)
         norm2 = torch.empty(N, dtype=torch.float32, device=dev)
         nmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        X_search, mean_search = X, mean  # (the f16x3 search may move to the cells' principal frame)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
         used_prune = used_seed = used_seeded_bounds = used_block_order = used_step_lists = False
@@ -562,6 +588,16 @@ class HipOps:
             err_lin = lib.meld_knn16_error_coef_lin(nprod)
             n_tiles = (NR + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
+            # The frame of the search (X_s, its mean and column extremes): the cells' principal frame where the first pass can
+            # use it -- operands in the split layout, step lists, all cells against all cells on one GPU -- else X itself.
+            # Everything up to the candidate lists works on X_s; refinement and the exact sweeps on X.
+            lead = int(lib.meld_knn16_split_dims(d))
+            if (self.rotate and lead > 0 and nprod == 1 and not cross and self.prune and self.step_lists and self.seed and N >= 16384
+                    and q_begin == 0 and q_count == N and (comm is None or getattr(comm, "world", 1) == 1) and bw_fixed is None):
+                X_s = self.principal_frame(X, mean, lead)
+                if X_s is not None:
+                    sums_s, col_min, col_max = self.col_stats(X_s)
+                    X_search, mean_search = X_s, sums_s / N
             Rt = torch.empty(n_tiles * lib.meld_knn16_tile_bytes(d), dtype=torch.uint8, device=dev)
             Q = torch.empty(q_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device=dev)
             Qn = torch.empty(q_pad, dtype=torch.float32, device=dev)
@@ -574,9 +610,9 @@ class HipOps:
                 nmax = torch.maximum(nmax, Qn[:q_count].max().reshape(1))
             else:
                 if col_min is not None:
-                    check(lib.meld_knn16_prepare_scaled(ptr(X), N, d, ptr(mean), ptr(col_min), ptr(col_max), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare_scaled")
+                    check(lib.meld_knn16_prepare_scaled(ptr(X_search), N, d, ptr(mean_search), ptr(col_min), ptr(col_max), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare_scaled")
                 else:
-                    check(lib.meld_knn16_prepare(ptr(X), N, d, ptr(mean), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
+                    check(lib.meld_knn16_prepare(ptr(X_search), N, d, ptr(mean_search), q_begin, q_count, ptr(Rt), ptr(Q), ptr(Qn), ptr(norm2), ptr(nmax), ptr(scale_info), st), "meld_knn16_prepare")
             tm.stop("prepare")
             cand_idx = torch.empty(q_pad * cap, dtype=torch.int32, device=dev)
             cand_d2 = torch.empty(q_pad * cap, dtype=torch.float32, device=dev)
@@ -610,7 +646,7 @@ class HipOps:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
                 if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
-                    check(lib.meld_knn16_seed_thresholds(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
+                    check(lib.meld_knn16_seed_thresholds(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
                 else:
                     check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
@@ -633,7 +669,7 @@ class HipOps:
                         t0s = min(comm.rank * per, n_tiles)
                         t1s = min(t0s + per, n_tiles)
                         tmpb.zero_()
-                        check(lib.meld_knn16_tile_spheres(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(tmpb), t0s, max(t1s - t0s, 0), st), "meld_knn16_tile_spheres")
+                        check(lib.meld_knn16_tile_spheres(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(tmpb), t0s, max(t1s - t0s, 0), st), "meld_knn16_tile_spheres")
                         parts = (tmpb[: rows_c * row_b], tmpb[rows_c * row_b : rows_c * (row_b + 4)], tmpb[rows_c * (row_b + 4) : rows_c * (row_b + 8)])
                         for arr, width in zip(parts, (row_b, 4, 4)):
                             mine = arr[comm.rank * per * width : (comm.rank + 1) * per * width].clone()
@@ -654,13 +690,13 @@ class HipOps:
                     step_list = torch.empty(n_blocks * n_tiles, dtype=torch.int32, device=dev)
                     step_cnt = torch.empty(n_blocks, dtype=torch.int32, device=dev)
                     scratch = torch.empty(lib.meld_knn16_list_scratch_bytes(N), dtype=torch.uint8, device=dev)
-                    check(lib.meld_knn16_step_lists_direct(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), ptr(seeds), ptr(Qn), nprod,
+                    check(lib.meld_knn16_step_lists_direct(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), ptr(Rt), ptr(seeds), ptr(Qn), nprod,
                                                            ptr(tmpb), ptr(scratch), ptr(step_list), n_tiles, ptr(step_cnt), st), "meld_knn16_step_lists_direct")
                     del scratch
                     work = step_cnt
                 else:
                     lb2 = torch.empty(lib.meld_knn16_bounds_bytes(N, q_count), dtype=torch.uint8, device=dev)
-                    check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X), N, d, ptr(mean), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
+                    check((lib.meld_knn16_bounds_from_spheres if spheres_shared else lib.meld_knn16_bounds)(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), ptr(Rt), q_begin, q_count, ptr(seeds) if seeded_bounds else None, ptr(Qn) if seeded_bounds else None, nprod, ptr(tmpb), ptr(lb2), st), "meld_knn16_bounds")
                 if direct:
                     pass
                 elif want_lists:
@@ -697,14 +733,14 @@ class HipOps:
                     s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
                     s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
                     if step_list is not None:
-                        check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, st), "meld_knn16_topk_listed(sliced)")
+                        check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, int(X_search is not X), st), "meld_knn16_topk_listed(sliced)")
                     else:
                         check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
                     check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_count, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
                 elif step_list is not None:
-                    check(lib.meld_knn16_topk_listed(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, st), "meld_knn16_topk_listed")
+                    check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, int(X_search is not X), st), "meld_knn16_topk_listed")
                 else:
                     check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
@@ -779,7 +815,7 @@ class HipOps:
             q2_pad = ((n_flag_h + BQ2 - 1) // BQ2) * BQ2
             Q2 = torch.empty(q2_pad * lib.meld_knn16_query_bytes(d), dtype=torch.uint8, device=dev)
             Qn2 = torch.empty(q2_pad, dtype=torch.float32, device=dev)
-            check(lib.meld_knn16_prepare_rows(ptr(X), N, d, ptr(mean), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), ptr(Qn2), st), "meld_knn16_prepare_rows")
+            check(lib.meld_knn16_prepare_rows(ptr(X_search), N, d, ptr(mean_search), ptr(research["scale_info"]), q_begin, ptr(rows2), n_flag_h, ptr(Q2), ptr(Qn2), st), "meld_knn16_prepare_rows")
             # few queries: cut the references into slices so that the re-search fills the chip
             n_blocks2 = q2_pad // BQ2
             resident = lib.meld_knn16_resident_blocks(d, 3)
@@ -956,7 +992,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), principal_frame=bool(X_search is not X), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)

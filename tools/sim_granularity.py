@@ -42,6 +42,28 @@ C1, r1 = meb(Xp.view(T, 64, -1))          # tile spheres
 C2, r2 = meb(Xp.view(2 * T, 32, -1))      # half tiles
 C4, r4 = meb(Xp.view(4 * T, 16, -1))      # quarter tiles (the ordering's leaves)
 print("radius: tile %.3f  half %.3f  quarter %.3f" % (r1.mean(), r2.mean(), r4.mean()))
+# a bound that is not a ball (round-4 review, item 1a): the axis-aligned box of a tile in the top-k principal coordinates
+# (distance within a subspace <= distance), combined with the ball bound by max
+Xc = Xo - Xo.mean(0, keepdim=True)
+evals, evecs = torch.linalg.eigh(Xc.T @ Xc / N)
+BOXK = (6, 8, 10, 16)
+proj = {k: (Xp - Xo.mean(0, keepdim=True)) @ evecs[:, -k:] for k in BOXK}
+boxes = {}
+for k in BOXK:
+    for rs in (1, 2):
+        pk = proj[k].view(T * rs, 64 // rs, k)
+        boxes[(k, rs)] = (pk.min(1).values, pk.max(1).values)
+
+
+def box_dist(Pk, lo, hi):
+    """[nq, n_boxes] euclidean distance of every query to every box (0 inside)"""
+    out = torch.zeros(Pk.shape[0], lo.shape[0], dtype=Pk.dtype, device=Pk.device)
+    for j in range(Pk.shape[1]):
+        e = torch.clamp_min(torch.maximum(lo[None, :, j] - Pk[:, j:j + 1], Pk[:, j:j + 1] - hi[None, :, j]), 0)
+        out += e * e
+    return out.sqrt()
+
+
 g = torch.Generator().manual_seed(0)
 waves = torch.randint(32, T - 40, (NW,), generator=g).tolist()
 n2 = (Xo * Xo).sum(1)
@@ -92,6 +114,18 @@ for w in waves:
     # per-query test alone (no transposed test), per single query
     lb1 = torch.cdist(P, C1) - r1[None, :]
     add("per-query ball test alone, 1q x 64r (mean over queries)", (lb1 <= s[:, None]).float().mean())
+    lv11 = rule(1, 1)[0]
+    lb2 = torch.cdist(P, C2) - r2[None, :]
+    for k in BOXK:
+        Pk = proj[k][64 * w: 64 * w + 64]
+        bd = box_dist(Pk, *boxes[(k, 1)])
+        keep = torch.maximum(lb1, bd) <= s[:, None]
+        add("per-query ball + %2d-d principal box, 1q x 64r" % k, keep.float().mean())
+        add("   kernel rule 64q x 64r with the box in the per-query test (k = %2d)" % k, (keep.any(0) & lv11).float().mean())
+        bd2 = box_dist(Pk, *boxes[(k, 2)])
+        keep2 = torch.maximum(lb2, bd2) <= s[:, None]
+        add("   per-query ball + box on half tiles, 1q x 32r (k = %2d)" % k, keep2.float().mean())
+        add("   64q x 32r pieces with ball + box (k = %2d; no transposed test)" % k, keep2.any(0).float().mean())
 wt = G.info.get("wave_tiles_done")
 print("N = %d, %d sampled waves; product computes %.4f of the blocks" % (N, NW, (wt / float(T * T)) if wt else float("nan")))
 for k, v in acc.items():
