@@ -103,11 +103,11 @@ int meld_knn16_debug_split(int on);
 /* The cells' principal frame for that search (frame.hip; no reference counterpart -- graphtools searches the data as given):
  *   meld_cov_sample_f64:  cov[d*d] (row-major, upper triangle; zeroed by the caller) += the scatter matrix about mean[d] of
  *                         the rows 0, stride, 2 stride, ... of X[N][d]
- *   meld_rotate_rows_f64: out[N][d] = (X - mean) V, V[d][d] row-major with the new axes as columns; out != X
+ *   meld_rotate_rows_f64: out[N][d] = (X - mean) A^T, At[d][meld_frame_max_dims()] = the new axes as rows, zero-padded; out != X
  * d <= meld_frame_max_dims().  The eigenvectors are the caller's business (a d x d problem: host LAPACK). */
 int meld_frame_max_dims(void);
 int meld_cov_sample_f64(const double* X, int64_t N, int d, const double* mean, int64_t stride, double* cov, meld_stream_t stream);
-int meld_rotate_rows_f64(const double* X, int64_t N, int d, const double* mean, const double* V, double* out, meld_stream_t stream);
+int meld_rotate_rows_f64(const double* X, int64_t N, int d, const double* mean, const double* At, double* out, meld_stream_t stream);
 int meld_knn16_block_queries(void);      /* BQ */
 int meld_knn16_row_capacity(int ksel);   /* CAP */
 double meld_knn16_error_coef(int nprod, int d);       /* worst case: E <= coef * max|x~|^2 (depends on the dimension:

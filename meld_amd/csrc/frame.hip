@@ -35,31 +35,28 @@ __global__ __launch_bounds__(256) void cov_sample_kernel(const double* __restric
   }
 }
 
-// out[r][:] = (X[r][:] - mean) V,  V row-major [d][d] (column j = the j-th axis of the new frame), on v_mfma_f64_16x16x4_f64: a
-// workgroup walks a contiguous range of 64-row tiles, wave w the rows 16 w .. 16 w + 15 of a tile against all the columns.  V sits
-// in LDS (zero beyond d) and is read as B fragments (V[4 ks + lane / 16][16 cb + lane % 16]); the rows pass through LDS once on the
-// way in (coalesced loads, centred; the loads of the NEXT tile are in flight while this one is multiplied) and once on the way out
-// (coalesced stores).  D fragment: lane holds rows lane / 16 + 4 i (i = 0..3) of column lane % 16.  (A vector-FMA version with V in
-// LDS was bound by its LDS reads, 14 per 13 FMAs; loads issued one by one behind a run-time trip count cost as much again: 1.1 ms at
-// 1M x 50 against 0.15 ms of memory traffic.)
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-constexpr int FR_KS = FR_DMAX / 4;   // K steps of 4
-constexpr int FR_CB = FR_DMAX / 16;  // column blocks of 16
+// out[r][j] = (X[r][:] - mean) . A_j,  A = the new axes as ROWS, At[d][FR_DMAX] zero-padded.  A workgroup walks a contiguous range
+// of 64-row tiles; lane = row: every lane holds its (centred) row in registers, wave w computes a quarter of the columns, and the
+// axes are read with SCALAR loads (constant address space, wave-uniform addresses: eight doubles per s_load_dwordx16) and enter the
+// FMAs as scalar operands -- no LDS traffic for them at all.  The rows pass through LDS once on the way in (coalesced loads; the
+// loads of the NEXT tile are in flight while this one is multiplied) and once on the way out (coalesced stores).
+// (Measured on the way, 1M x 50: V in LDS read at wave-uniform addresses, 14 LDS reads per 13 FMAs: 1.1 ms; the same with the tile
+// loads issued one by one behind a run-time trip count: 1.1 ms more; v_mfma_f64_16x16x4_f64 with V as B fragments: 0.93 ms, 0.75 of
+// them the MFMAs -- the fp64 matrix instruction runs far below its nominal rate here; 0.19 ms is what the memory side takes; this
+// version 0.69 ms: ~24 cycles per wave-wide fp64 FMA.)
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) f64x8* const_f64x8_ptr;
 constexpr int FR_LD = FR_DMAX + 1;
 constexpr int FR_NQ = FR_ROWS * FR_DMAX / 256;  // elements of a tile per thread
+constexpr int FR_CPG = FR_DMAX / 4;             // columns per wave at most
 __global__ __launch_bounds__(256) void rotate_rows_kernel(const double* __restrict__ X, int64_t N, int d, const double* __restrict__ mean,
-                                                          const double* __restrict__ V, double* __restrict__ out, int64_t tiles_per_wg) {
+                                                          const double* __restrict__ At, double* __restrict__ out, int64_t tiles_per_wg) {
   __shared__ double sx[FR_ROWS][FR_LD];
-  __shared__ double sv[FR_DMAX][FR_LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l16 = lane & 15, lk = lane >> 4;
-  const int ks_n = (d + 3) >> 2, cb_n = (d + 15) >> 4;
-  for (int u = tid; u < FR_DMAX * FR_DMAX; u += 256) {
-    const int k = u >> 6, c = u & 63;
-    sv[k][c] = (k < d && c < d) ? V[k * d + c] : 0.0;
-  }
-  const int dk = 4 * ks_n;  // columns of the tile the MFMAs read (zero from d on)
+  const int cpg = (d + 3) >> 2;  // columns of this wave: j0 .. j0 + cpg - 1
+  const int j0 = w * cpg;
+  const int k8n = (d + 7) >> 3;  // chunks of eight coordinates
   const double mk = (lane < d) ? mean[lane] : 0.0;  // (a thread always handles column tid % 64)
   const int64_t n_tiles = (N + FR_ROWS - 1) / FR_ROWS;
   const int64_t t_begin = (int64_t)blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
@@ -77,33 +74,48 @@ __global__ __launch_bounds__(256) void rotate_rows_kernel(const double* __restri
   for (int64_t t = t_begin; t < t_end; ++t) {
     const int64_t row0 = t * FR_ROWS;
     const int cnt = (int)min((int64_t)FR_ROWS, N - row0);
-    __syncthreads();  // (V staged; the previous tile has left sx)
+    __syncthreads();  // (the previous tile has left sx)
 #pragma unroll
     for (int q = 0; q < FR_NQ; ++q) {
       const int u = tid + 256 * q, rr = u >> 6, k = u & 63;
-      if (k < dk) sx[rr][k] = xv[q] - mk;  // (padding rows and columns: mk - mk = 0)
+      sx[rr][k] = xv[q] - mk;  // (padding rows and columns: mk - mk = 0)
     }
     fetch(t + 1);
     __syncthreads();
-    f64x4 acc[FR_CB];
+    double xr[FR_DMAX];  // my row
 #pragma unroll
-    for (int cb = 0; cb < FR_CB; ++cb) acc[cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < FR_DMAX; ++k) xr[k] = sx[lane][k];
+    double res[FR_CPG];
+    // four columns at a time: four independent FMA chains (one chain alone waits out the fp64 FMA latency at every step -- the
+    // workgroup has one wave per SIMD; half rows in registers at three waves per SIMD spill and take 1.2 ms)
 #pragma unroll
-    for (int ks = 0; ks < FR_KS; ++ks) {
-      if (ks < ks_n) {  // (uniform)
-        const double a = sx[16 * w + l16][4 * ks + lk];
+    for (int c4 = 0; c4 < FR_CPG; c4 += 4) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (c4 < cpg) {  // (uniform)
+        const_f64x8_ptr arow[4];
 #pragma unroll
-        for (int cb = 0; cb < FR_CB; ++cb)
-          if (cb < cb_n) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sv[4 * ks + lk][16 * cb + l16], acc[cb], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)  // (columns beyond the wave's share or beyond d read a valid row; their result is dropped)
+          arow[i] = (const_f64x8_ptr)(uintptr_t)(At + (size_t)min(j0 + c4 + i, d - 1) * FR_DMAX);
+#pragma unroll
+        for (int k8 = 0; k8 < FR_DMAX / 8; ++k8) {
+          if (k8 < k8n) {  // (uniform; the axes are zero beyond d)
+            f64x8 av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = arow[i][k8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] = fma(xr[8 * k8 + e], av[i][e], acc[i]);
+          }
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res[c4 + i] = acc[i];
     }
     __syncthreads();  // (every wave has read its rows)
 #pragma unroll
-    for (int cb = 0; cb < FR_CB; ++cb)
-      if (cb < cb_n) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sx[16 * w + lk + 4 * i][16 * cb + l16] = acc[cb][i];
-      }
+    for (int c = 0; c < FR_CPG; ++c)
+      if (c < cpg && j0 + c < d) sx[lane][j0 + c] = res[c];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < FR_NQ; ++q) {
@@ -129,12 +141,12 @@ extern "C" int meld_cov_sample_f64(const double* X, int64_t N, int d, const doub
   return MELD_OK;
 }
 
-// out[N][d] = (X - mean) V   (V row-major [d][d]; out must not alias X)
-extern "C" int meld_rotate_rows_f64(const double* X, int64_t N, int d, const double* mean, const double* V, double* out, meld_stream_t stream) {
-  MELD_CHECK_ARG(X && mean && V && out && N > 0 && d > 0 && d <= FR_DMAX && X != out, "meld_rotate_rows_f64: bad arguments (d <= %d)", FR_DMAX);
-  const unsigned tiles = (unsigned)ceil_div(N, FR_ROWS);
-  const int64_t per = ceil_div((int64_t)tiles, (int64_t)768);  // (three workgroups per CU by their LDS)
-  hipLaunchKernelGGL(rotate_rows_kernel, dim3((unsigned)ceil_div((int64_t)tiles, per)), dim3(256), 0, S(stream), X, N, d, mean, V, out, per);
+// out[N][d] = (X - mean) A^T: row j of At[d][meld_frame_max_dims()] (zero-padded) = the j-th axis of the new frame; out must not alias X
+extern "C" int meld_rotate_rows_f64(const double* X, int64_t N, int d, const double* mean, const double* At, double* out, meld_stream_t stream) {
+  MELD_CHECK_ARG(X && mean && At && out && N > 0 && d > 0 && d <= FR_DMAX && X != out, "meld_rotate_rows_f64: bad arguments (d <= %d)", FR_DMAX);
+  const int64_t tiles = ceil_div(N, FR_ROWS);
+  const int64_t per = ceil_div(tiles, (int64_t)1024);
+  hipLaunchKernelGGL(rotate_rows_kernel, dim3((unsigned)ceil_div(tiles, per)), dim3(256), 0, S(stream), X, N, d, mean, At, out, per);
   MELD_LAUNCH_CHECK("rotate_rows_kernel");
   return MELD_OK;
 }

@@ -483,9 +483,11 @@ class HipOps:
         tot = float(evals.sum())
         if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
             return None
-        V = torch.from_numpy(np.ascontiguousarray(evecs[:, ::-1])).to(X.device)
+        At = np.zeros((d, int(lib.meld_frame_max_dims())))
+        At[:, :d] = evecs[:, ::-1].T  # the axes as rows, by descending variance
+        At = torch.from_numpy(At).to(X.device)
         out = torch.empty_like(X)
-        check(lib.meld_rotate_rows_f64(ptr(X), N, d, ptr(mean), ptr(V), ptr(out), st), "meld_rotate_rows_f64")
+        check(lib.meld_rotate_rows_f64(ptr(X), N, d, ptr(mean), ptr(At), ptr(out), st), "meld_rotate_rows_f64")
         return out
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
