@@ -387,9 +387,16 @@ def main():
             executed = 2.0 * rows * N * 16 * blocks
             # exact tile pruning: the kernel counts the (64 queries x 64 references) blocks it really computed
             wt = G.info.get("wave_tiles_done")
+            partial = None
             if wt:
                 executed = 2.0 * 64 * 64 * 16 * blocks * float(wt)
                 computed_frac = float(wt) / (math.ceil(rows / 64) * math.ceil(N / 64))
+                on = G.info.get("blocks_past_partial_test")
+                if on is not None and nprod == 1:
+                    # partial test (principal frame): every computed (wave, tile) pair issues K block 0 of its two blocks of 32
+                    # references; only the blocks that pass the test issue the other kb - 1 K blocks
+                    executed = 2.0 * 16 * (64 * 64 * float(wt) + 32 * 64 * (kb - 1) * float(on))
+                    partial = {"blocks_of_32_refs_past_the_first_k_block": int(on), "of": 2 * int(wt), "frac": float(on) / (2.0 * float(wt))}
             peak, kname = PEAK_MFMA_F16_TFLOPS, "knn16_topk_kernel (split-fp16 hi/lo distance GEMM on v_mfma_f32_32x32x16_f16 + streaming top-k)"
         else:
             kp = int(G.info.get("KP", d + 2))
@@ -419,9 +426,13 @@ def main():
             "stages".format(kp, ", split-fp16 products nprod={}".format(G.info.get("nprod")) if search == "f16x3" else "",
                             flops / t_knn / 1e12 / PEAK_MFMA_F32_TFLOPS, G.info.get("n_researched_rows", 0)),
             "blocks_computed_frac": computed_frac,
+            "partial_test": (partial if search == "f16x3" else None),
             "pruning_note": "algorithmic = the brute-force distance GEMM the path is specified by (SURVEY.md 8d); exact "
             "tile pruning (triangle-inequality bounds, results unchanged) lets a wave skip the (64 x 64) blocks that "
-            "cannot hold a neighbour: blocks_computed_frac of them are computed, `executed` counts only those",
+            "cannot hold a neighbour: blocks_computed_frac of them are computed, `executed` counts only those; in the cells' "
+            "principal frame a computed block of 32 references is tested behind its first K block (a distance over some coordinates "
+            "never exceeds the distance) and issues its other K blocks only if some partial value is within reach of its row: "
+            "`partial_test` counts those, `executed` = K block 0 of every computed block + the other K blocks of the ones that went on",
             "ms": 1e3 * t_knn,
         }
     if "cheby_steps" in ev:

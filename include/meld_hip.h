@@ -243,7 +243,8 @@ int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, c
                            const int32_t* block_order, int n_slices /* as meld_knn16_topk: slice y walks the entries y, y + S, ... of a
                            block's list into its own candidate rows; merge with meld_knn16_merge_slices */, meld_stream_t stream);
 /* ... with the partial test of the SPLIT layout: partial_test != 0 lets the pass drop a block of 32 references behind its first K
- * block when no partial value is within reach of its row (same rows, counts and thresholds; see meld_knn16_split_dims) */
+ * block when no partial value is within reach of its row (same rows, counts and thresholds; see meld_knn16_split_dims).
+ * tiles_done (optional) holds TWO counters here: [0] (wave, tile) pairs computed, [1] blocks of 32 references that went on. */
 int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
                                    int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
                                    int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,

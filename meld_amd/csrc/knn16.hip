@@ -317,6 +317,7 @@ struct K16Args {
   const int* step_cnt;
   long long list_stride;
   int ee_hi;  // EE kernels (SPLIT layout): physical K slots [16, ee_hi) hold the coordinates behind K block 0
+  int planes_used;  // 64-vector planes (8 K slots each) of a reference tile that hold anything: the hi-only pass copies no others
 };
 #define K16_COLD(FIELD) \
   (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
@@ -549,7 +550,17 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const int stage_off = (NPROD == 3) ? tid : (((tid >> 6) << 7) + (tid & 63));
   constexpr int STAGE_STRIDE = (NPROD == 3) ? K16_THREADS : 2 * K16_THREADS;  // offset step per round
   const bool stage_last = !STAGE_TAIL || wave < (N_STAGE % K16_THREADS) / 64;  // (wave-uniform)
-#define K16_ROUND_OK(U) ((U) + 1 < NS || stage_last)
+  // NPROD == 1: the last 64-vector plane of a tile (K slots 8 p .. 8 p + 7, one wave's copy of the last round) may hold nothing but
+  // padding -- d = 50: 56 of 64 slots used -- and is then never copied: its LDS slots are zeroed once (the queries' slots there are
+  // zero too, but 0 x stale bits could be a NaN).  An eighth of the tile stream at d = 50, and the stream is what bounds the
+  // kernel once the partial test has thinned the MFMAs (105 GB per launch at the fabric's copy rate).
+  const bool skip_tail = NPROD == 1 && NS >= 2 && (NS - 1) * (K16_THREADS / 64) + wave >= a.planes_used;  // (wave-uniform)
+  if (skip_tail) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      reinterpret_cast<float4*>(lds_ring + b * LDS_TILE_H)[((NS - 1) * (K16_THREADS / 64) + wave) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#define K16_ROUND_OK(U) (((U) + 1 < NS || stage_last) && !((U) + 1 == NS && skip_tail))
   // The descriptor (SGPRs) carries the tile base, the per-thread offset is one loop-invariant VGPR and the
   // round offset an SGPR.
   const int stage_voff = stage_off * 16;
@@ -582,7 +593,13 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 #define K16_STAGED() __builtin_amdgcn_s_waitcnt(0x0F70)
   // ... all but the copies of the request issued last (every wave issues at least NS - 1 copies per tile)
   constexpr int N_INFLIGHT = NS - (STAGE_TAIL ? 1 : 0);
-#define K16_STAGED_BUT_LAST() __builtin_amdgcn_s_waitcnt(0x0F70 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14))
+  // (a wave that skips its copy of the last round has one request fewer in flight per tile)
+  constexpr int N_INFLIGHT_SKIP = (!STAGE_TAIL && NS >= 2) ? N_INFLIGHT - 1 : N_INFLIGHT;
+#define K16_STAGED_BUT_LAST()                                                                                      \
+  do {                                                                                                             \
+    if (skip_tail) __builtin_amdgcn_s_waitcnt(0x0F70 | (N_INFLIGHT_SKIP & 15) | ((N_INFLIGHT_SKIP >> 4) << 14));   \
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | (N_INFLIGHT & 15) | ((N_INFLIGHT >> 4) << 14));                       \
+  } while (0)
   // tile barrier that leaves the vector-memory counter alone (LDS traffic of this wave done, then s_barrier)
 #define K16_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   K16_LOAD(__builtin_amdgcn_readfirstlane(LIST ? (int)(list_entry(0) & 0xFFFFFFu) : tile_of(0)), 0u);
@@ -915,7 +932,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
           }
           const float m0 = min16(accA0), m1 = min16(accA1);
           if (__any(m0 < thrp[0] || m1 < thrp[1])) select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
-          if (ABL == 2) ++st_go;
+          ++st_go;
         }
       }
       ++n_done;
@@ -1022,7 +1039,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false, true);  // drain: sub-tile 1 of the last tile
   {
     unsigned long long* tiles_done = K16_COLD(tiles_done);
-    if (tiles_done && lane == 0) atomicAdd(tiles_done, (unsigned long long)n_done);
+    if (tiles_done && lane == 0) {
+      atomicAdd(tiles_done, (unsigned long long)n_done);
+      if (EE) atomicAdd(tiles_done + 1, (unsigned long long)st_go);  // (blocks of 32 references that went on past K block 0)
+    }
   }
 
   unsigned long long* stats = ABL == 2 ? K16_COLD(stats) : nullptr;
@@ -2747,6 +2767,11 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   const char* ee_env = getenv("MELD_KNN16_EE");
   const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
   ka.ee_hi = 16 + d - dA;
+  {
+    const int slots_used = dA > 0 ? 16 + (d - dA) + 3 : d + 3;
+    const char* sk = getenv("MELD_KNN16_SKIP_PAD");  // (=0: copy the padding plane as before, for A-B measurements)
+    ka.planes_used = (sk && atoi(sk) == 0) ? 2 * KB : (slots_used + 7) / 8;
+  }
 #ifndef K16_PROFILING
   MELD_CHECK_ARG(abl == 0, "MELD_KNN16_ABLATION needs a library built with -DK16_PROFILING");
 #endif
@@ -2890,6 +2915,7 @@ extern "C" int meld_knn16_topk_listed(const void* Q16, const float* Qn, const vo
 // The same with the partial test of the SPLIT layout (meld_knn16_split_dims(d) > 0): partial_test != 0 lets the pass drop a block
 // of 32 references behind its first K block when no partial value is within reach of its row -- same rows, counts and
 // thresholds; worth asking for when the leading coordinates of the operands carry the distances (principal coordinates).
+// tiles_done (optional) then counts two things: [0] the (wave, tile) pairs computed, [1] the blocks of 32 references that went on.
 extern "C" int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref,
                                               int d, int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt,
                                               int64_t list_stride, const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,

@@ -466,7 +466,7 @@ class HipOps:
         check(self.lib.meld_col_stats_f64(ptr(X), N, d, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(tmp), tb, _stream()), "meld_col_stats_f64")
         return out[0], out[1], out[2]
 
-    def principal_frame(self, X, mean, lead):
+    def principal_frame(self, X, mean, lead, comm=None):
         """The cells in their principal frame, ``(X - mean) V`` with the eigenvectors of the covariance (of at most 32768 evenly
         spaced rows, ``meld_cov_sample_f64``) in descending order of variance (``meld_rotate_rows_f64``) -- or None when the
         ``lead`` leading coordinates would carry less than half of the variance (the search's partial test would seldom drop a
@@ -479,6 +479,13 @@ class HipOps:
             return None
         cov = torch.zeros(d, d, dtype=torch.float64, device=X.device)
         check(lib.meld_cov_sample_f64(ptr(X), N, d, ptr(mean), max(1, N // 32768), ptr(cov), st), "meld_cov_sample_f64")
+        if comm is not None and getattr(comm, "world", 1) > 1:
+            # ranks of a row-sharded build hold the same cells but sum their scatter matrices in different orders (atomics): all
+            # take rank 0's bits, so that the frame -- and the decision to use one -- is the same everywhere (the tile spheres
+            # are shared between the ranks)
+            if comm.rank != 0:
+                cov.zero_()
+            comm.all_reduce_sum(cov)
         evals, evecs = np.linalg.eigh(cov.cpu().numpy(), UPLO="U")  # (row-major upper triangle)
         tot = float(evals.sum())
         if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
@@ -591,12 +598,12 @@ class HipOps:
             n_tiles = (NR + TS - 1) // TS
             q_pad = ((q_count + BQ - 1) // BQ) * BQ
             # The frame of the search (X_s, its mean and column extremes): the cells' principal frame where the first pass can
-            # use it -- operands in the split layout, step lists, all cells against all cells on one GPU -- else X itself.
+            # use it -- operands in the split layout, seeds and step lists, the whole graph or a row shard of it -- else X itself.
             # Everything up to the candidate lists works on X_s; refinement and the exact sweeps on X.
             lead = int(lib.meld_knn16_split_dims(d))
             if (self.rotate and lead > 0 and nprod == 1 and not cross and self.prune and self.step_lists and self.seed and N >= 16384
-                    and q_begin == 0 and q_count == N and (comm is None or getattr(comm, "world", 1) == 1) and bw_fixed is None):
-                X_s = self.principal_frame(X, mean, lead)
+                    and q_begin % BQ == 0 and bw_fixed is None):
+                X_s = self.principal_frame(X, mean, lead, comm)
                 if X_s is not None:
                     sums_s, col_min, col_max = self.col_stats(X_s)
                     X_search, mean_search = X_s, sums_s / N
@@ -627,7 +634,7 @@ class HipOps:
                 # (the cut keeps everything within max(rf * bandwidth_scale, 1) bandwidths: never less than the bandwidth entry)
                 rfac = max(rfac * float(bw_scale), 1.0)
             lb2 = block_order = step_list = step_cnt = None
-            tiles_done = torch.zeros(1, dtype=torch.int64, device=dev)
+            tiles_done = torch.zeros(2, dtype=torch.int64, device=dev)  # [(wave, tile) pairs computed, blocks of 32 references past the partial test]
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
             n_blocks = q_pad // BQ
             seeds = None
@@ -862,12 +869,13 @@ class HipOps:
         keep_off = _scan_i32(lib, keep_cnt, st)
         # ONE read-back for the three scalars the host wants here (each one is an idle gap of the GPU of ~50 us: nothing is queued
         # behind it): rows still flagged after the second stage, kept entries, (wave, tile) pairs the first pass computed
-        heads = [n_flag[0].to(torch.int64), keep_off[q_count]] + ([tiles_done[0]] if tiles_done is not None else [])
+        heads = [n_flag[0].to(torch.int64), keep_off[q_count]] + ([tiles_done[0], tiles_done[1]] if tiles_done is not None else [])
         heads_h = torch.stack(heads).tolist()
         if n_flag_stale:
             n_flag_h = int(heads_h[0])
         m_main = int(heads_h[1])
         tiles_done_h = int(heads_h[2]) if tiles_done is not None else None
+        blocks_on_h = int(heads_h[3]) if tiles_done is not None and X_search is not X else None
 
         # Many uncertified rows with a short candidate list (dense low-dimensional data: more than ksel cells
         # inside the radius inflated by the search-error allowance): search once more with the longest list
@@ -998,7 +1006,7 @@ class HipOps:
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
-                    wave_tiles_done=tiles_done_h)
+                    wave_tiles_done=tiles_done_h, blocks_past_partial_test=blocks_on_h)
         if assembled is not None:
             info["assembled"] = assembled  # (rowptr, col, val) of the symmetrised rows: the caller skips assemble_rows
         return keys, vals, bw, info

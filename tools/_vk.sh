@@ -1,7 +1,9 @@
 #!/bin/bash
-# search-stage time with variant builds of the library (tools/build_variant.sh): bash tools/_vk.sh [N] v1 v2 ...   ("base" = the in-tree build)
-n=$1; shift
+# search kernel time with variant builds: bash tools/_vk.sh v1 v2 ...
+cp meld_amd/libmeld_hip.so /tmp/libmeld_hip_base.so
+echo "== base"; python tools/knn_only.py 1000000 4 2>&1 | tail -1
 for v in "$@"; do
-  lib=meld_amd/libmeld_hip_$v.so; [ "$v" = base ] && lib=meld_amd/libmeld_hip.so
-  echo "== $v"; MELD_HIP_LIB=$PWD/$lib python tools/knn_only.py $n 3 2>&1 | grep -v amdgpu.ids | tail -3
+  cp meld_amd/libmeld_hip_$v.so meld_amd/libmeld_hip.so
+  echo "== $v"; python tools/knn_only.py 1000000 4 2>&1 | tail -1
 done
+cp /tmp/libmeld_hip_base.so meld_amd/libmeld_hip.so
