@@ -554,7 +554,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // padding -- d = 50: 56 of 64 slots used -- and is then never copied: its LDS slots are zeroed once (the queries' slots there are
   // zero too, but 0 x stale bits could be a NaN).  An eighth of the tile stream at d = 50, and the stream is what bounds the
   // kernel once the partial test has thinned the MFMAs (105 GB per launch at the fabric's copy rate).
-  const bool skip_tail = NPROD == 1 && NS >= 2 && (NS - 1) * (K16_THREADS / 64) + wave >= a.planes_used;  // (wave-uniform)
+  // (the plane must exist: with an odd number of K blocks the last round has planes for half of the waves only -- the others
+  // would zero the head of the NEXT ring buffer under its first copy: one build in twenty lost a block's candidates that way)
+  const int tail_plane = (NS - 1) * (K16_THREADS / 64) + wave;
+  const bool skip_tail = NPROD == 1 && NS >= 2 && tail_plane < 2 * KB && tail_plane >= a.planes_used;  // (wave-uniform)
   if (skip_tail) {
 #pragma unroll
     for (int b = 0; b < 3; ++b)
