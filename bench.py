@@ -361,7 +361,7 @@ def main():
                 N, d, {1_000_000: "BASELINE configs[3] size, the size the metric is quoted on", 500_000: "BASELINE configs[2]",
                        50_000: "BASELINE configs[1]"}.get(N, "custom size"), args.knn, args.beta, args.order, p),
             "spmm_kernel": G.info.get("spmm"),
-            "search_options": {k: G.info.get(k) for k in ("search", "nprod", "prune", "radius_cut", "seed") if k in G.info},
+            "search_options": {k: G.info.get(k) for k in ("search", "nprod", "prune", "radius_cut", "seed", "step_lists", "principal_frame") if k in G.info},
             "parallelism": "single GPU" if world == 1 else "rows sharded over {} GPUs, all-gather per Chebyshev step".format(world),
             "nnz_W": nnz,
             "mean_degree": nnz / N,

@@ -89,6 +89,16 @@ PY
   python tools/list_stats.py 2>&1 | grep -v amdgpu.ids | tail -9
   MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats" | head -2
   } > $out/knn_ablation.txt
+{ stamp; echo "# the partial-distance test of the first pass (principal frame, K block 0 = 13 coordinates): what it drops (kernel counters), what it could drop (tools/sim_partial.py), what the frame costs (tools/time_rotate.py), A-B timings of the search stage"
+  MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats\|knn_topk" | head -4
+  echo "## default"; python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  echo "## MELD_KNN16_EE=0 (principal frame, no test)"; MELD_KNN16_EE=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  echo "## MELD_KNN_ROTATE=0 (cells as given, no test)"; MELD_KNN_ROTATE=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  echo "## MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 (cells as given, test forced on)"; MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  echo "## MELD_KNN16_SKIP_PAD=0 (the all-padding plane of every tile staged as before)"; MELD_KNN16_SKIP_PAD=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  python tools/time_rotate.py 2>&1 | grep -v amdgpu.ids | tail -9
+  python tools/sim_partial.py 1000000 64 2>&1 | grep -v amdgpu.ids | tail -16
+  DATA=iid python tools/sim_partial.py 200000 32 2>&1 | grep -v amdgpu.ids | head -3; } > $out/partial_test.txt
 { stamp; echo "# per-rank compute of the sharded driver on ONE GPU (stand-in collectives, results wrong by construction): tools/shard_emulate.py"
   for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done
   echo "# rank 0 with the recurrences enqueued from C on a REAL one-rank RCCL communicator (RCCL=1: meld_cheby_run_sharded / meld_lanczos_steps_sharded), and the per-step Python loops beside it (RCCL=0)"
