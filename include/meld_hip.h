@@ -236,6 +236,11 @@ size_t meld_knn16_list_scratch_bytes(int64_t n_ref);
 int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, const double* mean, const float* scale_info, const float* norm2_max,
                                  const void* Rt16, const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* scratch,
                                  uint32_t* list, int64_t list_stride, int32_t* cnt, meld_stream_t stream);
+/* ... with the bounds taken from the first K block of the operands alone (lead_only != 0; SPLIT layout, cells in a frame whose
+ * leading coordinates carry the distances -- see meld_knn16_split_dims): lower bounds all the same, a quarter of the tile stream. */
+int meld_knn16_step_lists_direct_lead(const double* X, int64_t N, int d, const double* mean, const float* scale_info, const float* norm2_max,
+                                 const void* Rt16, const float* thr_seed, const float* q_norm2, int nprod, void* temp, void* scratch,
+                                 uint32_t* list, int64_t list_stride, int32_t* cnt, int lead_only, meld_stream_t stream);
 int meld_knn16_topk_listed(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, int64_t n_ref, int d,
                            int64_t q_count, int ksel, const uint32_t* step_list, const int32_t* step_cnt, int64_t list_stride,
                            const float* norm2_max, int64_t q_begin, const float* thr_init, int knn, double radius_factor,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "meld_knn16_step_lists": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr]),
     "meld_knn16_list_scratch_bytes": (_sz, [_i64]),
     "meld_knn16_step_lists_direct": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr]),
+    "meld_knn16_step_lists_direct_lead": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _i32, _ptr]),
     "meld_knn16_topk_listed": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_knn16_topk_listed_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "meld_knn16_seed_thresholds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),

@@ -1383,7 +1383,11 @@ __global__ __launch_bounds__(256) void tile_spheres_kernel(const double* __restr
 // is max(bound(w, t), bound(t, w)), so (w, t) is listed iff A[w][t] and B[t][w]: a bit-matrix transpose and an AND
 // (knn16_bits_transpose_and_kernel) replace the table's 488 MB at 1M cells, the 64 x 64-entry symmetrisation pass over it and the
 // list builder's pass over it.  wthr[w] = largest seed of wave w + the search-error allowance (-inf: no cells).
-template <int KB, bool SEEDED, int BT, bool BITS = false>  // BT threads = BT centroids per workgroup
+// KU < KB (KU = 1, SPLIT operand layout, cells in their principal frame): only the first K block of the operands is staged and
+// multiplied -- |p_A - c_A| over its dA coordinates never exceeds |p - c|, and the radius of a tile in the full space is at least its
+// radius in that subspace, so (|p_A - c_A| - rho)^2 is a lower bound too (N_A = |p_A|^2 - m_p only lowers it further); a quarter of
+// the staging and two of five MFMAs per accumulator.  |c_A|^2 is summed here from the hi + lo parts of the centroid row.
+template <int KB, bool SEEDED, int BT, bool BITS = false, int KU = KB>  // BT threads = BT centroids per workgroup
 __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* __restrict__ C16, const float* __restrict__ Cn,
                                                                 const float* __restrict__ Cr,
                                                                 const _Float16* __restrict__ Rt16, int n_tiles,
@@ -1395,9 +1399,9 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
                                                                 const float* __restrict__ q_norm2, float err_c, float err_l,
                                                                 __half* __restrict__ lb2, const float* __restrict__ wthr = nullptr,
                                                                 unsigned long long* __restrict__ bits_a = nullptr,
-                                                                unsigned long long* __restrict__ bits_b = nullptr, int wpr = 0) {
+                                                                unsigned long long* __restrict__ bits_b = nullptr, int wpr = 0, int dA = 0) {
   constexpr int TPB = 1;  // one table row per wave of the search kernel: its 64 queries = one reference tile
-  constexpr int HV = KB * 2 * K16_TS;   // hi vectors per tile
+  constexpr int HV = KU * 2 * K16_TS;   // hi vectors per tile (of the K blocks that are used)
   constexpr int NS = (HV + BT - 1) / BT;
   __shared__ __attribute__((aligned(16))) float4 lds_a[2][HV];
   // SEEDED: the per-query terms ride on the matrix pipe too.  acc_pt - s_p^2 - 2 s_p rho_t = acc_pt + (s_p^2)(-1) + (s_p)(-2 rho_t):
@@ -1408,15 +1412,25 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
   __shared__ __attribute__((aligned(16))) f16x8 lds_x[2][2 * K16_TS];  // per cell of the tile: (s_p^2, s_p, 0 ...); second half: zeros
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jq = lane & 31, h = lane >> 5;
   const int c_base = blockIdx.x * BT + wave * 64;
-  f16x8 bhi[2][KB];
+  f16x8 bhi[2][KU];
   float cn[2], cr[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const f16x8* qrow = reinterpret_cast<const f16x8*>(C16 + (size_t)(c_base + g * 32 + jq) * (KB * 32));
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
+    for (int kb = 0; kb < KU; ++kb) bhi[g][kb] = qrow[(kb * 2 + h) * 2 + 0];
     cn[g] = Cn[c_base + g * 32 + jq];
     cr[g] = Cr[c_base + g * 32 + jq];
+    if (KU < KB) {  // |c_A|^2 over the dA coordinates of K block 0 (the half-lanes of a centroid hold slots 0..7 and 8..15)
+      const f16x8 lo = qrow[(0 * 2 + h) * 2 + 1];
+      float n = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (8 * h + e < dA) ? (float)bhi[g][0][e] + (float)lo[e] : 0.0f;
+        n = fmaf(v, v, n);
+      }
+      cn[g] = n + __shfl_xor(n, 32, 64);
+    }
   }
   float wcol[2] = {-INFINITY, -INFINITY};  // BITS: start threshold (+ allowance) of the wave whose cells are this centroid's tile
   if (BITS) {
@@ -1437,7 +1451,8 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
       bx[g][1] = (_Float16)(-__half2float(__float2half_ru(2.0f * cr[g])));
     }
   }
-  const float err_abs = err_coef * norm2_max[0] * scale_info[0] * scale_info[0];
+  // (KU < KB: + 2^-19 n_max for |c_A|^2 taken from the hi + lo parts)
+  const float err_abs = (err_coef + (KU < KB ? 1.9073486328125e-06f : 0.0f)) * norm2_max[0] * scale_info[0] * scale_info[0];
   const int b_lo = (int)((long long)n_blocks * blockIdx.y / gridDim.y);
   const int b_hi = (int)((long long)n_blocks * (blockIdx.y + 1) / gridDim.y);
   const int n_steps = (b_hi - b_lo) * TPB;
@@ -1501,7 +1516,7 @@ __global__ __launch_bounds__(BT) void knn16_tile_bounds_kernel(const _Float16* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
+        for (int kb = 0; kb < KU; ++kb) {
           const f16x8 ahi = a8[(kb * 2 + h) * K16_TS + sub * 32 + jq];
           c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], c1, 0, 0, 0);
@@ -2490,10 +2505,10 @@ extern "C" size_t meld_knn16_list_scratch_bytes(int64_t n_ref) {
   return ((n_q * sizeof(float) + 255) / 256) * 256 + 3 * n_q * wpr * sizeof(unsigned long long);
 }
 
-extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
-                                            const float* norm2_max, const void* Rt16, const float* thr_seed, const float* q_norm2,
-                                            int nprod, void* temp, void* scratch, uint32_t* list, int64_t list_stride, int32_t* cnt,
-                                            meld_stream_t stream) {
+static int k16_step_lists_direct_impl(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                      const float* norm2_max, const void* Rt16, const float* thr_seed, const float* q_norm2,
+                                      int nprod, void* temp, void* scratch, uint32_t* list, int64_t list_stride, int32_t* cnt,
+                                      int lead_only, meld_stream_t stream) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_step_lists_direct: nprod must be 1 or 3");
   MELD_CHECK_ARG(X && mean && scale_info && norm2_max && Rt16 && thr_seed && q_norm2 && temp && scratch && list && cnt && N > 0,
                  "meld_knn16_step_lists_direct: bad arguments");
@@ -2522,7 +2537,16 @@ extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, c
   const int gx = (int)(n_c / bt);
   const int gy = std::max(1, std::min(n_q, (int)ceil_div(2048, gx)));
   const float ec = (float)meld_knn16_error_coef(1, d);
+  // lead_only (the caller's word that the leading coordinates carry the distances, SPLIT layout only): bounds from K block 0 alone
+  const int dA = k16_dA(d, KB);
+  const bool lead = lead_only != 0 && dA > 0 && KB >= 2 && !(getenv("MELD_KNN16_LEAD_BOUNDS") && atoi(getenv("MELD_KNN16_LEAD_BOUNDS")) == 0);
 #define K16_BITS_LAUNCH(KBV, BTV)                                                                                          \
+  if (lead)                                                                                                                \
+    hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true, BTV, true, (KBV >= 2 ? 1 : KBV)>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr, \
+                       reinterpret_cast<const _Float16*>(Rt16), n_t, 0, n_q, ec, norm2_max, scale_info, thr_seed, N, es, 1, q_norm2, \
+                       (float)meld_knn16_error_coef_const(nprod, d), (float)meld_knn16_error_coef_lin(nprod), (__half*)nullptr, wthr,  \
+                       bits_a, bits_b, wpr, dA);                                                                          \
+  else                                                                                                                     \
   hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true, BTV, true>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr,        \
                      reinterpret_cast<const _Float16*>(Rt16), n_t, 0, n_q, ec, norm2_max, scale_info, thr_seed, N, es, 1, q_norm2, \
                      (float)meld_knn16_error_coef_const(nprod, d), (float)meld_knn16_error_coef_lin(nprod), (__half*)nullptr, wthr,  \
@@ -2556,6 +2580,24 @@ extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, c
                      (long long)list_stride, cnt);
   MELD_LAUNCH_CHECK("knn16_step_list_bits_kernel");
   return MELD_OK;
+}
+
+extern "C" int meld_knn16_step_lists_direct(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                            const float* norm2_max, const void* Rt16, const float* thr_seed, const float* q_norm2,
+                                            int nprod, void* temp, void* scratch, uint32_t* list, int64_t list_stride, int32_t* cnt,
+                                            meld_stream_t stream) {
+  return k16_step_lists_direct_impl(X, N, d, mean, scale_info, norm2_max, Rt16, thr_seed, q_norm2, nprod, temp, scratch, list, list_stride, cnt, 0,
+                                    stream);
+}
+// The same with the bounds taken from the first K block of the operands alone (lead_only != 0; SPLIT layout, cells handed over in
+// a frame whose leading coordinates carry the distances): lower bounds all the same -- the lists are a superset of the exact ones
+// either way -- for a quarter of the tile stream and two of five MFMAs per bound.
+extern "C" int meld_knn16_step_lists_direct_lead(const double* X, int64_t N, int d, const double* mean, const float* scale_info,
+                                                 const float* norm2_max, const void* Rt16, const float* thr_seed, const float* q_norm2,
+                                                 int nprod, void* temp, void* scratch, uint32_t* list, int64_t list_stride, int32_t* cnt,
+                                                 int lead_only, meld_stream_t stream) {
+  return k16_step_lists_direct_impl(X, N, d, mean, scale_info, norm2_max, Rt16, thr_seed, q_norm2, nprod, temp, scratch, list, list_stride, cnt,
+                                    lead_only, stream);
 }
 
 // Start values for the thresholds of meld_knn16_topk's first pass (thr_init, scaled units, roundup(q_count, BQ)
@@ -2793,11 +2835,11 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   do {                               \
     if (step_list != nullptr) {      \
       K16_DEV_LIST_ABL(KBV)          \
-      if (ee && KBV >= 2) {          \
+      if (ee && KBV >= 2 && KBV <= 6) { /* (beyond six K blocks the variant spills; the frame kernels stop at d = 64 anyway) */ \
         if (stats != nullptr)        \
-          hipLaunchKernelGGL((knn16_topk_kernel<(KBV >= 2 ? KBV : 2), 2, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 6) ? KBV : 2), 2, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
         else                         \
-          hipLaunchKernelGGL((knn16_topk_kernel<(KBV >= 2 ? KBV : 2), 0, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 6) ? KBV : 2), 0, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
       } else if (stats != nullptr)   \
         hipLaunchKernelGGL((knn16_topk_kernel<KBV, 2, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
       else                           \

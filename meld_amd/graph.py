@@ -699,8 +699,8 @@ class HipOps:
                     step_list = torch.empty(n_blocks * n_tiles, dtype=torch.int32, device=dev)
                     step_cnt = torch.empty(n_blocks, dtype=torch.int32, device=dev)
                     scratch = torch.empty(lib.meld_knn16_list_scratch_bytes(N), dtype=torch.uint8, device=dev)
-                    check(lib.meld_knn16_step_lists_direct(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), ptr(Rt), ptr(seeds), ptr(Qn), nprod,
-                                                           ptr(tmpb), ptr(scratch), ptr(step_list), n_tiles, ptr(step_cnt), st), "meld_knn16_step_lists_direct")
+                    check(lib.meld_knn16_step_lists_direct_lead(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), ptr(Rt), ptr(seeds), ptr(Qn), nprod,
+                                                                ptr(tmpb), ptr(scratch), ptr(step_list), n_tiles, ptr(step_cnt), int(X_search is not X), st), "meld_knn16_step_lists_direct")
                     del scratch
                     work = step_cnt
                 else:

@@ -36,8 +36,10 @@ def _resource_usage(src):
 def test_search_kernels_do_not_spill():
     rows = _resource_usage(os.path.join(ROOT, "meld_amd", "csrc", "knn16.hip"))
     product = {k: v for k, v in rows.items() if "knn16_topk_kernelILi" in k and "ELi0ELi" in k}  # ABL = 0
-    # KB = 1..9 x NPROD in {1, 3}, table-driven (LIST = false) + KB = 1..9 list-driven hi-only first pass (LIST = true)
-    assert len(product) == 27 and sum("ELb1E" in k for k in product) == 9, sorted(product)
+    # KB = 1..9 x NPROD in {1, 3}, table-driven (LIST = false) + KB = 1..9 list-driven hi-only first pass (LIST = true) + KB = 2..6
+    # the same with the partial test behind the first K block (EE = true)
+    assert len(product) == 32, sorted(product)
+    assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 5, sorted(product)
     for name, r in product.items():
         assert r["ScratchSize [bytes/lane]:"] == 0, (name, r)
     # the benchmark configuration (d = 50: KB = 4, hi-only first pass) keeps three waves per SIMD, on both kernels
