@@ -1079,14 +1079,20 @@ def test_direct_step_lists_equal_the_table_driven_ones():
     X, _ = mo.synthetic_cells(400000, n_dims=50, seed=5)  # (enough query blocks for the list-driven pass: 2 x the resident workgroups)
     Xd = torch.from_numpy(X).cuda()
     graphs = {}
-    for direct in ("1", "0"):
+    # (in the principal frame the direct lists take their bounds from the first K block of the operands alone -- lower bounds all the
+    # same, a few more blocks computed: "lead"; MELD_KNN16_LEAD_BOUNDS=0 gives them the full distances the table is built from)
+    for direct, lead in (("1", "0"), ("0", "0"), ("1", "1")):
         os.environ["MELD_KNN_LIST_DIRECT"] = direct
+        os.environ["MELD_KNN16_LEAD_BOUNDS"] = lead
         try:
-            graphs[direct] = meld_amd.build_knn_graph(Xd, knn=15)
+            graphs[direct if lead == "0" else "lead"] = meld_amd.build_knn_graph(Xd, knn=15)
         finally:
             os.environ.pop("MELD_KNN_LIST_DIRECT", None)
-        assert graphs[direct].info["step_lists"]
-    A, B = graphs["1"], graphs["0"]
+            os.environ.pop("MELD_KNN16_LEAD_BOUNDS", None)
+        assert graphs[direct if lead == "0" else "lead"].info["step_lists"]
+    A, B, L = graphs["1"], graphs["0"], graphs["lead"]
+    assert torch.equal(A.rowptr, L.rowptr) and torch.equal(A.col, L.col) and torch.equal(A.val, L.val)
+    assert 0 <= L.info["wave_tiles_done"] - A.info["wave_tiles_done"] <= 0.02 * A.info["wave_tiles_done"]
     assert torch.equal(A.rowptr, B.rowptr) and torch.equal(A.col, B.col) and torch.equal(A.val, B.val)
     # the same (wave, tile) blocks were computed -- except by the padding waves of the last query block (128 padding queries here),
     # which the direct lists leave out of every step and the table keeps at whatever their padding seeds say

@@ -96,6 +96,8 @@ PY
   echo "## MELD_KNN_ROTATE=0 (cells as given, no test)"; MELD_KNN_ROTATE=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
   echo "## MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 (cells as given, test forced on)"; MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 python tools/knn_only.py 1000000 4 2>&1 | tail -1
   echo "## MELD_KNN16_SKIP_PAD=0 (the all-padding plane of every tile staged as before)"; MELD_KNN16_SKIP_PAD=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
+  echo "## stage timers of a step (bench.py --stages): default, and MELD_KNN16_LEAD_BOUNDS=0 (the direct lists' bounds from all K blocks)"
+  bash tools/_stages.sh A=1 2>&1 | grep -v amdgpu.ids | tail -1; bash tools/_stages.sh MELD_KNN16_LEAD_BOUNDS=0 2>&1 | grep -v amdgpu.ids | tail -1
   python tools/time_rotate.py 2>&1 | grep -v amdgpu.ids | tail -9
   python tools/sim_partial.py 1000000 64 2>&1 | grep -v amdgpu.ids | tail -16
   DATA=iid python tools/sim_partial.py 200000 32 2>&1 | grep -v amdgpu.ids | head -3; } > $out/partial_test.txt
