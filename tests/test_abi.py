@@ -53,3 +53,25 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|meld_oracle|/root/reference", txt, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_split_layout_geometry_is_a_function_of_the_dimension():
+    """No compute, no GPU: which dimensions get the split operand layout (13 coordinates and their norm pieces in K block 0, see
+    include/meld_hip.h) -- wherever d > 13 and d + 6 K slots fit the K blocks d + 3 needs -- and the development switch."""
+    from meld_amd._lib import get_lib
+
+    lib = get_lib()
+    want = {1: 0, 13: 0, 14: 13, 26: 13, 27: 0, 29: 0, 30: 13, 42: 13, 43: 0, 45: 0, 46: 13, 50: 13, 58: 13, 59: 0, 61: 0, 62: 13, 141: 0}
+    for d, lead in want.items():
+        kb = lib.meld_knn16_kblocks(d)
+        assert kb == (d + 3 + 15) // 16
+        assert lib.meld_knn16_split_dims(d) == lead, d
+        assert (lead == 13) == (d > 13 and d + 6 <= 16 * kb)
+    assert lib.meld_knn16_split_dims(500) == 0  # (no kernel for that many K blocks)
+    was = lib.meld_knn16_debug_split(0)
+    try:
+        assert was == 1 and lib.meld_knn16_split_dims(50) == 0
+    finally:
+        lib.meld_knn16_debug_split(was)
+    assert lib.meld_knn16_split_dims(50) == 13 and lib.meld_knn16_debug_split(-1) == 1
+    assert lib.meld_frame_max_dims() == 64
