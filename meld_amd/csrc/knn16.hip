@@ -67,6 +67,9 @@ constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 // references in which no partial value is below its row's threshold (+ |q_B|^2: the most the other blocks can take away, m_r
 // covering the fp16 rounding of r_B: see prepare16_kernel).  It pays when the leading coordinates carry the distances (principal
 // coordinates: the host rotates the cells for the search, meld_amd/graph.py; any orthonormal frame is valid).
+#ifndef K16_EE_PAIRS
+#define K16_EE_PAIRS 1
+#endif
 constexpr int K16_SPLIT_DA = 13;
 __host__ __device__ inline int k16_split_dims_of(int d, int KB, int enabled) {
   return (enabled && d > K16_SPLIT_DA && d + 6 <= 16 * KB) ? K16_SPLIT_DA : 0;
@@ -368,7 +371,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // a ring addressed by a rotating offset that is every A-fragment read.  (The earlier build kept two separate
   // arrays and the loop unrolled by two so that the pass could prove them disjoint; three arrays unrolled by three
   // spill and no longer fit the instruction cache.)  The waits are explicit instead: K16_STAGED / _BUT_LAST.
-  __shared__ __attribute__((aligned(16))) _Float16 lds_ring[3 * LDS_TILE_H];
+  // PAIR (EE kernels, -DK16_EE_PAIRS): two tiles per step and barrier, two buffers of two tiles -- the steps of the partial-test
+  // pass are short, and a barrier + the control around it per 64 references is a third of what a wave spends
+  constexpr bool PAIR = EE && (K16_EE_PAIRS != 0);
+  constexpr int NBUF = PAIR ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) _Float16 lds_ring[NBUF * LDS_TILE_H];
   constexpr int TILE_LDS_BYTES = LDS_TILE_H * 2;
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
@@ -560,7 +567,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   const bool skip_tail = NPROD == 1 && NS >= 2 && tail_plane < 2 * KB && tail_plane >= a.planes_used;  // (wave-uniform)
   if (skip_tail) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < NBUF; ++b)
       reinterpret_cast<float4*>(lds_ring + b * LDS_TILE_H)[((NS - 1) * (K16_THREADS / 64) + wave) * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #define K16_ROUND_OK(U) (((U) + 1 < NS || stage_last) && !((U) + 1 == NS && skip_tail))
@@ -605,7 +612,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   } while (0)
   // tile barrier that leaves the vector-memory counter alone (LDS traffic of this wave done, then s_barrier)
 #define K16_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  K16_LOAD(__builtin_amdgcn_readfirstlane(LIST ? (int)(list_entry(0) & 0xFFFFFFu) : tile_of(0)), 0u);
+  if constexpr (!PAIR) K16_LOAD(__builtin_amdgcn_readfirstlane(LIST ? (int)(list_entry(0) & 0xFFFFFFu) : tile_of(0)), 0u);
 
   // The query fragments / norms must have landed BEFORE the loop: otherwise the compiler sinks
   // their loads past the first barrier and then has to guard their first use inside the loop with
@@ -866,10 +873,39 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   // chosen during the previous iteration) is already known, so its tile loads go out at once and the
   // LDS round trip + scalar work that picks the step after it overlaps with the MFMA segments instead of
   // sitting in front of the loads.
+  // one tile of the partial-test pass (EE): the wave's 64 queries against the 64 references of the tile at tile_r
+  int n_done = 0;         // tiles this wave has taken part in
+  auto ee_tile = [&](const _Float16* tile_r, int t) __attribute__((always_inline)) {
+    // Per sub-tile (32 references): K block 0 (2 MFMAs), the partial test, and only a block that passes it goes on: the other
+    // K blocks, the vote and -- if some value is below its row's threshold -- the slow path.  No block is left pending across
+    // tiles; both A fragments of K block 0 are requested before the first MFMA.
+    const f16x8* a8 = reinterpret_cast<const f16x8*>(tile_r) + jq;
+    const f16x8 aA = a8[h * K16_TS], aB = a8[32 + h * K16_TS];
+    const float tA0 = thrp[0] + ee_c[0], tA1 = thrp[1] + ee_c[1];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = 0.0f;
+      accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[0][0], accA0, 0, 0, 0);
+      accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[1][0], accA1, 0, 0, 0);
+      if (__any(min16(accA0) < tA0 || min16(accA1) < tA1)) {
+        const f16x8* as = a8 + sub * 32;
+#pragma unroll
+        for (int kb = 1; kb < KB; ++kb) {
+          const f16x8 ahi = as[(kb * 2 + h) * K16_TS];
+          accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], accA0, 0, 0, 0);
+          accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], accA1, 0, 0, 0);
+        }
+        const float m0 = min16(accA0), m1 = min16(accA1);
+        if (__any(m0 < thrp[0] || m1 < thrp[1])) select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
+        ++st_go;
+      }
+    }
+    ++n_done;
+  };
   int s_cur = 0;
   int par = 0;
   int it = 0;             // tiles the workgroup has staged so far
-  int n_done = 0;         // tiles this wave has taken part in
   bool live_cur = true;   // does this wave take part in the current tile
   bool pend = false;      // accB holds a block that has not been voted on yet
   unsigned e_pref = 0u;   // LIST: the entry of the step after s_next
@@ -887,13 +923,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     live_next = entry_live(e1);
   }
   // tiles of steps 0 and s_next requested; the first one has to be there
-  if (s_next < n_scan && ABL != 9) {
-    K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), (unsigned)TILE_LDS_BYTES);
-    K16_STAGED_BUT_LAST();
-  } else {
-    K16_STAGED();
+  if constexpr (!PAIR) {
+    if (s_next < n_scan && ABL != 9) {
+      K16_LOAD(__builtin_amdgcn_readfirstlane(ABL == 8 ? (t_next & 63) : t_next), (unsigned)TILE_LDS_BYTES);
+      K16_STAGED_BUT_LAST();
+    } else {
+      K16_STAGED();
+    }
+    K16_TILE_BARRIER();
   }
-  K16_TILE_BARRIER();
   // ring positions (byte offsets, wave-uniform): the tile being read, the next one (requested), the one to request
   unsigned rd_b = 0u, nx_b = (unsigned)TILE_LDS_BYTES, wr_b = 2u * (unsigned)TILE_LDS_BYTES;
   auto scan_step = [&]() __attribute__((always_inline)) {
@@ -913,32 +951,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     }
 #endif
     if (EE && live_cur) {
-      // Per sub-tile (32 references): K block 0 (2 MFMAs), the partial test, and only a block that passes it goes on: the other
-      // K blocks, the vote and -- if some value is below its row's threshold -- the slow path.  No block is left pending across
-      // tiles; both A fragments of K block 0 are requested before the first MFMA.
-      const f16x8* a8 = reinterpret_cast<const f16x8*>(tile_r) + jq;
-      const f16x8 aA = a8[h * K16_TS], aB = a8[32 + h * K16_TS];
-      const float tA0 = thrp[0] + ee_c[0], tA1 = thrp[1] + ee_c[1];
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = 0.0f;
-        accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[0][0], accA0, 0, 0, 0);
-        accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(sub ? aB : aA, bhi[1][0], accA1, 0, 0, 0);
-        if (__any(min16(accA0) < tA0 || min16(accA1) < tA1)) {
-          const f16x8* as = a8 + sub * 32;
-#pragma unroll
-          for (int kb = 1; kb < KB; ++kb) {
-            const f16x8 ahi = as[(kb * 2 + h) * K16_TS];
-            accA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[0][kb], accA0, 0, 0, 0);
-            accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], accA1, 0, 0, 0);
-          }
-          const float m0 = min16(accA0), m1 = min16(accA1);
-          if (__any(m0 < thrp[0] || m1 < thrp[1])) select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
-          ++st_go;
-        }
-      }
-      ++n_done;
+      ee_tile(tile_r, t);
     } else if (live_cur) {
 #ifdef K16_SETPRIO
       __builtin_amdgcn_s_setprio(K16_SETPRIO);
@@ -1038,7 +1051,51 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
     wr_b = free_b;
   };
   tm_mark = tm_now();
-  while (s_cur < n_scan) scan_step();
+  if constexpr (PAIR) {
+    // Two list entries per step: buffer (p & 1) holds the tiles of pair p, the copies of pair p + 1 go into the other one at the
+    // top of the step (every wave has passed the barrier behind the step that read it) and have the step to land; entries are
+    // read two pairs ahead (scalar loads).  A wave waits for ALL its copies at the end of a step (vmcnt(0): nothing to count).
+    constexpr unsigned PB = 2u * (unsigned)TILE_LDS_BYTES;
+    const int n_pairs = (n_scan + 1) >> 1;
+    unsigned c0 = list_entry(0), c1 = list_entry(1), x0 = list_entry(2), x1 = list_entry(3);
+    if (n_scan > 0) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(c0 & 0xFFFFFFu)), 0u);
+    if (n_scan > 1) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(c1 & 0xFFFFFFu)), (unsigned)TILE_LDS_BYTES);
+    K16_STAGED();
+    K16_TILE_BARRIER();
+    for (int p = 0; p < n_pairs; ++p) {
+      const unsigned buf = (p & 1) ? PB : 0u, other = PB - buf;
+      const unsigned f0 = list_entry(2 * p + 4), f1 = list_entry(2 * p + 5);
+      if (2 * p + 2 < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(x0 & 0xFFFFFFu)), other);
+      if (2 * p + 3 < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(x1 & 0xFFFFFFu)), other + (unsigned)TILE_LDS_BYTES);
+      const char* ring = reinterpret_cast<const char*>(lds_ring);
+      if (entry_live(c0)) ee_tile(reinterpret_cast<const _Float16*>(ring + buf), (int)(c0 & 0xFFFFFFu));
+      if (2 * p + 1 < n_scan && entry_live(c1)) ee_tile(reinterpret_cast<const _Float16*>(ring + buf + TILE_LDS_BYTES), (int)(c1 & 0xFFFFFFu));
+      if (batch_every > 0 && (p & (batch_every / 2 - 1)) == batch_every / 2 - 1) {  // (batched compaction: as in the single-tile loop)
+        const int limit = ksel + K16_COLD(batch_slack);
+        unsigned long long todo = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int cg = g ? cnt[1] : cnt[0];
+          const int tot = cg + __shfl_xor(cg, 32, 64);
+          todo |= (__ballot(tot > limit) & 0xffffffffull) << (32 * g);
+        }
+        while (todo) {
+          const int j = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          squeeze(j >> 5, j & 31);
+          if (ABL == 2) ++st_sq;
+        }
+      }
+      K16_STAGED();
+      K16_TILE_BARRIER();
+      c0 = x0;
+      c1 = x1;
+      x0 = f0;
+      x1 = f1;
+      ++it;
+    }
+  }
+  while (!PAIR && s_cur < n_scan) scan_step();
   if (pend) segment(nullptr, 0, accA0, accA1, accB0, accB1, refB, false, true);  // drain: sub-tile 1 of the last tile
   {
     unsigned long long* tiles_done = K16_COLD(tiles_done);
