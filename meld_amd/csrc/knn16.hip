@@ -67,6 +67,9 @@ constexpr int K16_DMAX = 16 * 9 - 3;  // largest d (KB = 9)
 // references in which no partial value is below its row's threshold (+ |q_B|^2: the most the other blocks can take away, m_r
 // covering the fp16 rounding of r_B: see prepare16_kernel).  It pays when the leading coordinates carry the distances (principal
 // coordinates: the host rotates the cells for the search, meld_amd/graph.py; any orthonormal frame is valid).
+#ifndef K16_EE_W4
+#define K16_EE_W4 1
+#endif
 #ifndef K16_EE_PAIRS
 #define K16_EE_PAIRS 1
 #endif
@@ -343,7 +346,8 @@ template <int KB, int ABL, int NPROD, bool LIST = false, bool EE = false>  // 16
                                       // EE (with LIST, NPROD = 1, KB >= 2, operands in the SPLIT layout): a block of 32 references is tested
                                       // on its accumulators behind K block 0 and dropped when no partial value is within reach of its row
 __global__ __launch_bounds__(K16_THREADS)
-__attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL, NPROD)))) void knn16_topk_kernel(const K16Args a) {
+__attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PAIRS && K16_EE_W4 && KB <= 4) ? 1 : 0),
+                                   k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PAIRS && K16_EE_W4 && KB <= 4) ? 1 : 0)))) void knn16_topk_kernel(const K16Args a) {
   // Arguments the scan loop needs stay in SGPRs; the cold ones (K16_COLD: compaction parameters, the outputs
   // of the epilogue, profiling) are re-read from the kernel-argument segment where they are used -- kept live
   // across the loop they pushed the kernel past its 102 SGPRs, the spills went to VGPR lanes and on to
@@ -379,7 +383,16 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
   constexpr int TILE_LDS_BYTES = LDS_TILE_H * 2;
   __shared__ float lds_sd[K16_NWAVE][K16_CAPMAX];
   __shared__ int lds_si[K16_NWAVE][K16_CAPMAX];
-  __shared__ unsigned long long lds_wlive[3][K16_NWAVE];  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch
+  // per-wave live-step masks of the pruning window: [0/1] by step parity, [2] window switch.  Table-driven kernels only: the
+  // list-driven ones never read them and let the name alias the ranking scratch -- their 96 bytes are what separates four
+  // workgroups of the two-tile pass from the CU's 160 KiB of LDS
+  unsigned long long (*lds_wlive)[K16_NWAVE];
+  if constexpr (!LIST) {
+    __shared__ unsigned long long lds_wlive_own[3][K16_NWAVE];
+    lds_wlive = lds_wlive_own;
+  } else {
+    lds_wlive = reinterpret_cast<unsigned long long (*)[K16_NWAVE]>(&lds_sd[0][0]);
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -433,7 +446,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD), k16_waves(KB, ABL,
 
   int cnt[2] = {0, 0};  // entries this lane has appended to its half of the rows of its two queries
   const int half = cap >> 1;
-  if (lane == 0) lds_wlive[0][wave] = lds_wlive[1][wave] = lds_wlive[2][wave] = ~0ull;
+  if (!LIST && lane == 0) lds_wlive[0][wave] = lds_wlive[1][wave] = lds_wlive[2][wave] = ~0ull;
   // thr_init (optional, scaled units): a bound the caller knows every wanted neighbour to lie below (the
   // re-search of rows whose first-pass list could not be certified knows one); it starts the thresholds
   // there instead of at +inf, so that only a handful of candidates per query ever take the slow path
