@@ -42,9 +42,13 @@ def test_search_kernels_do_not_spill():
     assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 5, sorted(product)
     for name, r in product.items():
         assert r["ScratchSize [bytes/lane]:"] == 0, (name, r)
-    # the benchmark configuration (d = 50: KB = 4, hi-only first pass) keeps three waves per SIMD, on both kernels
-    for first_pass in [v for k, v in product.items() if "ILi4ELi0ELi1E" in k]:
-        assert first_pass["Occupancy [waves/SIMD]:"] == 3 and first_pass["VGPRs:"] <= 168, first_pass
+    # the benchmark configuration (d = 50: KB = 4, hi-only first pass) keeps three waves per SIMD on the table- and list-driven kernels,
+    # four on the two-tile partial-test pass (whose LDS -- two buffers of two tiles + the ranking scratch -- is a quarter of a CU's)
+    for name, first_pass in [(k, v) for k, v in product.items() if "ILi4ELi0ELi1E" in k]:
+        if "ELb1ELb1E" in name:
+            assert first_pass["Occupancy [waves/SIMD]:"] == 4 and first_pass["VGPRs:"] <= 128, first_pass
+        else:
+            assert first_pass["Occupancy [waves/SIMD]:"] == 3 and first_pass["VGPRs:"] <= 168, first_pass
     bounds = [v for k, v in rows.items() if "knn16_tile_bounds_kernel" in k]
     assert bounds and all(v["ScratchSize [bytes/lane]:"] == 0 for v in bounds)
 
