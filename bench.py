@@ -415,6 +415,8 @@ def main():
             "frac": executed / t_knn / 1e12 / peak,
             "traffic": (measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch"),
             "traffic_replayed_from": replayed_from(measured_traffic("knn16_topk", N, d)),
+            # the replayed traffic over THIS run's kernel time: what the fabric side of the L2s delivers (a plain copy reaches ~6300 GB/s)
+            "traffic_rate_gb_s": ((measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch") or 0.0) / t_knn / 1e9 or None,
             "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
             "traffic_commit": (measured_traffic("knn16_topk", N, d) or {}).get("commit"),
