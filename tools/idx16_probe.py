@@ -1,5 +1,7 @@
 """Timing probe for a narrower index word in the recurrence stream: the step kernels of whatever libmeld_hip.so is in place on the
-1M (or N) benchmark graph, self-check bypassed (the timing-only variant -DPT_IDX16_TIMING computes garbage).
+1M (or N) benchmark graph, self-check bypassed.  Used in round 5 with a timing-only variant of csrc/spmm_tiled.hip (a local patch,
+-DPT_IDX16_TIMING: 16-bit index words with the real column and flush bits, a lane-held row; it computed garbage and was not kept --
+what it did and what it measured is in profiles/r05_idx16_probe.txt); on the product library it simply times the three step kernels.
 python tools/idx16_probe.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
