@@ -417,6 +417,9 @@ def main():
             "traffic_replayed_from": replayed_from(measured_traffic("knn16_topk", N, d)),
             # the replayed traffic over THIS run's kernel time: what the fabric side of the L2s delivers (a plain copy reaches ~6300 GB/s)
             "traffic_rate_gb_s": ((measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch") or 0.0) / t_knn / 1e9 or None,
+            "bound_note": "`frac` = flops issued to the matrix pipe / dense f16 peak (a utilisation).  With the partial test most blocks stop "
+            "after one of four K blocks, so the pipe is mostly idle by design; what the kernel runs into is the fabric: its tile stream "
+            "(`traffic`, replayed from the PMC pass) over this run's kernel time is `traffic_rate_gb_s`, against ~6300 GB/s of a plain copy",
             "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
             "traffic_commit": (measured_traffic("knn16_topk", N, d) or {}).get("commit"),
