@@ -449,6 +449,9 @@ class HipOps:
         # the search runs in the cells' principal frame where that concentrates the distances in the leading coordinates (the
         # list-driven first pass tests a block behind its first K block: principal_frame)
         self.rotate = os.environ.get("MELD_KNN_ROTATE", "1") != "0"
+        # ... from this many cells on: the frame costs ~0.9 ms whatever the size (a read-back and a 50 x 50 eigenproblem on the host
+        # among it) and pays from ~250k cells (200k: 10.0 vs 9.8 ms per step without it; 350k: 14.6 vs 15.4; 500k: 21.0 vs 22.5)
+        self.rotate_min_cells = int(os.environ.get("MELD_KNN_ROTATE_MIN", "262144"))
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
         self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
@@ -601,8 +604,8 @@ class HipOps:
             # use it -- operands in the split layout, seeds and step lists, the whole graph or a row shard of it -- else X itself.
             # Everything up to the candidate lists works on X_s; refinement and the exact sweeps on X.
             lead = int(lib.meld_knn16_split_dims(d))
-            if (self.rotate and lead > 0 and nprod == 1 and not cross and self.prune and self.step_lists and self.seed and N >= 16384
-                    and q_begin % BQ == 0 and bw_fixed is None):
+            if (self.rotate and lead > 0 and nprod == 1 and not cross and self.prune and self.step_lists and self.seed
+                    and N >= max(16384, self.rotate_min_cells) and q_begin % BQ == 0 and bw_fixed is None):
                 X_s = self.principal_frame(X, mean, lead, comm)
                 if X_s is not None:
                     sums_s, col_min, col_max = self.col_stats(X_s)

@@ -11,6 +11,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _frame_at_every_size(monkeypatch):
+    """The product takes the principal frame from 262144 cells on (below that its fixed cost outweighs the gain); the tests want it at
+    the sizes they can afford."""
+    monkeypatch.setenv("MELD_KNN_ROTATE_MIN", "0")
+
+
 def _cells(n, d, seed, kind="mixture"):
     rng = np.random.default_rng(seed)
     if kind == "mixture":  # a few latent dimensions embedded in d, small isotropic noise: the leading principal coordinates carry the distances

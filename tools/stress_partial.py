@@ -3,6 +3,7 @@ same bandwidths.  python tools/stress_partial.py [reps] [d,d,...]     (the regre
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ.setdefault("MELD_KNN_ROTATE_MIN", "0")  # (the product takes the frame from 262144 cells on)
 from meld_amd.graph import HipOps
 from meld_amd.reorder import locality_permutation
 
