@@ -163,6 +163,57 @@ def test_filter_stage_matches_the_cpu_oracle_at_full_size(full):
     assert np.abs(dens.values[perm] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
+def test_whole_path_against_the_oracle_digest(full):
+    """The WHOLE path against the WHOLE oracle at full size, in the driver-run tier: tests/golden/g8_fullsize.npz holds digests of
+    a full oracle run at these sizes (brute-force kNN on the GPU box's host cores, 50 s / 170 s; tools/make_fullsize_golden.py) --
+    sha-256 of the canonical sparsity pattern in the cells' input order, and for W's values, the degrees, the bandwidths and the
+    densities (the oracle's lmax injected): seeded +-1 projections, norms and 4096 sampled entries.  The build compared is the one
+    that carries the headline: at these sizes the search runs in the principal frame with the partial-distance test
+    (``knn16_topk_kernel<4, 0, 1, true, true>``).  Pattern bit-exact; weights / degrees 1e-9, bandwidths 1e-12, densities within
+    the north star's 1e-5 of the column maximum (measured ~1e-14) -- all with the COMMON injected lmax, as everywhere."""
+    import os
+
+    from scipy import sparse
+
+    from tools.make_fullsize_golden import digest_vector, sha
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_fullsize.npz")
+    g = np.load(path)
+    op, labels, n = full["op"], full["labels"], full["N"]
+    pre = "n%d_" % n
+    assert pre + "nnz" in g.files, "no oracle digest for {} cells in {}".format(n, path)
+    G = op.graph
+    assert G.info["principal_frame"] and G.info["step_lists"] and G.info["blocks_past_partial_test"] is not None
+    assert G.info["blocks_past_partial_test"] < 2 * G.info["wave_tiles_done"]
+    W = sparse.csr_matrix(G.W)
+    W.sort_indices()
+    assert W.nnz == int(g[pre + "nnz"])
+    assert sha(W.indptr.astype(np.int64)) == str(g[pre + "sha_indptr"])
+    assert sha(W.indices.astype(np.int32)) == str(g[pre + "sha_indices"])
+    lmax_native = G.lmax
+    try:
+        G.lmax = float(g[pre + "lmax"])
+        dens = op.transform(labels)
+    finally:
+        G.lmax = lmax_native
+    assert [str(c) for c in dens.columns] == [str(s) for s in g[pre + "samples"]]
+    vecs = {"wdata": (W.data, 1e-9), "dw": (np.ravel(G.dw), 1e-9), "bandwidth": (np.ravel(G.bandwidth_host), 1e-12)}
+    for c in range(dens.shape[1]):
+        vecs["dens%d" % c] = (np.ascontiguousarray(dens.values[:, c]), 1e-5)
+    for i, (name, (v, tol)) in enumerate(sorted(vecs.items())):
+        proj, nrm, pos, val = digest_vector(v, 1000 + i)
+        assert np.array_equal(pos, g[pre + name + "_pos"])
+        ref_val, ref_nrm = g[pre + name + "_val"], float(g[pre + name + "_norm"])
+        if name.startswith("dens"):  # (relative to the column maximum: the densities cross zero)
+            assert np.abs(val - ref_val).max() <= tol * np.abs(ref_val).max(), name
+            assert np.abs(val - ref_val).max() <= 1e-11 * np.abs(ref_val).max(), name  # what is actually reached
+        else:
+            np.testing.assert_allclose(val, ref_val, rtol=tol, atol=0, err_msg=name)
+        assert abs(nrm - ref_nrm) <= tol * ref_nrm, name
+        # a +-1 projection moves by at most sum |delta|: sqrt(n) * tol * norm bounds it for entrywise-relative agreement
+        assert np.abs(proj - g[pre + name + "_proj"]).max() <= tol * ref_nrm * np.sqrt(v.shape[0]), name
+
+
 def test_filterbank_vertex_frequency_cluster_at_one_million_cells():
     """BASELINE configs[4] on one GPU: the filter-bank VertexFrequencyCluster at the 1M-cell size (the reference's dense
     algorithm cannot run beyond ~2e4 cells).  Properties that do not depend on the size: finite non-negative spectrogram
