@@ -467,6 +467,7 @@ def main():
         # the data dependence of the search on the line: the same step with the exact tile pruning switched off (every
         # 64 x 64 block computed -- what iid data without cluster structure would cost), one untimed step
         os.environ["MELD_KNN_PRUNE"] = "0"
+        opu = None
         try:
             mgraph.record_events(True)
             opu = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)

@@ -96,10 +96,8 @@ int meld_knn16_tile_refs(void);          /* TS */
  * skip the other K blocks where no partial value is within reach of its row.  Results are the same in any orthonormal frame;
  * the test prunes when the leading coordinates carry the distances (the Python host rotates the cells to principal
  * coordinates for the search; PCA-reduced input, the reference's default, already is such a frame).  0: plain layout.
- * meld_knn16_debug_split(0 / 1) switches the layout of operands prepared afterwards (development; -1 only reads); returns
- * the previous setting.  Operands, spheres and searches must be made under one setting. */
+ * The layout is a function of d alone (no process-wide switch). */
 int meld_knn16_split_dims(int d);
-int meld_knn16_debug_split(int on);
 /* The cells' principal frame for that search (frame.hip; no reference counterpart -- graphtools searches the data as given):
  *   meld_cov_sample_f64:  cov[d*d] (row-major, upper triangle; zeroed by the caller) += the scatter matrix about mean[d] of
  *                         the rows 0, stride, 2 stride, ... of X[N][d]
@@ -256,6 +254,14 @@ int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void*
                                    double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt, float* cand_thr,
                                    uint64_t* tiles_done, const int32_t* block_order, int n_slices, int partial_test,
                                    meld_stream_t stream);
+/* The partial test as a pass of its own over the step lists (round 6; the default route in the principal frame): every listed
+ * (wave, tile) pair is tested on K block 0 alone against the row's START threshold (thr_init, scaled units: the seeds the lists
+ * were built for) and loses its bit when no partial distance is within reach; step_list is rewritten in place, emptied entries
+ * dropped, cnt_out[block] = the new length (may alias step_cnt), tested (optional) += pairs tested.  meld_knn16_topk_listed over
+ * the thinned lists returns the rows the search over the full ones would (no reference counterpart: graphtools searches a tree). */
+int meld_knn16_partial_filter(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, const float* norm2_max, int d,
+                              int64_t q_count, const float* thr_init, uint32_t* step_list, const int32_t* step_cnt, int64_t list_stride,
+                              int32_t* cnt_out, uint64_t* tested, const int32_t* block_order, meld_stream_t stream);
 /* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
  * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
  * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2

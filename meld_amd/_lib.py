@@ -38,7 +38,6 @@ SIGNATURES = {
     "meld_knn16_kblocks": (_i32, [_i32]),
     "meld_knn16_tile_refs": (_i32, []),
     "meld_knn16_split_dims": (_i32, [_i32]),
-    "meld_knn16_debug_split": (_i32, [_i32]),
     "meld_knn16_block_queries": (_i32, []),
     "meld_knn16_row_capacity": (_i32, [_i32]),
     "meld_knn16_error_coef": (_f64, [_i32, _i32]),
@@ -66,6 +65,7 @@ SIGNATURES = {
     "meld_knn16_step_lists_direct_lead": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _i32, _ptr]),
     "meld_knn16_topk_listed": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     "meld_knn16_topk_listed_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i32, _f64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "meld_knn16_partial_filter": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     "meld_knn16_seed_thresholds": (_i32, [_ptr, _i64, _i32, _ptr, _ptr, _ptr, _i64, _i64, _i32, _f64, _i32, _ptr, _ptr]),
     "meld_knn16_seed_thresholds_mfma": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i64, _i32, _f64, _i32, _i32, _ptr, _ptr]),
     "meld_knn16_max_slices": (_i32, [_i32]),

@@ -324,6 +324,7 @@ struct K16Args {
   long long list_stride;
   int ee_hi;  // EE kernels (SPLIT layout): physical K slots [16, ee_hi) hold the coordinates behind K block 0
   int planes_used;  // 64-vector planes (8 K slots each) of a reference tile that hold anything: the hi-only pass copies no others
+  int count_go;     // EE kernels: tiles_done has a second slot for the blocks that went on (meld_knn16_topk_listed_partial only)
 };
 #define K16_COLD(FIELD) \
   (((const volatile K16Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr())->FIELD)
@@ -1114,7 +1115,7 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
     unsigned long long* tiles_done = K16_COLD(tiles_done);
     if (tiles_done && lane == 0) {
       atomicAdd(tiles_done, (unsigned long long)n_done);
-      if (EE) atomicAdd(tiles_done + 1, (unsigned long long)st_go);  // (blocks of 32 references that went on past K block 0)
+      if (EE && K16_COLD(count_go)) atomicAdd(tiles_done + 1, (unsigned long long)st_go);  // (blocks of 32 references that went on past K block 0)
     }
   }
 
@@ -1165,6 +1166,141 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
 #undef K16_STAGED_BUT_LAST
 #undef K16_TILE_BARRIER
 #undef K16_ROUND_OK
+}
+
+// ---- the partial-distance test as a pass of its own (round 6) ------------------------------------------------------------
+// knn16_partial_filter_kernel: the step lists of the first pass, thinned by the distances themselves over the coordinates of K
+// block 0.  For every list entry (tile | waves that cannot rule the tile out << 24) of a query block, every listed wave
+// multiplies K block 0 of its 64 queries with K block 0 of the tile's 64 references (4 MFMAs) and keeps its bit only if some
+// partial value lies below its row's START threshold + |q_hiB|^2 (+ the rounding allowance): the rule of the EE search kernel
+// above, against thresholds that never rise during the search -- so a (wave, tile) pair dropped here could not have produced a
+// candidate, and the search over the thinned lists appends exactly what the search over the full ones would.  What it buys: in
+// the cells' principal frame 80 % of the pairs fall away, and the search stages whole tiles (7 KiB at d = 50) for the remaining
+// fifth only; this pass stages 2 KiB per tile (the two hi planes of K block 0), has no selection, no slow path and no
+// data-dependent control -- eight tiles per barrier.  (The one-kernel form -- test and go on inside the search kernel -- staged
+// all K blocks of every listed tile for the 18 % of the blocks that went on: 94 GB per launch at 1M cells, at the fabric's
+// copy rate.  Staging K block 0 only and letting a block that goes on fetch the rest by itself was built first: 16.7 and, with
+// the fetch deferred across the barrier, 19.5 ms against 14.9 -- the blocks that go on come in bursts, their fetch latency is
+// exposed to all four waves at the next barrier.)
+// Entries are rewritten IN PLACE (an entry is written at or in front of where it was read; no list position is read twice),
+// emptied entries dropped, cnt_out = the new length.  One workgroup per query block = the search kernel's four waves.
+template <int TPS>  // tiles per step (and barrier)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn16_partial_filter_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
+                                                                   const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
+                                                                   const float* __restrict__ norm2_max, const float* __restrict__ thr_init,
+                                                                   unsigned* step_list, const int* __restrict__ step_cnt, long long list_stride,
+                                                                   int* __restrict__ cnt_out, unsigned long long* __restrict__ tested,
+                                                                   const int* __restrict__ block_order, int KB, int ee_hi) {
+  static_assert(TPS >= 2 && TPS <= 32 && (TPS & 1) == 0, "tiles per step");
+  __shared__ __attribute__((aligned(16))) _Float16 ring[2][TPS][2 * K16_TS * 8];  // K block 0, hi planes: [k-half][ref][8 halves]
+  __shared__ unsigned wmask[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jq = lane & 31, h = lane >> 5;
+  const int bx = block_order ? __builtin_amdgcn_readfirstlane(block_order[blockIdx.x]) : (int)blockIdx.x;
+  const int q_base = bx * K16_BQ + wave * 64;
+  // K block 0 of both query groups, and the most the other K blocks can take away from an accumulator (as in the EE kernel)
+  f16x8 b0[2];
+  float tA[2];
+  {
+    const float s_ = scale_info[0];
+    const float delta = 3.814697265625e-06f * (norm2_max[0] * s_ * s_) + 1e-30f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int q = q_base + g * 32 + jq;
+      const f16x8* qrow = reinterpret_cast<const f16x8*>(Q16 + (size_t)q * (size_t)(KB * 32));
+      b0[g] = qrow[h * 2];
+      float qb = 0.0f;
+      for (int kb = 1; kb < KB; ++kb) {
+        const f16x8 v8 = qrow[(kb * 2 + h) * 2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (16 * kb + 8 * h + e < ee_hi) ? (float)v8[e] : 0.0f;
+          qb = fmaf(v, v, qb);
+        }
+      }
+      qb += __shfl_xor(qb, 32, 64);
+      tA[g] = (thr_init[q] - Qn[q]) + (qb * 1.0001f + delta);
+    }
+  }
+  typedef const __attribute__((address_space(4))) unsigned* list_ptr_t;
+  unsigned* const my_list_w = step_list + (size_t)bx * (size_t)list_stride;
+  const list_ptr_t my_list = (list_ptr_t)(uintptr_t)my_list_w;
+  const int n = __builtin_amdgcn_readfirstlane(step_cnt[bx]);
+  const int n_steps = (n + TPS - 1) / TPS;
+  const size_t tile_bytes = (size_t)KB * 4096;  // KB x [k-half][plane][ref][8 halves]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned ring_base = (unsigned)(size_t)(lds_ptr_t)&ring[0][0][0];
+  const int lane16 = lane * 16;
+  // staging: 2 TPS pieces of 1 KiB per step, TPS / 2 per wave: piece k = plane (k & 1) of the step's tile (k >> 1)
+  auto stage = [&](int step, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < TPS / 2; ++u) {
+      const int k = wave * (TPS / 2) + u;
+      const int idx = step * TPS + (k >> 1);
+      if (idx < n) {
+        const size_t src = reinterpret_cast<size_t>(Rt16) + (size_t)(my_list[idx] & 0xFFFFFFu) * tile_bytes;
+        const i32x4 rsrc = {(int)(unsigned)src, (int)((src >> 32) & 0xffffu), 4096, 0x00020000};
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(
+                         (int)(ring_base + (unsigned)((buf * TPS + (k >> 1)) * 2048 + (k & 1) * 1024)))),
+                     "v"(lane16), "s"(rsrc), "s"((k & 1) * 2048)
+                     : "memory");
+      }
+    }
+  };
+  int out_n = 0;  // (wave 0: entries written so far)
+  unsigned long long n_tested = 0;
+  // the masks of step s_ -> the list, by wave 0 at the top of the next step (lane j: entry j of the step)
+  auto emit = [&](int s_) __attribute__((always_inline)) {
+    const int idx = s_ * TPS + lane;
+    const bool have = lane < TPS && idx < n;
+    const unsigned e = have ? my_list_w[idx] : 0u;
+    unsigned nm = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) nm |= ((wmask[s_ & 1][w] >> lane) & 1u) << w;
+    nm &= (e >> 24);
+    const bool keep = have && nm != 0u;
+    const unsigned long long b = __ballot(keep);
+    if (keep) my_list_w[out_n + __popcll(b & ((1ull << lane) - 1ull))] = (e & 0xFFFFFFu) | (nm << 24);
+    out_n += __popcll(b);
+  };
+  if (n_steps > 0) stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < n_steps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
+    if (wave == 0 && s > 0) emit(s - 1);
+    unsigned mybits = 0u;
+#pragma unroll
+    for (int j = 0; j < TPS; ++j) {
+      const int idx = s * TPS + j;
+      const unsigned e = idx < n ? my_list[idx] : 0u;
+      if ((e >> (24 + wave)) & 1u) {
+        const f16x8* a8 = reinterpret_cast<const f16x8*>(&ring[buf][j][0]) + jq;
+        const f16x8 aA = a8[h * K16_TS], aB = a8[h * K16_TS + 32];
+        f32x16 c00, c01, c10, c11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.0f;
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aA, b0[0], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aA, b0[1], c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aB, b0[0], c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aB, b0[1], c11, 0, 0, 0);
+        const bool hit = __builtin_fminf(min16(c00), min16(c10)) < tA[0] || __builtin_fminf(min16(c01), min16(c11)) < tA[1];
+        if (__any(hit)) mybits |= 1u << j;
+        ++n_tested;
+      }
+    }
+    if (lane == 0) wmask[buf][wave] = mybits;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (this wave's copies of the next step have landed)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (wave == 0) {
+    if (n_steps > 0) emit(n_steps - 1);
+    if (lane == 0) cnt_out[bx] = out_n;
+  }
+  if (tested && lane == 0) atomicAdd(tested, n_tested);
 }
 
 // Final form of the candidate rows: one wave per row sorts its entries by (value, index) with a bitonic network on
@@ -2025,15 +2161,13 @@ __global__ __launch_bounds__(64 * SEED_WAVES) void knn16_seed_mfma_kernel(const 
 
 using namespace meld;
 
-// SPLIT operand layout (k16_slot): on by default wherever it fits; meld_knn16_debug_split(0) restores the plain layout for
-// every operand prepared afterwards (development / A-B measurements: operands and searches must be made under one setting).
-static int g_k16_split = 1;
-static int k16_dA(int d, int KB) { return k16_split_dims_of(d, KB, g_k16_split); }
-extern "C" int meld_knn16_debug_split(int on) {
-  const int was = g_k16_split;
-  if (on >= 0) g_k16_split = on ? 1 : 0;
-  return was;
-}
+// SPLIT operand layout (k16_slot): wherever it fits.  A function of d alone: no process-wide switch (the boundary's contract is
+// "no global state"); the plain layout for A-B measurements is a compile-time choice of a development build (-DK16_PLAIN_LAYOUT).
+#ifdef K16_PLAIN_LAYOUT
+static int k16_dA(int, int) { return 0; }
+#else
+static int k16_dA(int d, int KB) { return k16_split_dims_of(d, KB, 1); }
+#endif
 extern "C" int meld_knn16_kblocks(int d);
 // coordinates K block 0 holds under the SPLIT layout (the list-driven first pass tests its accumulators behind that block: the
 // caller does well to hand the cells over in a frame whose leading coordinates carry the distances); 0: plain layout
@@ -2788,7 +2922,7 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
                          const float* norm2_max, int64_t q_begin, const float* thr_init, int knn,
                          double radius_factor, int32_t* cand_idx, float* cand_d2, int32_t* cand_cnt,
                          float* cand_thr, uint64_t* tiles_done, const int32_t* block_order, const uint32_t* step_list,
-                         const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream, int partial_test = 0) {
+                         const int32_t* step_cnt, int64_t list_stride, meld_stream_t stream, int partial_test = 0, int two_counters = 0) {
   MELD_CHECK_ARG(nprod == 1 || nprod == 3, "meld_knn16_topk: nprod must be 1 or 3");
   MELD_CHECK_ARG(step_list == nullptr || (step_cnt != nullptr && nprod == 1 && lb2 == nullptr && thr_init != nullptr),
                  "meld_knn16_topk_listed: step lists go with the hi-only pass, start thresholds and no table");
@@ -2882,6 +3016,7 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   const char* ee_env = getenv("MELD_KNN16_EE");
   const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
   ka.ee_hi = 16 + d - dA;
+  ka.count_go = two_counters;  // (a caller of meld_knn16_topk_listed passes ONE counter, whatever MELD_KNN16_EE forces)
   {
     const int slots_used = dA > 0 ? 16 + (d - dA) + 3 : d + 3;
     const char* sk = getenv("MELD_KNN16_SKIP_PAD");  // (=0: copy the padding plane as before, for A-B measurements)
@@ -3040,7 +3175,30 @@ extern "C" int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, 
   MELD_CHECK_ARG(step_list && step_cnt && list_stride > 0, "meld_knn16_topk_listed_partial: null step lists");
   return k16_topk_impl(Q16, Qn, Rt16, scale_info, n_ref, d, q_count, ksel, 1, n_slices, nullptr, norm2_max, q_begin, thr_init, knn,
                        radius_factor, cand_idx, cand_d2, cand_cnt, cand_thr, tiles_done, block_order, step_list, step_cnt, list_stride,
-                       stream, partial_test);
+                       stream, partial_test, 1);
+}
+
+// The partial-distance test as a pass over the step lists (knn16_partial_filter_kernel): lists built for operands in the SPLIT
+// layout (meld_knn16_split_dims(d) > 0), cells in a frame whose leading coordinates carry the distances.  step_list is rewritten
+// in place (entries of waves that fail the test cleared, empty entries dropped), cnt_out[block] = the new length (may alias
+// step_cnt), tested (optional) += the (wave, tile) pairs tested.  The search over the thinned lists (meld_knn16_topk_listed)
+// returns the rows the search over the full ones would.  thr_init: the start thresholds the lists were built for (scaled units).
+extern "C" int meld_knn16_partial_filter(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, const float* norm2_max,
+                                         int d, int64_t q_count, const float* thr_init, uint32_t* step_list, const int32_t* step_cnt,
+                                         int64_t list_stride, int32_t* cnt_out, uint64_t* tested, const int32_t* block_order,
+                                         meld_stream_t stream) {
+  MELD_CHECK_ARG(Q16 && Qn && Rt16 && scale_info && norm2_max && thr_init && step_list && step_cnt && cnt_out && list_stride > 0 && q_count > 0,
+                 "meld_knn16_partial_filter: null pointer or bad sizes");
+  const int KB = meld_knn16_kblocks(d);
+  if (KB < 0) return KB;
+  const int dA = k16_dA(d, KB);
+  MELD_CHECK_ARG(dA > 0 && KB >= 2, "meld_knn16_partial_filter: d = %d has no split operand layout", d);
+  const unsigned n_blocks = (unsigned)ceil_div(q_count, K16_BQ);
+  hipLaunchKernelGGL((knn16_partial_filter_kernel<8>), dim3(n_blocks), dim3(256), 0, S(stream), reinterpret_cast<const _Float16*>(Q16), Qn,
+                     reinterpret_cast<const _Float16*>(Rt16), scale_info, norm2_max, thr_init, step_list, step_cnt, (long long)list_stride, cnt_out,
+                     reinterpret_cast<unsigned long long*>(tested), block_order, KB, 16 + d - dA);
+  MELD_LAUNCH_CHECK("knn16_partial_filter_kernel");
+  return MELD_OK;
 }
 
 // Workgroups of the search kernel that are resident on the device at once (occupancy x CUs): the

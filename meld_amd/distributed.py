@@ -43,16 +43,20 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    _RCCL = {}  # process group -> the library's RCCL communicator on it (created once: ncclCommInitRank is a collective)
-
     def rccl(self):
         """Handle of the library's own RCCL communicator over this group (``meld_rccl_comm_create``), for the C-side recurrence
         loops (``meld_cheby_run_sharded`` / ``meld_lanczos_steps_sharded``: kernel and collective of every step enqueued from
         one call), or None when the group does not run on RCCL (gloo, the host-staged test collectives) or the loops are
-        switched off (``MELD_SHARDED_C_LOOPS=0``).  The unique id travels through torch.distributed."""
-        key = id(self.group) if self.group is not None else 0
-        if key in Comm._RCCL:
-            return Comm._RCCL[key]
+        switched off (``MELD_SHARDED_C_LOOPS=0``).  The unique id travels through torch.distributed.  Created once per process
+        group (ncclCommInitRank is a collective); the cache entry holds the group OBJECT, so a group torn down and re-created --
+        or another one at a recycled ``id()`` -- never sees a stale handle."""
+        try:
+            pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+        except Exception:
+            pg = self.group
+        hit = Comm._RCCL.get(id(pg))
+        if hit is not None and hit[0] is pg:
+            return hit[1]
         handle = None
         try:
             eligible = dist.get_backend(self.group) == "nccl" and torch.cuda.is_available() and os.environ.get("MELD_SHARDED_C_LOOPS", "1") != "0"
@@ -73,25 +77,36 @@ class Comm:
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 dist.broadcast_object_list(box, src=src, group=self.group)
                 h = C.c_void_p()
-                ok = 0
+
+                def agreed(ok):  # every rank takes the same path: MIN over the group, through torch.distributed
+                    flag = torch.tensor([int(ok)], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                    return int(flag.item()) == 1
+
                 try:
                     check(lib.meld_rccl_comm_create(box[0], self.world, self.rank, C.byref(h)), "meld_rccl_comm_create")
-                    # one all-reduce and one in-place all-gather through the new communicator before it is trusted with the filter
-                    st = torch.cuda.current_stream().cuda_stream
-                    probe = torch.ones(4, dtype=torch.float64, device="cuda")
-                    check(lib.meld_rccl_all_reduce_sum_f64(h, C.c_void_p(probe.data_ptr()), 4, st), "meld_rccl_all_reduce_sum_f64")
-                    full = torch.full((self.world, 2), -1.0, dtype=torch.float64, device="cuda")
-                    full[self.rank] = float(self.rank)
-                    mine = full[self.rank]
-                    check(lib.meld_rccl_all_gather(h, C.c_void_p(mine.data_ptr()), C.c_void_p(full.data_ptr()), 16, st), "meld_rccl_all_gather")
-                    want = torch.arange(self.world, dtype=torch.float64, device="cuda")[:, None].expand(-1, 2)
-                    ok = int(bool((probe == float(self.world)).all()) and bool((full == want).all()))
+                    created = True
                 except Exception:
-                    ok = 0
-                # every rank takes the same path: the C loops only if the communicator works on ALL of them
-                agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.group)
-                if int(agree.item()) == 1:
+                    created = False
+                # agreement on the creation BEFORE any collective is issued on the new communicator: a rank whose create failed
+                # would leave the others waiting inside the probe below
+                ok = agreed(created)
+                if ok:
+                    try:
+                        # one all-reduce and one in-place all-gather through the new communicator before it is trusted with the filter
+                        st = torch.cuda.current_stream().cuda_stream
+                        probe = torch.ones(4, dtype=torch.float64, device="cuda")
+                        check(lib.meld_rccl_all_reduce_sum_f64(h, C.c_void_p(probe.data_ptr()), 4, st), "meld_rccl_all_reduce_sum_f64")
+                        full = torch.full((self.world, 2), -1.0, dtype=torch.float64, device="cuda")
+                        full[self.rank] = float(self.rank)
+                        mine = full[self.rank]
+                        check(lib.meld_rccl_all_gather(h, C.c_void_p(mine.data_ptr()), C.c_void_p(full.data_ptr()), 16, st), "meld_rccl_all_gather")
+                        want = torch.arange(self.world, dtype=torch.float64, device="cuda")[:, None].expand(-1, 2)
+                        good = bool((probe == float(self.world)).all()) and bool((full == want).all())
+                    except Exception:
+                        good = False
+                    ok = agreed(good)
+                if ok:
                     handle = h
                 else:
                     if h.value:
@@ -100,8 +115,20 @@ class Comm:
 
                     warnings.warn("meld_amd: the library's own RCCL communicator failed its self-check; the sharded recurrences run their "
                                   "per-step loops over torch.distributed", RuntimeWarning)
-        Comm._RCCL[key] = handle
+        Comm._RCCL[id(pg)] = (pg, handle)  # (the strong reference keeps the id from being recycled while the entry lives)
         return handle
+
+    _RCCL = {}  # id(process group) -> (the group object, the library's RCCL communicator on it or None)
+
+    @classmethod
+    def release_rccl(cls):
+        """Destroy the cached communicators (call before ``dist.destroy_process_group()`` in a long-lived process)."""
+        from ._lib import get_lib
+
+        for _, h in cls._RCCL.values():
+            if h is not None and h.value:
+                get_lib().meld_rccl_comm_destroy(h)
+        cls._RCCL.clear()
 
     def all_gather_rows(self, full, local):
         """full[rank*R:(rank+1)*R] <- local, for every rank (in place when local is that slice)."""

@@ -308,8 +308,6 @@ class DeviceGraph:
     @property
     def bandwidth_host(self):
         """bandwidths in the units of the graph's metric (``bandwidth`` itself is the euclidean one of the rows the search saw)"""
-        if self.bandwidth is None:
-            return None
         if getattr(self, "bandwidth", None) is None:  # (a precomputed affinity has none)
             return None
         to_metric = getattr(self, "bandwidth_to_metric", None)
@@ -473,15 +471,20 @@ class HipOps:
         """The cells in their principal frame, ``(X - mean) V`` with the eigenvectors of the covariance (of at most 32768 evenly
         spaced rows, ``meld_cov_sample_f64``) in descending order of variance (``meld_rotate_rows_f64``) -- or None when the
         ``lead`` leading coordinates would carry less than half of the variance (the search's partial test would seldom drop a
-        block; any frame is valid, the graph is the same) or d is beyond the kernels' width.  Distances are those of ``X`` to
+        block; any frame is valid, the graph is the same).  Distances are those of ``X`` to
         rounding (V is orthonormal to 1e-15): the search only nominates candidates, their distances are evaluated in fp64 on
         ``X`` itself.  The d x d eigenproblem is solved on the host (one read-back of d x d numbers)."""
         lib, st = self.lib, _stream()
         N, d = int(X.shape[0]), int(X.shape[1])
-        if d > int(lib.meld_frame_max_dims()):
-            return None
-        cov = torch.zeros(d, d, dtype=torch.float64, device=X.device)
-        check(lib.meld_cov_sample_f64(ptr(X), N, d, ptr(mean), max(1, N // 32768), ptr(cov), st), "meld_cov_sample_f64")
+        wide = d > int(lib.meld_frame_max_dims())  # (beyond the frame kernels' row width: the same two products through the library)
+        stride = max(1, N // 32768)
+        if wide:
+            Xs = X[::stride] - mean
+            cov = torch.triu(Xs.T @ Xs)
+            del Xs
+        else:
+            cov = torch.zeros(d, d, dtype=torch.float64, device=X.device)
+            check(lib.meld_cov_sample_f64(ptr(X), N, d, ptr(mean), stride, ptr(cov), st), "meld_cov_sample_f64")
         if comm is not None and getattr(comm, "world", 1) > 1:
             # ranks of a row-sharded build hold the same cells but sum their scatter matrices in different orders (atomics): all
             # take rank 0's bits, so that the frame -- and the decision to use one -- is the same everywhere (the tile spheres
@@ -493,6 +496,11 @@ class HipOps:
         tot = float(evals.sum())
         if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
             return None
+        if wide:
+            # d in (64, 141]: a plain N x d x d fp64 GEMM (rocBLAS) -- PCA scores, the reference's default input (n_pca = 100), are
+            # already in their principal frame up to this rotation's rounding, so it is close to a permutation there
+            V = torch.from_numpy(np.ascontiguousarray(evecs[:, ::-1])).to(X.device)
+            return torch.addmm(-(mean @ V), X, V)
         At = np.zeros((d, int(lib.meld_frame_max_dims())))
         At[:, :d] = evecs[:, ::-1].T  # the axes as rows, by descending variance
         At = torch.from_numpy(At).to(X.device)
@@ -502,7 +510,7 @@ class HipOps:
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
-                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None, symm=(0, 0.0)):
+                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None, symm=(0, 0.0), count_rows_ge=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -515,7 +523,9 @@ class HipOps:
         ``meld/meld.py:106,117-118``): the kernel uses ``max(bw * bw_scale, eps)``; ``bw_fixed`` (fp64 device tensor [N], in
         the order of ``X``) replaces the adaptive k-th-neighbour bandwidth -- the kernel radius of every row is then known
         before the search, which starts its thresholds there and cuts nothing on its own.  ``knn_max`` ([UPSTREAM kNNGraph
-        ``knn_max``]): a row keeps its knn_max nearest cells (besides itself) at most."""
+        ``knn_max``]): a row keeps its knn_max nearest cells (besides itself) at most.  ``count_rows_ge``: report the number of rows
+        whose kernel radius holds at least that many cells, self counted (``info["rows_with_at_least"]``: what graphtools'
+        re-search loop branches on, see ``build_knn_graph``)."""
         lib, st, dev = self.lib, _stream(), X.device
         tm = tm or _Timer(False)
         N, d = int(X.shape[0]), int(X.shape[1])
@@ -539,7 +549,7 @@ class HipOps:
         X_search, mean_search = X, mean  # (the f16x3 search may move to the cells' principal frame)
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
-        used_prune = used_seed = used_seeded_bounds = used_block_order = used_step_lists = False
+        used_prune = used_seed = used_seeded_bounds = used_block_order = used_step_lists = used_two_phase = False
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if cross and search != "f16x3":
@@ -738,6 +748,22 @@ class HipOps:
                     main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
                 elif resident > 0 and n_blocks < 2 * resident:
                     main_slices = int(max(1, min(4, lib.meld_knn16_max_slices(ksel), -(-2 * resident // n_blocks), n_tiles // 64)))  # (more slices cost more in merging than they balance)
+            # The partial-distance test of the principal frame as a pass of its own (meld_knn16_partial_filter): every listed (wave,
+            # tile) pair is tested on K block 0 against the row's start threshold; the search then stages whole tiles for the fifth
+            # of the pairs that survive and needs no test of its own.  MELD_KNN_TWO_PHASE=0: the round-5 form, test and search in
+            # one kernel (every listed tile staged in full).
+            two_phase = (step_list is not None and X_search is not X and seeds is not None
+                         and os.environ.get("MELD_KNN_TWO_PHASE", "1") != "0" and os.environ.get("MELD_KNN16_EE") is None)
+            partial_in_search = int(X_search is not X and not two_phase)
+            tiles_b = tiles_done
+            if two_phase:
+                with _EventSpan("knn_filter", N=N, d=d, q=q_count):
+                    check(lib.meld_knn16_partial_filter(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), d, q_count, ptr(seeds), ptr(step_list),
+                                                        ptr(step_cnt), n_tiles, ptr(step_cnt), ptr(tiles_done), ptr(block_order), st), "meld_knn16_partial_filter")
+                    if block_order is not None:  # (longest blocks first, by what is left of them)
+                        block_order = torch.argsort(step_cnt, descending=True, stable=True).to(torch.int32)
+                tiles_b = tiles_done[1:]  # (the search counts the pairs it computes behind the filter's)
+                tm.stop("knn_filter")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 if main_slices > 1:
                     s_idx = torch.empty(main_slices * q_pad * cap, dtype=torch.int32, device=dev)
@@ -745,14 +771,14 @@ class HipOps:
                     s_cnt = torch.empty(main_slices * q_pad, dtype=torch.int32, device=dev)
                     s_thr = torch.full((main_slices, q_pad), float("inf"), dtype=torch.float32, device=dev)
                     if step_list is not None:
-                        check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), main_slices, int(X_search is not X), st), "meld_knn16_topk_listed(sliced)")
+                        check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_b), ptr(block_order), main_slices, partial_in_search, st), "meld_knn16_topk_listed(sliced)")
                     else:
                         check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, main_slices, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(s_idx), ptr(s_d2), ptr(s_cnt), ptr(s_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk(sliced)")
                     check(lib.meld_knn16_merge_slices(ptr(s_idx), ptr(s_d2), ptr(s_cnt), q_count, ksel, main_slices, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), st), "meld_knn16_merge_slices")
                     cand_thr.copy_(s_thr.amin(0))  # the merged row holds every reference below the smallest slice threshold
                     del s_idx, s_d2, s_cnt, s_thr
                 elif step_list is not None:
-                    check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), 1, int(X_search is not X), st), "meld_knn16_topk_listed")
+                    check(lib.meld_knn16_topk_listed_partial(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, ptr(step_list), ptr(step_cnt), n_tiles, ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_b), ptr(block_order), 1, partial_in_search, st), "meld_knn16_topk_listed")
                 else:
                     check(lib.meld_knn16_topk(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), NR, d, q_count, ksel, nprod, 1, ptr(lb2), ptr(nmax), 0 if cross else q_begin, ptr(seeds), knn_cut, rfac, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ptr(tiles_done), ptr(block_order), st), "meld_knn16_topk")
                 # the search is the one long launch of the build (26 of 45 ms at 1M cells) and the host has nothing to do
@@ -764,6 +790,7 @@ class HipOps:
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             used_block_order = block_order is not None
             used_step_lists = step_list is not None
+            used_two_phase = bool(two_phase)
             del lb2, step_list, step_cnt
             KP = 16 * KB
             research = dict(Rt=Rt, scale_info=scale_info, KB=KB, BQ=BQ) if nprod == 1 else None
@@ -879,6 +906,8 @@ class HipOps:
         m_main = int(heads_h[1])
         tiles_done_h = int(heads_h[2]) if tiles_done is not None else None
         blocks_on_h = int(heads_h[3]) if tiles_done is not None and X_search is not X else None
+        if blocks_on_h is not None and used_two_phase:
+            blocks_on_h *= 2  # (the search behind the filter counts (wave, tile) pairs: two blocks of 32 references each)
 
         # Many uncertified rows with a short candidate list (dense low-dimensional data: more than ksel cells
         # inside the radius inflated by the search-error allowance): search once more with the longest list
@@ -889,7 +918,8 @@ class HipOps:
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
-                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
+                                           assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm,
+                                           count_rows_ge=count_rows_ge)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -966,6 +996,13 @@ class HipOps:
                 fb_off = _scan_i32(lib, fb_cnt, st)
                 fb_total = int(fb_off[n_flag_h].item())
         tm.stop("radius_exact")
+        rows_at_least = None
+        if count_rows_ge is not None:
+            tot = keep_cnt.to(torch.int64)
+            if n_flag_h > 0 and fb_total > 0:
+                tot = tot.clone()
+                tot[flag_rows[:n_flag_h].to(torch.int64)] = fb_cnt.to(torch.int64)
+            rows_at_least = int(((tot + 1) >= int(count_rows_ge)).sum())  # (+ 1: the cell itself, K_ii = 1 is carried analytically)
 
         M = m_main + fb_total
         assembled = None
@@ -1005,11 +1042,13 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), principal_frame=bool(X_search is not X), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), principal_frame=bool(X_search is not X), two_phase=bool(used_two_phase), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
                     wave_tiles_done=tiles_done_h, blocks_past_partial_test=blocks_on_h)
+        if rows_at_least is not None:
+            info["rows_with_at_least"] = rows_at_least
         if assembled is not None:
             info["assembled"] = assembled  # (rowptr, col, val) of the symmetrised rows: the caller skips assemble_rows
         return keys, vals, bw, info
@@ -1089,8 +1128,6 @@ class HipOps:
             if done is not None:
                 return done
             del cursor, tcol, tval
-        if symm[0] != 0:  # (the sort path sums the two directions: graphtools' default only)
-            raise NotImplementedError("kernel_symm other than '+' is implemented on the row-bucket symmetrisation only")
         self.last_assemble = "sort" if n > 0 else "empty"
         if foreign and n > 0:
             rows = keys >> 32  # (the sentinel ~0 is -1 as int64: its row is negative)
@@ -1098,13 +1135,35 @@ class HipOps:
             keys, vals = keys[own].contiguous(), vals[own].contiguous()
             n = int(keys.shape[0])
         keys2, vals2 = self.sort_pairs(keys, vals, N)
-        tb = lib.meld_merge_temp_bytes(max(n, 1))
-        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
-        n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
-        ukeys = torch.empty_like(keys2)
-        uvals = torch.empty_like(vals2)
-        check(lib.meld_coo_merge(ptr(keys2), ptr(vals2), n, ptr(ukeys), ptr(uvals), ptr(n_unique), ptr(tmp), tb, st), "meld_coo_merge")
-        nnz = int(n_unique.item())
+        if symm[0] != 0 and n > 0:
+            # kernel_symm "*" / "mnn" behind the global sort (overfull row buckets -- hub cells --, MELD_ASSEMBLE=sort): the two HALVES
+            # of a key sit side by side; the rules of meld_csr_rows_sort_merge (csrc/assemble.hip) on them, as library segment
+            # reductions -- a rare path.  Symmetric functions of the pair: (i, j) and (j, i) get the same bits.
+            first = torch.ones(n, dtype=torch.bool, device=dev)
+            first[1:] = keys2[1:] != keys2[:-1]
+            seg = torch.cumsum(first, 0) - 1
+            nseg = int(seg[-1].item()) + 1
+            cnt = torch.bincount(seg, minlength=nseg)
+            if int(cnt.max().item()) > 2:
+                raise NotImplementedError("kernel_symm other than '+': an entry of the kernel occurs more than once per direction")
+            hi = torch.zeros(nseg, dtype=torch.float64, device=dev).scatter_reduce_(0, seg, vals2, "amax", include_self=False)
+            lo = torch.zeros(nseg, dtype=torch.float64, device=dev).scatter_reduce_(0, seg, vals2, "amin", include_self=False)
+            lo = torch.where(cnt == 2, lo, torch.zeros_like(lo))  # (the missing direction counts as 0)
+            if symm[0] == 1:
+                v, keep = 4.0 * hi * lo, cnt == 2
+            else:
+                v = 2.0 * (float(symm[1]) * lo + (1.0 - float(symm[1])) * hi)
+                keep = v != 0.0
+            ukeys, uvals = keys2[first][keep].contiguous(), v[keep].contiguous()
+            nnz = int(ukeys.shape[0])
+        else:
+            tb = lib.meld_merge_temp_bytes(max(n, 1))
+            tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+            n_unique = torch.zeros(1, dtype=torch.int64, device=dev)
+            ukeys = torch.empty_like(keys2)
+            uvals = torch.empty_like(vals2)
+            check(lib.meld_coo_merge(ptr(keys2), ptr(vals2), n, ptr(ukeys), ptr(uvals), ptr(n_unique), ptr(tmp), tb, st), "meld_coo_merge")
+            nnz = int(n_unique.item())
         rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
         col = torch.empty(nnz, dtype=torch.int32, device=dev)
         check(lib.meld_csr_from_keys(ptr(ukeys), nnz, row_begin, n_rows, ptr(rowptr), ptr(col), st), "meld_csr_from_keys")
@@ -1541,8 +1600,26 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
                 bw_fixed = bw_fixed.index_select(0, perm).contiguous()
         tm.stop("reorder")
 
-    keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                                   bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
+    # [UPSTREAM graphtools build_kernel_to_data] caps a row at knn_max + 1 cells only where its re-search ends at
+    # ``search_knn == knn_max``; the search sizes go (knn + 1) x 6, x 36, then knn_max + 1 (x 216 always exceeds the 127 this builder
+    # accepts), and a row that leaves the re-search earlier holds everything inside its radius anyway.  So the result IS the hard cap
+    # -- except where 36 (knn + 1) < knn_max + 1 (knn <= 2 here) and the loop never runs because no more than N // 10 rows have
+    # 6 (knn + 1) cells inside their radius (or 36 (knn + 1) >= N / 2): upstream then finishes those rows with an UNCAPPED radius
+    # search, and the graph is the one without knn_max.  That is decided by a count over the uncapped rows, so this corner builds
+    # the uncapped kernel first.
+    k1 = knn + 1
+    info = None
+    if knn_max is not None and decay is not None and math.isfinite(decay) and 36 * k1 < min(knn_max + 1, N):
+        trial = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
+                                        bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=None, symm=symm, count_rows_ge=6 * k1)
+        if trial[3]["rows_with_at_least"] <= N // 10 or 36 * k1 >= N / 2:
+            keys, vals, bw, info = trial
+            info["knn_max_uncapped_as_upstream"] = True
+            knn_max = None
+        del trial
+    if info is None:
+        keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
+                                                       bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
     if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
         bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:
@@ -1554,9 +1631,7 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         rowptr, col, val = asm[:3]
         ksum = asm[3] if len(asm) > 3 else None  # (the row sums came out of the buckets with the rows)
     else:
-        if symm[0] != 0:  # (the sort-based path -- overfull row buckets, MELD_ASSEMBLE=sort -- sums the two directions only)
-            raise NotImplementedError("kernel_symm={!r} is implemented on the row-bucket symmetrisation only".format(kernel_symm))
-        rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N)
+        rowptr, col, val = ops.assemble_rows(keys, vals, 0, N, N, symm=symm)
     del keys, vals
     tm.stop("symmetrize")
     if ksum is None:

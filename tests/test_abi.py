@@ -57,7 +57,7 @@ def test_product_never_imports_the_oracle():
 
 def test_split_layout_geometry_is_a_function_of_the_dimension():
     """No compute, no GPU: which dimensions get the split operand layout (13 coordinates and their norm pieces in K block 0, see
-    include/meld_hip.h) -- wherever d > 13 and d + 6 K slots fit the K blocks d + 3 needs -- and the development switch."""
+    include/meld_hip.h) -- wherever d > 13 and d + 6 K slots fit the K blocks d + 3 needs; a function of d alone."""
     from meld_amd._lib import get_lib
 
     lib = get_lib()
@@ -68,10 +68,6 @@ def test_split_layout_geometry_is_a_function_of_the_dimension():
         assert lib.meld_knn16_split_dims(d) == lead, d
         assert (lead == 13) == (d > 13 and d + 6 <= 16 * kb)
     assert lib.meld_knn16_split_dims(500) == 0  # (no kernel for that many K blocks)
-    was = lib.meld_knn16_debug_split(0)
-    try:
-        assert was == 1 and lib.meld_knn16_split_dims(50) == 0
-    finally:
-        lib.meld_knn16_debug_split(was)
-    assert lib.meld_knn16_split_dims(50) == 13 and lib.meld_knn16_debug_split(-1) == 1
+    assert lib.meld_knn16_split_dims(50) == 13
+    assert not hasattr(lib, "meld_knn16_debug_split")  # (round 5's process-wide layout switch is gone from the boundary)
     assert lib.meld_frame_max_dims() == 64

@@ -137,6 +137,32 @@ def test_graph_matches_oracle(n, d, knn):
     np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,d,knn", [(20000, 50, 15), (24000, 14, 10), (24000, 58, 10), (33555, 32, 5), (40000, 100, 15)])
+def test_graph_in_the_principal_frame_matches_oracle(n, d, knn, monkeypatch):
+    """A2-A5 on the kernel that carries the headline -- the list-driven first pass in the cells' principal frame with the
+    partial-distance test behind the first K block (``knn16_topk_kernel<.., LIST, EE>``; the product takes it from 262144 cells
+    on, ``MELD_KNN_ROTATE_MIN=0`` asks for it here) -- against the ORACLE itself (brute-force kNN, [UPSTREAM graphtools
+    ``build_kernel_to_data``] as restated at oracle/meld_oracle.py, reached from reference meld/meld.py:273), not against this
+    library's plain path: W, K (CSR, canonical order), degrees and bandwidths.  Shapes: C2's width; one and four K blocks' worth
+    of coordinates behind K block 0 (d = 14, 58); an odd number of K blocks searched in reference slices (33555 x 32, the shape
+    of round 5's staging bug); the reference's default width n_pca = 100."""
+    mo = _oracle()
+    import meld_amd
+
+    monkeypatch.setenv("MELD_KNN_ROTATE_MIN", "0")
+    X, _ = mo.synthetic_cells(n, n_dims=d, seed=7)
+    G = mo.build_graph(X, knn=knn, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute", n_jobs=-1)
+    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=40, thresh=1e-4, anisotropy=1)
+    info = DG.info
+    assert info["principal_frame"] and info["step_lists"] and info["prune"], info
+    assert info["blocks_past_partial_test"] is not None
+    assert info["blocks_past_partial_test"] < 2 * info["wave_tiles_done"]  # the test dropped something
+    _csr_close(DG.W, G.W, rtol=1e-9)
+    np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
+    _csr_close(DG.K, G.K, rtol=1e-9)
+    np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
+
+
 @pytest.mark.parametrize("n,d,knn", [(6000, 50, 15), (20000, 10, 5)])
 @pytest.mark.parametrize("opt", ["scale0.6", "scale0.93", "scale1.3", "fixed", "fixed_per_cell", "fixed_scaled"])
 def test_bandwidth_options_match_the_oracle(n, d, knn, opt):
@@ -205,11 +231,14 @@ def test_precomputed_matrices_match_the_oracle(kind):
         meld_amd.MELD(distance=name, verbose=0).fit(M[:, :5])
 
 
-@pytest.mark.parametrize("case", ["mixture", "low_d", "iid_100d", "large_knn_max"])
+@pytest.mark.parametrize("case", ["mixture", "low_d", "iid_100d", "large_knn_max", "uncapped_corner", "capped_corner"])
 def test_knn_max_matches_the_oracle(case):
     """graphtools' ``knn_max``: a row keeps its knn_max nearest cells (besides itself) at most -- through the candidate lists
     (ranked in refine) and, on iid 100-d data where the lists cannot certify the radius, through the certified top ranks or the
-    exact sweep; against the oracle's restatement of ``build_kernel_to_data(knn_max=)``."""
+    exact sweep; against the oracle's restatement of ``build_kernel_to_data(knn_max=)``.  The two ``corner`` cases: knn = 1 with
+    36 (knn + 1) < knn_max + 1, where upstream's re-search ends in an UNCAPPED radius search when no more than N // 10 rows hold
+    6 (knn + 1) cells inside their radius (decay 40: few do) and in the cap when more do (decay 2: wide radii) -- the builder
+    follows upstream in both (``build_knn_graph``)."""
     mo = _oracle()
     import meld_amd
 
@@ -220,15 +249,32 @@ def test_knn_max_matches_the_oracle(case):
         X, knn, kmax = mo.synthetic_cells(3000, n_dims=5, seed=3)[0], 5, 8
     elif case == "iid_100d":
         X, knn, kmax = rng.normal(size=(600, 100)), 5, 9
-    else:
+    elif case == "large_knn_max":
         X, knn, kmax = mo.synthetic_cells(4000, n_dims=20, seed=3)[0], 10, 100
-    G = mo.build_graph(X, knn=knn, algorithm="brute", knn_max=kmax)
-    assert (np.diff(G.K_directed.indptr) <= kmax + 1).all()
-    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, knn_max=kmax)
+    elif case == "capped_corner":
+        X, knn, kmax = rng.normal(size=(3000, 2)), 1, 100
+    else:  # a jittered grid (five cells inside every radius) and ONE cell with 120 others at its nearest-neighbour distance
+        grid = np.stack(np.meshgrid(np.arange(54.0), np.arange(54.0)), -1).reshape(-1, 2) + rng.normal(0, 0.02, size=(2916, 2))
+        ang = np.linspace(0, 2 * np.pi, 120, endpoint=False)
+        centre = np.array([-3.0, -3.0])
+        ring = centre + 0.5 * np.stack([np.cos(ang), np.sin(ang)], 1) * (1 + rng.normal(0, 1e-3, size=(120, 1)))
+        X, knn, kmax = np.concatenate([grid, centre[None], ring]), 1, 100
+    decay = {"capped_corner": 2, "uncapped_corner": 10}.get(case, 40)
+    # (the corner cases: tree search, exact differences -- sklearn's brute force forms |x|^2 + |y|^2 - 2 x.y, too coarse for the
+    # ring's tiny distances under the decay exponent)
+    G = mo.build_graph(X, knn=knn, decay=decay, algorithm="ball_tree" if "corner" in case else "brute", knn_max=kmax)
+    if case != "uncapped_corner":
+        assert (np.diff(G.K_directed.indptr) <= kmax + 1).all()
+    else:
+        assert (np.diff(G.K_directed.indptr) > kmax + 1).any()  # (upstream's uncapped radius search: the oracle follows it)
+    DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=decay, knn_max=kmax)
     _csr_close(DG.W, G.W, rtol=1e-9)
     np.testing.assert_allclose(DG.dw, G.dw, rtol=1e-9)
-    full = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn)
-    assert DG.nnz <= full.nnz and (case == "large_knn_max" or DG.nnz < full.nnz)
+    full = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=decay)
+    assert bool(DG.info.get("knn_max_uncapped_as_upstream")) == (case == "uncapped_corner")
+    if case == "capped_corner":
+        assert (np.diff(G.K_directed.indptr) == kmax + 1).any()  # (the cap bites)
+    assert DG.nnz <= full.nnz and (case in ("large_knn_max", "uncapped_corner") or DG.nnz < full.nnz)
     with pytest.raises(ValueError):
         meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, knn_max=knn - 1)
 

@@ -55,8 +55,7 @@ def test_graph_does_not_depend_on_the_frame_or_the_partial_test(kind, d, monkeyp
     base, info = _graph(ops, Xd)
     assert info["principal_frame"] and info["step_lists"] and info["blocks_past_partial_test"] is not None
     assert info["blocks_past_partial_test"] < 2 * info["wave_tiles_done"]  # the test dropped something
-    # (a) the same frame without the test, (b) no frame (the test is then not asked for), (c) no frame with the test forced on,
-    # (d) the plain operand layout
+    # (a) the same frame without the test, (b) no frame (the test is then not asked for), (c) no frame with the test forced on
     monkeypatch.setenv("MELD_KNN16_EE", "0")
     a, _ = _graph(HipOps(), Xd)
     monkeypatch.delenv("MELD_KNN16_EE")
@@ -67,13 +66,7 @@ def test_graph_does_not_depend_on_the_frame_or_the_partial_test(kind, d, monkeyp
     monkeypatch.setenv("MELD_KNN16_EE", "1")
     c, _ = _graph(ops_b, Xd)
     monkeypatch.delenv("MELD_KNN16_EE")
-    was = lib.meld_knn16_debug_split(0)
-    try:
-        assert lib.meld_knn16_split_dims(d) == 0
-        dd, _ = _graph(ops_b, Xd)
-    finally:
-        lib.meld_knn16_debug_split(was)
-    for other in (a, b, c, dd):
+    for other in (a, b, c):
         for u, v in zip(base, other):
             assert torch.equal(u, v)
 

@@ -38,7 +38,7 @@ def test_search_kernels_do_not_spill():
     product = {k: v for k, v in rows.items() if "knn16_topk_kernelILi" in k and "ELi0ELi" in k}  # ABL = 0
     # KB = 1..9 x NPROD in {1, 3}, table-driven (LIST = false) + KB = 1..9 list-driven hi-only first pass (LIST = true) + KB = 2..6
     # the same with the partial test behind the first K block (EE = true)
-    assert len(product) == 32, sorted(product)
+    assert len(product) == 32, sorted(product)  # (round 6: KB = 7 of the partial-test kernel is served by the two-pass route)
     assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 5, sorted(product)
     for name, r in product.items():
         assert r["ScratchSize [bytes/lane]:"] == 0, (name, r)

@@ -30,6 +30,7 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
         mg.record_events(False)
     kb = (50 + 3 + 15) // 16
     ideal = (n / 32.0) ** 2 * kb * 32 / 1024 / 2.4e9 * 1e3
+    print("pairs listed-and-tested %s, blocks of 32 refs computed in full %s, two_phase %s" % (info.get("wave_tiles_done"), info.get("blocks_past_partial_test"), info.get("two_phase")))
     print("N=%d knn_topk %.2f ms  (hi.hi MFMA stream @2.4GHz %.2f ms, %.1f%%)  stage2 %.2f ms  researched %d  swept %d  env %s" % (
         n, ms, ideal, 100 * ideal / ms, ev.get("knn_topk_stage2", [0.0])[0], info["n_researched_rows"], info["n_flagged_rows"],
         {k: v for k, v in os.environ.items() if k.startswith("MELD_KNN")}))
