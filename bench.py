@@ -392,11 +392,17 @@ def main():
                 executed = 2.0 * 64 * 64 * 16 * blocks * float(wt)
                 computed_frac = float(wt) / (math.ceil(rows / 64) * math.ceil(N / 64))
                 on = G.info.get("blocks_past_partial_test")
+                kept = G.info.get("pairs_past_filter")  # two-pass route (round 6): (wave, tile) pairs the list-filter pass left to the search
                 if on is not None and nprod == 1:
-                    # partial test (principal frame): every computed (wave, tile) pair issues K block 0 of its two blocks of 32
-                    # references; only the blocks that pass the test issue the other kb - 1 K blocks
-                    executed = 2.0 * 16 * (64 * 64 * float(wt) + 32 * 64 * (kb - 1) * float(on))
-                    partial = {"blocks_of_32_refs_past_the_first_k_block": int(on), "of": 2 * int(wt), "frac": float(on) / (2.0 * float(wt))}
+                    # partial test (principal frame): every (wave, tile) pair the search kernel computes issues K block 0 of its two
+                    # blocks of 32 references; only the blocks that pass the test issue the other kb - 1 K blocks.  Two-pass route:
+                    # the pairs the search computes are the ones the filter pass kept; the filter pass's own flops (K block 0 of
+                    # every listed pair) are reported under `roofline_filter`
+                    searched = float(kept) if kept is not None else float(wt)
+                    executed = 2.0 * 16 * (64 * 64 * searched + 32 * 64 * (kb - 1) * float(on))
+                    partial = {"blocks_of_32_refs_past_the_first_k_block": int(on), "of": int(2 * searched), "frac": float(on) / (2.0 * searched)}
+                    if kept is not None:
+                        partial.update(pairs_listed_and_tested_by_the_filter_pass=int(wt), pairs_it_kept=int(kept), kept_frac=float(kept) / float(wt))
             peak, kname = PEAK_MFMA_F16_TFLOPS, "knn16_topk_kernel (split-fp16 hi/lo distance GEMM on v_mfma_f32_32x32x16_f16 + streaming top-k)"
         else:
             kp = int(G.info.get("KP", d + 2))
@@ -417,9 +423,10 @@ def main():
             "traffic_replayed_from": replayed_from(measured_traffic("knn16_topk", N, d)),
             # the replayed traffic over THIS run's kernel time: what the fabric side of the L2s delivers (a plain copy reaches ~6300 GB/s)
             "traffic_rate_gb_s": ((measured_traffic("knn16_topk", N, d) or {}).get("bytes_per_launch") or 0.0) / t_knn / 1e9 or None,
-            "bound_note": "`frac` = flops issued to the matrix pipe / dense f16 peak (a utilisation).  With the partial test most blocks stop "
-            "after one of four K blocks, so the pipe is mostly idle by design; what the kernel runs into is the fabric: its tile stream "
-            "(`traffic`, replayed from the PMC pass) over this run's kernel time is `traffic_rate_gb_s`, against ~6300 GB/s of a plain copy",
+            "bound_note": "`frac` = flops issued to the matrix pipe / dense f16 peak (a utilisation).  Round 6: the partial test runs as a pass "
+            "of its own over the step lists (`roofline_filter`), this kernel stages whole tiles only for the pairs that pass kept (a quarter) -- "
+            "its tile stream (`traffic`, replayed from the PMC pass; `traffic_rate_gb_s` over this run's kernel time) is no longer at the "
+            "fabric's copy rate (~6300 GB/s); what it runs into is its selection slow path (two thirds of its blocks hold a candidate)",
             "traffic_note": (measured_traffic("knn16_topk", N, d) or {}).get(
                 "note", "no PMC pass on record for this size (profiles/pmc/traffic.json); a bench run collects no counters"),
             "traffic_commit": (measured_traffic("knn16_topk", N, d) or {}).get("commit"),
@@ -440,6 +447,22 @@ def main():
             "`partial_test` counts those, `executed` = K block 0 of every computed block + the other K blocks of the ones that went on",
             "ms": 1e3 * t_knn,
         }
+    if "knn_filter" in ev and "roofline" in out and G.info.get("two_phase"):
+        # the list-filter pass in front of the search (meld_knn16_partial_filter): K block 0 of every listed (wave, tile) pair, 4 MFMAs
+        t_f = float(np.mean(ev["knn_filter"])) * 1e-3
+        wt = float(G.info.get("wave_tiles_done") or 0)
+        ex_f = 2.0 * 64 * 64 * 16 * wt
+        out["roofline_filter"] = {
+            "kernel": "knn16_partial_filter_kernel<8, 4> (K block 0 of every listed (wave, tile) pair on v_mfma_f32_32x32x16_f16, lists thinned in place)",
+            "bound": "mfma", "achieved": ex_f / t_f / 1e12, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ex_f / t_f / 1e12 / PEAK_MFMA_F16_TFLOPS,
+            "ms": 1e3 * t_f, "pairs_tested": int(wt), "pairs_kept": G.info.get("pairs_past_filter"),
+            "traffic": (measured_traffic("knn16_partial_filter", N, d) or {}).get("bytes_per_launch"),
+            "traffic_replayed_from": replayed_from(measured_traffic("knn16_partial_filter", N, d)),
+            "note": "HIP events around the launch (+ the re-sort of the dispatch order behind it); issue-bound: one LDS-DMA piece costs ~180 "
+                    "cycles of issue, the test ~300 per pair (4 MFMAs = 128 pipe cycles + the minima over 64 accumulator registers); "
+                    "without its staging the pass takes 5.2 ms, without its arithmetic 2.7, with neither 1.0 (DESIGN.md 4.1.8)",
+        }
+        out["roofline"]["search_ms_filter_plus_search"] = 1e3 * (t_f + float(np.mean(ev["knn_topk"])) * 1e-3)
     if "cheby_steps" in ev:
         out["roofline_cheby"] = cheby_roofline(G, ev, args.order, p, N, d)
     if world == 1 and not args.no_extra and N == 1_000_000 and d == 50:

@@ -261,7 +261,8 @@ int meld_knn16_topk_listed_partial(const void* Q16, const float* Qn, const void*
  * the thinned lists returns the rows the search over the full ones would (no reference counterpart: graphtools searches a tree). */
 int meld_knn16_partial_filter(const void* Q16, const float* Qn, const void* Rt16, const float* scale_info, const float* norm2_max, int d,
                               int64_t q_count, const float* thr_init, uint32_t* step_list, const int32_t* step_cnt, int64_t list_stride,
-                              int32_t* cnt_out, uint64_t* tested, const int32_t* block_order, meld_stream_t stream);
+                              int32_t* cnt_out, uint64_t* tested, const int32_t* block_order /* optional: workgroup g takes block
+                              block_order[g] */, meld_stream_t stream);
 /* Radius cut (cand_thr != NULL; knn and radius_factor = (-ln thresh)^(1/decay) of the kernel that will be
  * built from the lists): once a row holds knn + 1 entries, its bandwidth^2 is at most A + E (A = its
  * (knn+1)-th smallest approximate d2, E = the row's search-error allowance), so nothing with approximate d2

@@ -1184,8 +1184,10 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
 // exposed to all four waves at the next barrier.)
 // Entries are rewritten IN PLACE (an entry is written at or in front of where it was read; no list position is read twice),
 // emptied entries dropped, cnt_out = the new length.  One workgroup per query block = the search kernel's four waves.
-template <int TPS>  // tiles per step (and barrier)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void knn16_partial_filter_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
+// (eight tiles per step at four waves per SIMD; 4 tiles x 6 waves, 6 x 5, 2 x 8 measured 5.8 ... 6.9 against 5.4-5.8 ms: the SIMDs are
+// busy issuing -- an LDS-DMA piece costs ~180 cycles of issue, the test ~300 per (wave, tile) -- not waiting)
+template <int TPS, int WPE>  // tiles per step (and barrier); waves per SIMD the kernel is compiled for
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void knn16_partial_filter_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
                                                                    const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
                                                                    const float* __restrict__ norm2_max, const float* __restrict__ thr_init,
                                                                    unsigned* step_list, const int* __restrict__ step_cnt, long long list_stride,
@@ -1223,63 +1225,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       tA[g] = (thr_init[q] - Qn[q]) + (qb * 1.0001f + delta);
     }
   }
-  typedef const __attribute__((address_space(4))) unsigned* list_ptr_t;
   unsigned* const my_list_w = step_list + (size_t)bx * (size_t)list_stride;
-  const list_ptr_t my_list = (list_ptr_t)(uintptr_t)my_list_w;
   const int n = __builtin_amdgcn_readfirstlane(step_cnt[bx]);
   const int n_steps = (n + TPS - 1) / TPS;
-  const size_t tile_bytes = (size_t)KB * 4096;  // KB x [k-half][plane][ref][8 halves]
+  // K block 0 of a tile = its first two hi planes (tile = KB x [k-half][plane][ref][8 halves]: bytes 0 and 2048).  (The same planes
+  // gathered into a contiguous array of their own first, 2 KiB per tile: 5.48 against 5.46 ms -- the pass is not short of
+  // bandwidth: without its staging it takes 5.2 ms, without its arithmetic 2.7, with neither 1.0.)
+  const size_t tile_bytes = (size_t)KB * 4096;
+  const int plane_stride = 2048;
+  const size_t src_base = reinterpret_cast<size_t>(Rt16);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const unsigned ring_base = (unsigned)(size_t)(lds_ptr_t)&ring[0][0][0];
   const int lane16 = lane * 16;
+  // The entries of a step ride in ONE register: lane j < TPS holds entry j (0 past the end of the list: no wave listed), loaded
+  // two steps ahead of their use by one vector load; a tile's entry reaches the scalar side by v_readlane.  (First version: a
+  // scalar load and its wait per tile -- 1.5 of the pass's 5.4 ms at 1M cells were spent waiting for list entries.)
+  auto load_entries = [&](int step) __attribute__((always_inline)) {
+    const int idx = step * TPS + lane;
+    return (lane < TPS && idx < n) ? my_list_w[idx] : 0u;
+  };
   // staging: 2 TPS pieces of 1 KiB per step, TPS / 2 per wave: piece k = plane (k & 1) of the step's tile (k >> 1)
-  auto stage = [&](int step, int buf) __attribute__((always_inline)) {
+  auto stage = [&](unsigned ev, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < TPS / 2; ++u) {
       const int k = wave * (TPS / 2) + u;
-      const int idx = step * TPS + (k >> 1);
-      if (idx < n) {
-        const size_t src = reinterpret_cast<size_t>(Rt16) + (size_t)(my_list[idx] & 0xFFFFFFu) * tile_bytes;
+      const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)ev, k >> 1);
+      if (e >> 24) {
+        const size_t src = src_base + (size_t)(e & 0xFFFFFFu) * tile_bytes;
         const i32x4 rsrc = {(int)(unsigned)src, (int)((src >> 32) & 0xffffu), 4096, 0x00020000};
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(
                          (int)(ring_base + (unsigned)((buf * TPS + (k >> 1)) * 2048 + (k & 1) * 1024)))),
-                     "v"(lane16), "s"(rsrc), "s"((k & 1) * 2048)
+                     "v"(lane16), "s"(rsrc), "s"((k & 1) * plane_stride)
                      : "memory");
       }
     }
   };
   int out_n = 0;  // (wave 0: entries written so far)
   unsigned long long n_tested = 0;
-  // the masks of step s_ -> the list, by wave 0 at the top of the next step (lane j: entry j of the step)
-  auto emit = [&](int s_) __attribute__((always_inline)) {
-    const int idx = s_ * TPS + lane;
-    const bool have = lane < TPS && idx < n;
-    const unsigned e = have ? my_list_w[idx] : 0u;
+  // the masks of a step -> the list, by wave 0 at the top of the next step (lane j: entry j of the step, still in its register)
+  auto emit = [&](unsigned ev, int par) __attribute__((always_inline)) {
     unsigned nm = 0u;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) nm |= ((wmask[s_ & 1][w] >> lane) & 1u) << w;
-    nm &= (e >> 24);
-    const bool keep = have && nm != 0u;
+    for (int w = 0; w < 4; ++w) nm |= ((wmask[par][w] >> lane) & 1u) << w;
+    nm &= (ev >> 24);
+    const bool keep = nm != 0u;
     const unsigned long long b = __ballot(keep);
-    if (keep) my_list_w[out_n + __popcll(b & ((1ull << lane) - 1ull))] = (e & 0xFFFFFFu) | (nm << 24);
+    if (keep) my_list_w[out_n + __popcll(b & ((1ull << lane) - 1ull))] = (ev & 0xFFFFFFu) | (nm << 24);
     out_n += __popcll(b);
   };
-  if (n_steps > 0) stage(0, 0);
+  unsigned ev_prev = 0u, ev_cur = load_entries(0), ev_nxt = load_entries(1);
+  if (n_steps > 0) stage(ev_cur, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   for (int s = 0; s < n_steps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
-    if (wave == 0 && s > 0) emit(s - 1);
+    const unsigned ev_nn = load_entries(s + 2);
+    if (s + 1 < n_steps) stage(ev_nxt, buf ^ 1);
+    if (wave == 0 && s > 0) emit(ev_prev, buf ^ 1);
     unsigned mybits = 0u;
 #pragma unroll
     for (int j = 0; j < TPS; ++j) {
-      const int idx = s * TPS + j;
-      const unsigned e = idx < n ? my_list[idx] : 0u;
+      const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)ev_cur, j);
       if ((e >> (24 + wave)) & 1u) {
         const f16x8* a8 = reinterpret_cast<const f16x8*>(&ring[buf][j][0]) + jq;
         const f16x8 aA = a8[h * K16_TS], aB = a8[h * K16_TS + 32];
+        // (four independent accumulators; one pair after the other -- 55 instead of 70 registers, up to eight waves per SIMD --
+        // measured 5.9 against 5.4 ms: the pass is not short of waves)
         f32x16 c00, c01, c10, c11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c00[r] = c01[r] = c10[r] = c11[r] = 0.0f;
@@ -1295,9 +1307,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (lane == 0) wmask[buf][wave] = mybits;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // (this wave's copies of the next step have landed)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ev_prev = ev_cur;
+    ev_cur = ev_nxt;
+    ev_nxt = ev_nn;
   }
   if (wave == 0) {
-    if (n_steps > 0) emit(n_steps - 1);
+    if (n_steps > 0) emit(ev_prev, (n_steps - 1) & 1);
     if (lane == 0) cnt_out[bx] = out_n;
   }
   if (tested && lane == 0) atomicAdd(tested, n_tested);
@@ -3194,7 +3209,7 @@ extern "C" int meld_knn16_partial_filter(const void* Q16, const float* Qn, const
   const int dA = k16_dA(d, KB);
   MELD_CHECK_ARG(dA > 0 && KB >= 2, "meld_knn16_partial_filter: d = %d has no split operand layout", d);
   const unsigned n_blocks = (unsigned)ceil_div(q_count, K16_BQ);
-  hipLaunchKernelGGL((knn16_partial_filter_kernel<8>), dim3(n_blocks), dim3(256), 0, S(stream), reinterpret_cast<const _Float16*>(Q16), Qn,
+  hipLaunchKernelGGL((knn16_partial_filter_kernel<8, 4>), dim3(n_blocks), dim3(256), 0, S(stream), reinterpret_cast<const _Float16*>(Q16), Qn,
                      reinterpret_cast<const _Float16*>(Rt16), scale_info, norm2_max, thr_init, step_list, step_cnt, (long long)list_stride, cnt_out,
                      reinterpret_cast<unsigned long long*>(tested), block_order, KB, 16 + d - dA);
   MELD_LAUNCH_CHECK("knn16_partial_filter_kernel");

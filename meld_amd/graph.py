@@ -550,6 +550,7 @@ class HipOps:
         search = self.search
         cand_thr, rfac, tiles_done = None, 1.0, None
         used_prune = used_seed = used_seeded_bounds = used_block_order = used_step_lists = used_two_phase = False
+        partial_in_search = 0
         if search == "f16x3" and lib.meld_knn16_kblocks(d) < 0:
             search = "wide"  # d beyond the instantiated MFMA kernels (d > 141)
         if cross and search != "f16x3":
@@ -647,7 +648,7 @@ class HipOps:
                 # (the cut keeps everything within max(rf * bandwidth_scale, 1) bandwidths: never less than the bandwidth entry)
                 rfac = max(rfac * float(bw_scale), 1.0)
             lb2 = block_order = step_list = step_cnt = None
-            tiles_done = torch.zeros(2, dtype=torch.int64, device=dev)  # [(wave, tile) pairs computed, blocks of 32 references past the partial test]
+            tiles_done = torch.zeros(4, dtype=torch.int64, device=dev)  # [(wave, tile) pairs looked at, blocks of 32 references past the partial test (two-pass route: pairs the search computed, then its blocks)]
             will_prune = self.prune and q_begin % TS == 0 and N >= 16384 and not cross
             n_blocks = q_pad // BQ
             seeds = None
@@ -749,12 +750,13 @@ class HipOps:
                 elif resident > 0 and n_blocks < 2 * resident:
                     main_slices = int(max(1, min(4, lib.meld_knn16_max_slices(ksel), -(-2 * resident // n_blocks), n_tiles // 64)))  # (more slices cost more in merging than they balance)
             # The partial-distance test of the principal frame as a pass of its own (meld_knn16_partial_filter): every listed (wave,
-            # tile) pair is tested on K block 0 against the row's start threshold; the search then stages whole tiles for the fifth
-            # of the pairs that survive and needs no test of its own.  MELD_KNN_TWO_PHASE=0: the round-5 form, test and search in
-            # one kernel (every listed tile staged in full).
+            # tile) pair is tested on K block 0 against the row's start threshold and the lists are thinned in place; the search
+            # then stages whole tiles for the quarter of the pairs that survive (it keeps its own test per block of 32 references:
+            # 30 % of the blocks of a surviving pair still stop behind K block 0).  MELD_KNN_TWO_PHASE=0: the round-5 form, every
+            # listed tile staged in full by the one kernel that tests and searches.
             two_phase = (step_list is not None and X_search is not X and seeds is not None
                          and os.environ.get("MELD_KNN_TWO_PHASE", "1") != "0" and os.environ.get("MELD_KNN16_EE") is None)
-            partial_in_search = int(X_search is not X and not two_phase)
+            partial_in_search = int(X_search is not X)
             tiles_b = tiles_done
             if two_phase:
                 with _EventSpan("knn_filter", N=N, d=d, q=q_count):
@@ -762,7 +764,7 @@ class HipOps:
                                                         ptr(step_cnt), n_tiles, ptr(step_cnt), ptr(tiles_done), ptr(block_order), st), "meld_knn16_partial_filter")
                     if block_order is not None:  # (longest blocks first, by what is left of them)
                         block_order = torch.argsort(step_cnt, descending=True, stable=True).to(torch.int32)
-                tiles_b = tiles_done[1:]  # (the search counts the pairs it computes behind the filter's)
+                tiles_b = tiles_done[1:]  # (the search counts the pairs it computes, and its blocks, behind the filter's)
                 tm.stop("knn_filter")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 if main_slices > 1:
@@ -899,15 +901,14 @@ class HipOps:
         keep_off = _scan_i32(lib, keep_cnt, st)
         # ONE read-back for the three scalars the host wants here (each one is an idle gap of the GPU of ~50 us: nothing is queued
         # behind it): rows still flagged after the second stage, kept entries, (wave, tile) pairs the first pass computed
-        heads = [n_flag[0].to(torch.int64), keep_off[q_count]] + ([tiles_done[0], tiles_done[1]] if tiles_done is not None else [])
+        heads = [n_flag[0].to(torch.int64), keep_off[q_count]] + ([tiles_done[0], tiles_done[2] if used_two_phase else tiles_done[1], tiles_done[1]] if tiles_done is not None else [])
         heads_h = torch.stack(heads).tolist()
         if n_flag_stale:
             n_flag_h = int(heads_h[0])
         m_main = int(heads_h[1])
         tiles_done_h = int(heads_h[2]) if tiles_done is not None else None
         blocks_on_h = int(heads_h[3]) if tiles_done is not None and X_search is not X else None
-        if blocks_on_h is not None and used_two_phase:
-            blocks_on_h *= 2  # (the search behind the filter counts (wave, tile) pairs: two blocks of 32 references each)
+        pairs_kept_h = int(heads_h[4]) if tiles_done is not None and used_two_phase else None  # (wave, tile) pairs the filter pass left to the search
 
         # Many uncertified rows with a short candidate list (dense low-dimensional data: more than ksel cells
         # inside the radius inflated by the search-error allowance): search once more with the longest list
@@ -1046,7 +1047,7 @@ class HipOps:
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
-                    wave_tiles_done=tiles_done_h, blocks_past_partial_test=blocks_on_h)
+                    wave_tiles_done=tiles_done_h, blocks_past_partial_test=blocks_on_h, pairs_past_filter=pairs_kept_h)
         if rows_at_least is not None:
             info["rows_with_at_least"] = rows_at_least
         if assembled is not None:

@@ -28,7 +28,7 @@ cnt = collections.Counter()
 for f in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for tag, pat in (("knn16_topk", "knn16_topk_kernel<4, 0, 1"), ("pt_step", "pt_step_kernel<2,"), ("pt_step_p1", "pt_step_kernel<1,"),
+        for tag, pat in (("knn16_topk", "knn16_topk_kernel<4, 0, 1"), ("knn16_partial_filter", "knn16_partial_filter_kernel"), ("pt_step", "pt_step_kernel<2,"), ("pt_step_p1", "pt_step_kernel<1,"),
                          ("cheby_step", "cheby_step_kernel<2")):
             if pat in k:
                 acc[tag][r["Counter_Name"]] += float(r["Counter_Value"])
