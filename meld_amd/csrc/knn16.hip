@@ -911,7 +911,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
           accA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[1][kb], accA1, 0, 0, 0);
         }
         const float m0 = min16(accA0), m1 = min16(accA1);
-        if (__any(m0 < thrp[0] || m1 < thrp[1])) select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
+        if (__any(m0 < thrp[0] || m1 < thrp[1])) {
+          const unsigned t0s = tm_now();
+          select(accA0, accA1, m0, m1, t * K16_TS + 32 * sub + 4 * h);
+          if (ABL == 2) {
+            const unsigned dsel = tm_now() - t0s;
+            tm_sel += dsel;
+            tm_mark += dsel;  // (not counted as segment time)
+          }
+        }
         ++st_go;
       }
     }
@@ -1081,9 +1089,12 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
       const unsigned f0 = list_entry(2 * p + 4), f1 = list_entry(2 * p + 5);
       if (2 * p + 2 < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(x0 & 0xFFFFFFu)), other);
       if (2 * p + 3 < n_scan) K16_LOAD(__builtin_amdgcn_readfirstlane((int)(x1 & 0xFFFFFFu)), other + (unsigned)TILE_LDS_BYTES);
+      tm_lap(tm_tail);  // (MELD_KNN16_STATS: the copy requests of the next pair)
       const char* ring = reinterpret_cast<const char*>(lds_ring);
-      if (entry_live(c0)) ee_tile(reinterpret_cast<const _Float16*>(ring + buf), (int)(c0 & 0xFFFFFFu));
-      if (2 * p + 1 < n_scan && entry_live(c1)) ee_tile(reinterpret_cast<const _Float16*>(ring + buf + TILE_LDS_BYTES), (int)(c1 & 0xFFFFFFu));
+      const bool live0 = entry_live(c0), live1 = 2 * p + 1 < n_scan && entry_live(c1);
+      if (live0) ee_tile(reinterpret_cast<const _Float16*>(ring + buf), (int)(c0 & 0xFFFFFFu));
+      if (live1) ee_tile(reinterpret_cast<const _Float16*>(ring + buf + TILE_LDS_BYTES), (int)(c1 & 0xFFFFFFu));
+      if (live0 || live1) tm_lap(tm_seg); else tm_lap(tm_idle);
       if (batch_every > 0 && (p & (batch_every / 2 - 1)) == batch_every / 2 - 1) {  // (batched compaction: as in the single-tile loop)
         const int limit = ksel + K16_COLD(batch_slack);
         unsigned long long todo = 0;
@@ -1100,8 +1111,11 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
           if (ABL == 2) ++st_sq;
         }
       }
+      tm_lap(tm_tail);
       K16_STAGED();
+      tm_lap(tm_dma);
       K16_TILE_BARRIER();
+      tm_lap(tm_bar);
       c0 = x0;
       c1 = x1;
       x0 = f0;
@@ -1129,14 +1143,15 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
       atomicAdd(stats + 1, (unsigned long long)st_slow);
       atomicAdd(stats + 2, (unsigned long long)a);
       atomicAdd(stats + 3, (unsigned long long)st_sq);
-      if (wave == 0) atomicAdd(stats + 4, (unsigned long long)it);
+      const int it_tiles = PAIR ? n_scan : it;  // (the two-tile loop counts pairs)
+      if (wave == 0) atomicAdd(stats + 4, (unsigned long long)it_tiles);
       atomicAdd(stats + 5, (unsigned long long)tm_seg);
       atomicAdd(stats + 6, (unsigned long long)tm_sel);
       atomicAdd(stats + 7, (unsigned long long)tm_tail);
       atomicAdd(stats + 8, (unsigned long long)tm_dma);
       atomicAdd(stats + 9, (unsigned long long)tm_bar);
       atomicAdd(stats + 10, (unsigned long long)tm_idle);
-      atomicAdd(stats + 11, (unsigned long long)it);
+      atomicAdd(stats + 11, (unsigned long long)it_tiles);
       if (EE) atomicAdd(stats + 12, (unsigned long long)st_go);
     }
   }
@@ -1192,7 +1207,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                                                                    const float* __restrict__ norm2_max, const float* __restrict__ thr_init,
                                                                    unsigned* step_list, const int* __restrict__ step_cnt, long long list_stride,
                                                                    int* __restrict__ cnt_out, unsigned long long* __restrict__ tested,
-                                                                   const int* __restrict__ block_order, int KB, int ee_hi) {
+                                                                   const int* __restrict__ block_order, int KB, int ee_hi, int abl) {
+  // (abl: timing-only ablations of -DK16_PROFILING builds, MELD_KNN_FILTER_ABL: 1 = no staging behind the first step, 2 = no tests)
   static_assert(TPS >= 2 && TPS <= 32 && (TPS & 1) == 0, "tiles per step");
   __shared__ __attribute__((aligned(16))) _Float16 ring[2][TPS][2 * K16_TS * 8];  // K block 0, hi planes: [k-half][ref][8 halves]
   __shared__ unsigned wmask[2][4];
@@ -1281,13 +1297,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   for (int s = 0; s < n_steps; ++s) {
     const int buf = s & 1;
     const unsigned ev_nn = load_entries(s + 2);
-    if (s + 1 < n_steps) stage(ev_nxt, buf ^ 1);
+    if (s + 1 < n_steps && !(abl & 1)) stage(ev_nxt, buf ^ 1);
     if (wave == 0 && s > 0) emit(ev_prev, buf ^ 1);
     unsigned mybits = 0u;
 #pragma unroll
     for (int j = 0; j < TPS; ++j) {
       const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)ev_cur, j);
-      if ((e >> (24 + wave)) & 1u) {
+      if (((e >> (24 + wave)) & 1u) && !(abl & 2)) {
         const f16x8* a8 = reinterpret_cast<const f16x8*>(&ring[buf][j][0]) + jq;
         const f16x8 aA = a8[h * K16_TS], aB = a8[h * K16_TS + 32];
         // (four independent accumulators; one pair after the other -- 55 instead of 70 registers, up to eight waves per SIMD --
@@ -3209,9 +3225,13 @@ extern "C" int meld_knn16_partial_filter(const void* Q16, const float* Qn, const
   const int dA = k16_dA(d, KB);
   MELD_CHECK_ARG(dA > 0 && KB >= 2, "meld_knn16_partial_filter: d = %d has no split operand layout", d);
   const unsigned n_blocks = (unsigned)ceil_div(q_count, K16_BQ);
+  int abl = 0;
+#ifdef K16_PROFILING
+  if (const char* e = getenv("MELD_KNN_FILTER_ABL")) abl = atoi(e);
+#endif
   hipLaunchKernelGGL((knn16_partial_filter_kernel<8, 4>), dim3(n_blocks), dim3(256), 0, S(stream), reinterpret_cast<const _Float16*>(Q16), Qn,
                      reinterpret_cast<const _Float16*>(Rt16), scale_info, norm2_max, thr_init, step_list, step_cnt, (long long)list_stride, cnt_out,
-                     reinterpret_cast<unsigned long long*>(tested), block_order, KB, 16 + d - dA);
+                     reinterpret_cast<unsigned long long*>(tested), block_order, KB, 16 + d - dA, abl);
   MELD_LAUNCH_CHECK("knn16_partial_filter_kernel");
   return MELD_OK;
 }

@@ -4,7 +4,7 @@
 # bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3), fabric traffic (PMC) of the hot kernels,
 # PMC passes over the search and the recurrence kernels, the per-wave timeline of a recurrence step, and the full-oracle
 # parity runs at 1M and 500k, the VertexFrequencyCluster line at 1M and the per-rank compute of the sharded driver.  Every file carries the commit; copy gpurun_out/prof_<tag>/* to profiles/.
-tag=${1:-r05}; commit=${2:-unknown}; quick=${3:-}
+tag=${1:-r06}; commit=${2:-unknown}; quick=${3:-}
 out=gpurun_out/prof_$tag; mkdir -p $out/pmc; export TMPDIR=/tmp
 stamp() { echo "# commit $commit, $(date -u +%Y-%m-%dT%H:%MZ), $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//')"; }
 cpu=""; [ "$quick" = "cpufull" ] && cpu="--cpu-full"   # (the 27-minute CPU protocol only when asked for)
@@ -82,25 +82,28 @@ if vals.get("TCC_EA0_RDREQ_sum"):
     d["cheby_step_wide@1000000x64cols"] = rec
     json.dump(d, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 PY
-{ stamp; echo "# search ablations (-DK16_PROFILING build of knn16.hip; list-driven kernel) + what perfect seeds would be worth + list statistics"
-  # (meld_amd/libmeld_hip_prof.so: built BEFORE the call, on the build host -- `bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING
-  # -DK16_DEV_KB4`; the object files it links against do not travel to the GPU box)
-  if [ -f meld_amd/libmeld_hip_prof.so ]; then MELD_HIP_LIB=$PWD/meld_amd/libmeld_hip_prof.so python tools/knn_ablate.py 2>&1 | grep -v amdgpu.ids; else echo "(no profiling build of the library in the tree: ablations skipped)"; python tools/knn_ablate.py 2>&1 | grep -v amdgpu.ids | grep "product\|table\|per wave\|seed /"; fi
+{ stamp; echo "# the two passes of the search at 1M x 50 (principal frame): the list-filter pass (K block 0 of every listed pair) and the list-driven search over the thinned lists"
+  echo "## product (HIP events around the two launches; tools/knn_only.py)"; python tools/knn_only.py 1000000 4 2>&1 | grep -v amdgpu.ids | tail -3
+  echo "## MELD_KNN_TWO_PHASE=0: the round-5 form (one kernel tests and searches, every listed tile staged in full)"; MELD_KNN_TWO_PHASE=0 python tools/knn_only.py 1000000 4 2>&1 | grep -v amdgpu.ids | tail -2
+  echo "## MELD_KNN_ROTATE=0: cells as given (no frame, no test)"; MELD_KNN_ROTATE=0 python tools/knn_only.py 1000000 3 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "## counters of the search kernel behind the filter (MELD_KNN16_STATS): blocks, slow path, appends, where a wave's cycles go"
+  MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats" | head -3
+  # (meld_amd/libmeld_hip_prof.so: built BEFORE the call, on the build host -- `bash tools/build_variant.sh prof knn16.hip -DK16_PROFILING`;
+  # the object files it links against do not travel to the GPU box)
+  if [ -f meld_amd/libmeld_hip_prof.so ]; then
+    echo "## filter pass, timing-only ablations of the -DK16_PROFILING build (MELD_KNN_FILTER_ABL: 0 = product, 1 = no staging behind the first step, 2 = no tests, 3 = neither); knn_filter in ms"
+    for a in 0 1 2 3; do echo -n "abl $a: "; MELD_HIP_LIB=$PWD/meld_amd/libmeld_hip_prof.so MELD_KNN_FILTER_ABL=$a python tools/knn_only.py 1000000 3 2>&1 | grep "knn_filter" | tail -1; done
+    echo "## search over the thinned lists, timing-only ablations of the list kernel (MELD_KNN16_ABLATION: 1 = no selection, 8 = MFMAs only with tiles from an L2-hot set, 9 = MFMAs only without tile loads); knn_topk in ms"
+    for a in 1 8 9; do echo -n "abl $a: "; MELD_HIP_LIB=$PWD/meld_amd/libmeld_hip_prof.so MELD_KNN16_ABLATION=$a python tools/knn_only.py 1000000 3 2>&1 | grep "knn_filter" | tail -1; done
+  else echo "(no profiling build of the library in the tree: ablations skipped)"; fi
+  echo "## d = 100 (the reference's default n_pca): 1M x 100, principal frame by the library rotation, the same two passes"
+  DIMS=100 python tools/knn_only.py 1000000 3 2>&1 | grep -v amdgpu.ids | tail -3
+  DIMS=100 MELD_KNN_ROTATE=0 python tools/knn_only.py 1000000 2 2>&1 | grep -v amdgpu.ids | tail -1
   python tools/list_stats.py 2>&1 | grep -v amdgpu.ids | tail -9
-  MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats" | head -2
-  } > $out/knn_ablation.txt
-{ stamp; echo "# the partial-distance test of the first pass (principal frame, K block 0 = 13 coordinates): what it drops (kernel counters), what it could drop (tools/sim_partial.py), what the frame costs (tools/time_rotate.py), A-B timings of the search stage"
-  MELD_KNN16_STATS=1 python tools/knn_only.py 1000000 1 2>&1 | grep "stats\|knn_topk" | head -4
-  echo "## default"; python tools/knn_only.py 1000000 4 2>&1 | tail -1
-  echo "## MELD_KNN16_EE=0 (principal frame, no test)"; MELD_KNN16_EE=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
-  echo "## MELD_KNN_ROTATE=0 (cells as given, no test)"; MELD_KNN_ROTATE=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
-  echo "## MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 (cells as given, test forced on)"; MELD_KNN_ROTATE=0 MELD_KNN16_EE=1 python tools/knn_only.py 1000000 4 2>&1 | tail -1
-  echo "## MELD_KNN16_SKIP_PAD=0 (the all-padding plane of every tile staged as before)"; MELD_KNN16_SKIP_PAD=0 python tools/knn_only.py 1000000 4 2>&1 | tail -1
-  echo "## stage timers of a step (bench.py --stages): default, and MELD_KNN16_LEAD_BOUNDS=0 (the direct lists' bounds from all K blocks)"
-  bash tools/_stages.sh A=1 2>&1 | grep -v amdgpu.ids | tail -1; bash tools/_stages.sh MELD_KNN16_LEAD_BOUNDS=0 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "## what the frame costs (tools/time_rotate.py), what the test could drop (tools/sim_partial.py)"
   python tools/time_rotate.py 2>&1 | grep -v amdgpu.ids | tail -9
   python tools/sim_partial.py 1000000 64 2>&1 | grep -v amdgpu.ids | tail -16
-  DATA=iid python tools/sim_partial.py 200000 32 2>&1 | grep -v amdgpu.ids | head -3; } > $out/partial_test.txt
+  } > $out/knn_ablation.txt
 { stamp; echo "# per-rank compute of the sharded driver on ONE GPU (stand-in collectives, results wrong by construction): tools/shard_emulate.py"
   for g in 2 4 8; do python tools/shard_emulate.py 1000000 $g 1 2>&1 | grep "^rank\|^collectives\|^lmax" | tail -3; done
   echo "# rank 0 with the recurrences enqueued from C on a REAL one-rank RCCL communicator (RCCL=1: meld_cheby_run_sharded / meld_lanczos_steps_sharded), and the per-step Python loops beside it (RCCL=0)"
@@ -110,14 +113,11 @@ PY
 { stamp; echo "# what a finer pruning granularity than 64 queries x 64 references would compute (tools/sim_granularity.py, the kernel's own rule per piece)"
   python tools/sim_granularity.py 1000000 96 2>&1 | grep -v amdgpu.ids | tail -20; } > $out/knn_granularity.txt
 { stamp; echo "# fuzz of the graph builder against the oracle, graphtools' bandwidth / knn_max options drawn (tools/fuzz_graph.py)"
-  FUZZ_OPTIONS=1 FUZZ_N_MAX=8000 timeout 900 python tools/fuzz_graph.py 80 7 2>&1 | grep -v amdgpu.ids | tail -85
+  FUZZ_OPTIONS=1 FUZZ_N_MAX=8000 timeout 600 python tools/fuzz_graph.py 50 7 2>&1 | grep -v amdgpu.ids | tail -55
   echo "# product only (builds, symmetry, finiteness)"
-  FUZZ_OPTIONS=1 FUZZ_NO_ORACLE=1 timeout 400 python tools/fuzz_graph.py 300 11 2>&1 | grep -v amdgpu.ids | grep -v "^ok" | tail -12; } > $out/fuzz.txt
+  FUZZ_OPTIONS=1 FUZZ_NO_ORACLE=1 timeout 300 python tools/fuzz_graph.py 200 11 2>&1 | grep -v amdgpu.ids | grep -v "^ok" | tail -12; } > $out/fuzz.txt
 { stamp; echo "# whole path against the whole oracle (brute-force kNN on all host cores) at other shapes and with graphtools' graph keywords: tools/parity_200k.py"
+  DIMS=100 KNN=15 SEED=4 python tools/parity_200k.py 300000 2>&1 | grep -v amdgpu.ids
   DIMS=20 KNN=5 SEED=3 python tools/parity_200k.py 300000 2>&1 | grep -v amdgpu.ids
-  DIMS=100 KNN=30 SEED=4 python tools/parity_200k.py 150000 2>&1 | grep -v amdgpu.ids
-  DIMS=10 KNN=10 SEED=5 OPTS='{"bandwidth_scale": 0.9}' python tools/parity_200k.py 250000 2>&1 | grep -v amdgpu.ids
-  DIMS=50 KNN=15 SEED=6 OPTS='{"knn_max": 20}' python tools/parity_200k.py 200000 2>&1 | grep -v amdgpu.ids
-  DIMS=30 KNN=12 SEED=7 OPTS='{"kernel_symm": "mnn", "theta": 0.4}' python tools/parity_200k.py 200000 2>&1 | grep -v amdgpu.ids
-  DIMS=3 KNN=15 SEED=8 python tools/parity_200k.py 400000 2>&1 | grep -v amdgpu.ids; } > $out/parity_shapes.txt
+  DIMS=30 KNN=12 SEED=7 OPTS='{"kernel_symm": "mnn", "theta": 0.4}' python tools/parity_200k.py 270000 2>&1 | grep -v amdgpu.ids; } > $out/parity_shapes.txt
 ls -la $out $out/pmc

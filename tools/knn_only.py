@@ -13,7 +13,7 @@ from oracle import meld_oracle as mo
 
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for n in [int(a) for a in sys.argv[1].split(",")]:
-    X, _ = mo.synthetic_cells(n, n_dims=50, seed=0)
+    X, _ = mo.synthetic_cells(n, n_dims=int(os.environ.get("DIMS", "50")), seed=0)
     Xd = torch.from_numpy(X).cuda()
     perm = locality_permutation(Xd)
     if perm is not None:
@@ -28,7 +28,7 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
         ms = ev["knn_topk"][0]
         print({k: round(v[0], 2) for k, v in ev.items()})
         mg.record_events(False)
-    kb = (50 + 3 + 15) // 16
+    kb = (int(os.environ.get("DIMS", "50")) + 3 + 15) // 16
     ideal = (n / 32.0) ** 2 * kb * 32 / 1024 / 2.4e9 * 1e3
     print("pairs listed-and-tested %s, blocks of 32 refs computed in full %s, two_phase %s" % (info.get("wave_tiles_done"), info.get("blocks_past_partial_test"), info.get("two_phase")))
     print("N=%d knn_topk %.2f ms  (hi.hi MFMA stream @2.4GHz %.2f ms, %.1f%%)  stage2 %.2f ms  researched %d  swept %d  env %s" % (

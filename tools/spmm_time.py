@@ -78,3 +78,12 @@ x1 = torch.rand(n, dtype=torch.float64, device="cuda"); z1 = torch.rand(n, dtype
 best, med = timed(lambda: G.ops.lanczos_spmv(G, x1, z1, y1, state, dots), reps)
 print("%-28s lanczos spmv (p=1, fp32 values): best %.1f us median %.1f us" % (tag, best, med), flush=True)
 
+
+# a plain streaming copy of the step's byte count beside it (the yardstick for "what does a byte cost": the PMC passes of
+# tools/pmc_spmm.sh print its counters next to pt_step's): half the bytes read, half written, one torch copy kernel
+byts2 = cheby_bytes_per_step(G.nnz, n, 2)
+src = torch.empty(byts2 // 16, dtype=torch.float64, device="cuda").normal_()
+dst = torch.empty_like(src)
+best, med = timed(lambda: dst.copy_(src), reps)
+print("%-28s plain copy of the p = 2 step's bytes (%d B read + written): best %.1f us median %.1f us  frac(best) %.3f"
+      % (tag, 2 * src.numel() * 8, best, med, 2 * src.numel() * 8 / best / 1e3 / 8000), flush=True)
