@@ -24,7 +24,7 @@ for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "elementwise_kernel" in k and "copy" in k.lower() or "copyBuffer" in k:
+        if "elementwise_kernel" in k and "MulFunctor" in k:
             k = "plain copy (torch)("
         if "pt_step" in k or k.startswith("plain copy"):
             short = k.split("(")[0].replace("void meld::", "")
