@@ -487,9 +487,44 @@ def main():
                                             ms_per_step_whole_fit_transform=1e3 * tc,
                                             note="BASELINE configs[2] (500k x 50): untimed extra pass of this run, X resident")
         del Xc, opc, densc
+        # the reference's own default width: graphtools' n_pca = 100 (forwarded at reference meld/meld.py:117-118) hands the graph
+        # builder 100 principal components -- one extra untimed pass over 1M x 100 cells of the same mixture (a warm-up + one step):
+        # seven K blocks, the principal frame by the library rotation, the same two search passes
+        try:
+            Xw, lw = synthetic_cells(N, n_dims=100, seed=0)
+            Xw = torch.from_numpy(Xw).cuda()
+            opw = None
+            for i in range(2):
+                if i == 1:
+                    torch.cuda.synchronize()
+                    mgraph.record_events(True)
+                opw = meld_amd.MELD(knn=args.knn, beta=args.beta, chebyshev_order=args.order, verbose=0)
+                tw = time.perf_counter()
+                opw.fit_transform(Xw, lw)
+                tw = time.perf_counter() - tw
+            torch.cuda.synchronize()
+            evw = mgraph.event_times_ms()
+            mgraph.record_events(False)
+            iw = opw.graph.info
+            out["roofline_d100"] = {
+                "workload": "1000000 cells x 100 dims (the reference's default n_pca), same mixture, seed 0",
+                "ms_per_step_whole_fit_transform": 1e3 * tw, "cells_per_s_whole_fit_transform": N / tw,
+                "search_filter_ms": float(np.mean(evw["knn_filter"])) if "knn_filter" in evw else None,
+                "search_ms": float(np.mean(evw["knn_topk"])) if "knn_topk" in evw else None,
+                "principal_frame": bool(iw.get("principal_frame")), "two_phase": bool(iw.get("two_phase")),
+                "pairs_listed": iw.get("wave_tiles_done"), "pairs_past_filter": iw.get("pairs_past_filter"),
+                "blocks_past_partial_test": iw.get("blocks_past_partial_test"), "nnz_W": int(opw.graph.nnz),
+                "note": "untimed extra pass of this run (a warm-up + one step), X resident; HIP events around the two search launches",
+            }
+            del Xw, opw
+        except Exception as e:  # (an extra: never the reason a bench line is missing)
+            out["roofline_d100"] = {"error": repr(e)}
+            mgraph.record_events(False)
         # the data dependence of the search on the line: the same step with the exact tile pruning switched off (every
         # 64 x 64 block computed -- what iid data without cluster structure would cost), one untimed step
         os.environ["MELD_KNN_PRUNE"] = "0"
+        dev_was = os.environ.get("MELD_DEV")
+        os.environ["MELD_DEV"] = "1"  # (a development switch: read only under MELD_DEV=1, meld_amd/_options.py)
         opu = None
         try:
             mgraph.record_events(True)
@@ -501,6 +536,10 @@ def main():
             evu = mgraph.event_times_ms()
         finally:
             del os.environ["MELD_KNN_PRUNE"]
+            if dev_was is None:
+                del os.environ["MELD_DEV"]
+            else:
+                os.environ["MELD_DEV"] = dev_was
             mgraph.record_events(False)
         if "knn_topk" in evu and "roofline" in out:
             t_u = float(np.mean(evu["knn_topk"])) * 1e-3

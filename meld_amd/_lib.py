@@ -5,6 +5,8 @@ The product path has no CPU fallback: if the shared library is missing or fails 
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import ctypes as C
 import os
 
@@ -175,7 +177,7 @@ def get_lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("MELD_HIP_LIB") or LIB_PATH  # (development: an alternative build of the same library)
+    path = opt("MELD_HIP_LIB") or LIB_PATH  # (development: an alternative build of the same library)
     if not os.path.exists(path):
         raise ImportError(
             "meld_amd: {} not found. The MI355X HIP extension is mandatory (there is no CPU "

@@ -1,6 +1,8 @@
 """Build libmeld_hip.so in-tree for gfx950 with hipcc (cross-compiles without a GPU)."""
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import os
 import shutil
 import subprocess
@@ -136,9 +138,9 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError("hipcc failed on {}".format(src))
-    if "spmm_tiled.hip" in rebuilt or (force and os.environ.get("MELD_BUILD_SKIP_GATE") != "1"):
+    if "spmm_tiled.hip" in rebuilt or (force and opt("MELD_BUILD_SKIP_GATE") != "1"):
         # the recurrence kernel names physical registers its inline asm owns: checked on the emitted assembly before linking
-        if os.environ.get("MELD_BUILD_SKIP_GATE") != "1":
+        if opt("MELD_BUILD_SKIP_GATE") != "1":
             gate_stream_slots(hipcc, verbose)
     if force or procs or _stale(OUT, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", OUT]

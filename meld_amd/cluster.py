@@ -42,6 +42,8 @@ PCA (``meld_amd.pca``) and a seeded k-means++ / Lloyd KMeans follow (assignment 
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import os
 
 import numpy as np
@@ -407,7 +409,7 @@ class VertexFrequencyCluster:
         # iterate stays ROW-major [npad, R], the matrix is streamed once per product instead of once per column pair (1M cells,
         # 64 probes: 1.0 instead of 3.4 ms per product), one all-gather per product on a sharded graph instead of R / 2, and the
         # local rows are already in the shape the dense algebra of `visit` wants.
-        wide = R > 32 and R <= 64 and hasattr(ops, "cheby_step_wide") and os.environ.get("MELD_VFC_WIDE", "1") != "0"
+        wide = R > 32 and R <= 64 and hasattr(ops, "cheby_step_wide") and opt("MELD_VFC_WIDE", "1") != "0"
         self._fb["spmm"] = "wide" if wide else "pairs"
         if wide:
             def local(T):  # noqa: F811  (row-major iterate [npad, R])

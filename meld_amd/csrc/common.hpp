@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/meld_hip.h"
@@ -53,6 +54,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Development switches of the library (A-B measurements, ablations, counters): read only under MELD_DEV=1, so that a stray
+// variable in a production environment cannot change which kernels run (the same rule as meld_amd/_options.py on the host side)
+static inline const char* meld_dev_getenv(const char* name) {
+  const char* dev = getenv("MELD_DEV");
+  return (dev && dev[0] == '1' && dev[1] == 0) ? getenv(name) : nullptr;
+}
 
 // Device-resident Lanczos on the tiled layout without a scalar kernel between the iterations: the SpMV of iteration k derives its
 // own scalars from the partial sums the axpy of iteration k - 1 left (beta_{k-1} = sqrt(sum nrm2_prev), s_k = 1 / beta_{k-1},

@@ -2500,7 +2500,7 @@ static int k16_bounds_impl(const double* X, int64_t N, int d, const double* mean
   const float ec = (float)meld_knn16_error_coef(1, d);
   const float es = (float)meld_knn16_error_coef(nprod, d);  // the search's allowance: a tile is skipped only if d2_approx < thr fails for sure
   // queries = all the cells: wave w is tile w and the table can be symmetrised (see knn16_bounds_symmetrize_kernel)
-  const bool symmetric = q_begin == 0 && q_count == N && getenv("MELD_KNN_SYMMETRIC_BOUNDS_OFF") == nullptr;
+  const bool symmetric = q_begin == 0 && q_count == N && meld_dev_getenv("MELD_KNN_SYMMETRIC_BOUNDS_OFF") == nullptr;
 #define K16_BOUNDS_LAUNCH(KBV, SD, BTV)                                                                                   \
   hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, SD, BTV>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr,               \
                      reinterpret_cast<const _Float16*>(Rt16), n_t, (int)(q_begin / K16_TS), n_q, ec, norm2_max,           \
@@ -2711,7 +2711,7 @@ __global__ __launch_bounds__(256) void knn16_step_list_bits_kernel(const unsigne
 }
 
 static int k16_two_sided() {  // scan order: own tiles, then alternately forwards / backwards (0 = forwards only; profiling hook)
-  const char* e = getenv("MELD_KNN16_TWO_SIDED");
+  const char* e = meld_dev_getenv("MELD_KNN16_TWO_SIDED");
   return e ? (atoi(e) != 0) : 1;
 }
 
@@ -2774,7 +2774,7 @@ static int k16_step_lists_direct_impl(const double* X, int64_t N, int d, const d
   const float ec = (float)meld_knn16_error_coef(1, d);
   // lead_only (the caller's word that the leading coordinates carry the distances, SPLIT layout only): bounds from K block 0 alone
   const int dA = k16_dA(d, KB);
-  const bool lead = lead_only != 0 && dA > 0 && KB >= 2 && !(getenv("MELD_KNN16_LEAD_BOUNDS") && atoi(getenv("MELD_KNN16_LEAD_BOUNDS")) == 0);
+  const bool lead = lead_only != 0 && dA > 0 && KB >= 2 && !(meld_dev_getenv("MELD_KNN16_LEAD_BOUNDS") && atoi(meld_dev_getenv("MELD_KNN16_LEAD_BOUNDS")) == 0);
 #define K16_BITS_LAUNCH(KBV, BTV)                                                                                          \
   if (lead)                                                                                                                \
     hipLaunchKernelGGL((knn16_tile_bounds_kernel<KBV, true, BTV, true, (KBV >= 2 ? 1 : KBV)>), dim3(gx, gy), dim3(BTV), 0, st, c16, cn, cr, \
@@ -2984,9 +2984,9 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   const int tile_origin = (int)((q_begin / K16_TS) % n_tiles);  // the scan starts at the queries' own position
   // profiling hooks (never set in production): MELD_KNN16_ABLATION=1 distances without selection,
   // =3 MFMAs only; MELD_KNN16_PADLDS=<bytes> extra dynamic LDS to lower the workgroups per CU
-  const char* abl_env = getenv("MELD_KNN16_ABLATION");
+  const char* abl_env = meld_dev_getenv("MELD_KNN16_ABLATION");
   const int abl = abl_env ? atoi(abl_env) : 0;
-  const char* pad_env = getenv("MELD_KNN16_PADLDS");
+  const char* pad_env = meld_dev_getenv("MELD_KNN16_PADLDS");
   const size_t pad_lds = pad_env ? (size_t)atoi(pad_env) : 0;
   const _Float16* q = reinterpret_cast<const _Float16*>(Q16);
   const _Float16* r = reinterpret_cast<const _Float16*>(Rt16);
@@ -2994,13 +2994,13 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   // batched compaction: every 64 tiles, rows with > ksel + 64 entries (with the seeded thresholds the rows fill slowly:
   // 32 / 32, the setting before the seeds, costs 0.9 ms more at 1M cells; none at all 0.4 ms more)
   int batch_every = 64, batch_slack = 64;
-  if (const char* e = getenv("MELD_KNN16_BATCH_EVERY")) {  // profiling hooks (a power of two, or 0 = off)
+  if (const char* e = meld_dev_getenv("MELD_KNN16_BATCH_EVERY")) {  // profiling hooks (a power of two, or 0 = off)
     batch_every = atoi(e);
     MELD_CHECK_ARG(batch_every >= 0 && (batch_every & (batch_every - 1)) == 0, "MELD_KNN16_BATCH_EVERY must be a power of two");
   }
-  if (const char* e = getenv("MELD_KNN16_BATCH_SLACK")) batch_slack = std::max(0, atoi(e));
+  if (const char* e = meld_dev_getenv("MELD_KNN16_BATCH_SLACK")) batch_slack = std::max(0, atoi(e));
   const int two_sided = k16_two_sided();
-  if (getenv("MELD_KNN16_STATS")) {  // profiling hook: selection counters, printed after the launch
+  if (meld_dev_getenv("MELD_KNN16_STATS")) {  // profiling hook: selection counters, printed after the launch
     static unsigned long long* counters[64] = {nullptr};  // (a racing first call leaks 256 B at worst)
     int dev = 0;
     MELD_HIP_CALL(hipGetDevice(&dev));
@@ -3044,13 +3044,13 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   // for it (`partial_test`: it knows whether the leading coordinates carry the distances -- where they do not, the test drops
   // nothing and costs 15 %); MELD_KNN16_EE=0 / 1 overrides the caller, for A-B measurements
   const int dA = k16_dA(d, KB);
-  const char* ee_env = getenv("MELD_KNN16_EE");
+  const char* ee_env = meld_dev_getenv("MELD_KNN16_EE");
   const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
   ka.ee_hi = 16 + d - dA;
   ka.count_go = two_counters;  // (a caller of meld_knn16_topk_listed passes ONE counter, whatever MELD_KNN16_EE forces)
   {
     const int slots_used = dA > 0 ? 16 + (d - dA) + 3 : d + 3;
-    const char* sk = getenv("MELD_KNN16_SKIP_PAD");  // (=0: copy the padding plane as before, for A-B measurements)
+    const char* sk = meld_dev_getenv("MELD_KNN16_SKIP_PAD");  // (=0: copy the padding plane as before, for A-B measurements)
     ka.planes_used = (sk && atoi(sk) == 0) ? 2 * KB : (slots_used + 7) / 8;
   }
 #ifndef K16_PROFILING
@@ -3227,7 +3227,7 @@ extern "C" int meld_knn16_partial_filter(const void* Q16, const float* Qn, const
   const unsigned n_blocks = (unsigned)ceil_div(q_count, K16_BQ);
   int abl = 0;
 #ifdef K16_PROFILING
-  if (const char* e = getenv("MELD_KNN_FILTER_ABL")) abl = atoi(e);
+  if (const char* e = meld_dev_getenv("MELD_KNN_FILTER_ABL")) abl = atoi(e);
 #endif
   hipLaunchKernelGGL((knn16_partial_filter_kernel<8, 4>), dim3(n_blocks), dim3(256), 0, S(stream), reinterpret_cast<const _Float16*>(Q16), Qn,
                      reinterpret_cast<const _Float16*>(Rt16), scale_info, norm2_max, thr_init, step_list, step_cnt, (long long)list_stride, cnt_out,

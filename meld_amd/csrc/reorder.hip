@@ -506,7 +506,7 @@ extern "C" int meld_order_update_keys(uint32_t* key, const int32_t* child, const
 extern "C" int meld_assign_nearest(const double* X, int64_t N, int d, const double* cents, int n_per_group,
                                    const int32_t* group, const int64_t* order, int32_t* out, meld_stream_t stream) {
   MELD_CHECK_ARG(X && cents && out && N > 0 && d > 0 && n_per_group > 0, "meld_assign_nearest: bad arguments");
-  static const bool valu_only = getenv("MELD_ASSIGN") && !strcmp(getenv("MELD_ASSIGN"), "valu");  // (A/B: the FMA kernels)
+  static const bool valu_only = meld_dev_getenv("MELD_ASSIGN") && !strcmp(meld_dev_getenv("MELD_ASSIGN"), "valu");  // (A/B: the FMA kernels)
   if (!valu_only && d <= AS_DMAX && n_per_group <= 64 && (group == nullptr || order != nullptr)) {
     const unsigned grid = (unsigned)ceil_div(N, (int64_t)AM_WG_PTS);
     const int KP = (d + 1) & ~1, nbl = n_per_group <= 32 ? 1 : 2;

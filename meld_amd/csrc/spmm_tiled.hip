@@ -1316,7 +1316,7 @@ extern "C" int meld_pt_build(const int64_t* rowptr, const int32_t* col, const do
   int32_t* seg = const_cast<int32_t*>(layout->seg);
   // plan: by estimated time when the scratch for the weights fits the (not yet written) value stream, by entries otherwise
   {
-    static const bool by_entries = getenv("MELD_PT_PLAN") && !strcmp(getenv("MELD_PT_PLAN"), "entries");
+    static const bool by_entries = meld_dev_getenv("MELD_PT_PLAN") && !strcmp(meld_dev_getenv("MELD_PT_PLAN"), "entries");
     const size_t scan_bytes = meld_scan_temp_bytes(n_rows);
     const size_t off_w = sizeof(int64_t) * (size_t)(n_rows + 1), off_t = (off_w + sizeof(int32_t) * (size_t)n_rows + 255) / 256 * 256;
     if (!by_entries && nb > 1 && off_t + scan_bytes <= sizeof(double) * (size_t)layout->stream_len) {

@@ -20,6 +20,8 @@ tests inject a NumPy stand-in to exercise exactly this communication code under 
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import os
 
 import numpy as np
@@ -59,7 +61,7 @@ class Comm:
             return hit[1]
         handle = None
         try:
-            eligible = dist.get_backend(self.group) == "nccl" and torch.cuda.is_available() and os.environ.get("MELD_SHARDED_C_LOOPS", "1") != "0"
+            eligible = dist.get_backend(self.group) == "nccl" and torch.cuda.is_available() and opt("MELD_SHARDED_C_LOOPS", "1") != "0"
         except Exception:
             eligible = False
         if eligible:
@@ -182,7 +184,7 @@ def exchange_capacity(rows_per_rank, ksel, world, locality=False):
     instead of 256 MB per rank at 8 ranks); without an ordering the entries spread evenly and the capacity is the even
     share of the bound.  An overflow is detected and falls back to the variable-length exchange.
     ``MELD_EXCHANGE_CAP`` overrides (the tests force the fallback with it)."""
-    env = os.environ.get("MELD_EXCHANGE_CAP")
+    env = opt("MELD_EXCHANGE_CAP")
     if env:
         return int(env)
     total = int(rows_per_rank) * int(ksel)
@@ -265,7 +267,7 @@ def build_sharded_graph(X, ops, comm, knn=5, decay=40, thresh=1e-4, anisotropy=1
         comm.all_reduce_sum(tot)
         return rowptr, col, val, dw, ksum_all, [int(v) for v in tot.tolist()]
 
-    fixed = os.environ.get("MELD_EXCHANGE", "fixed") != "variable" and hasattr(ops, "partition_remote") and cap > 0
+    fixed = opt("MELD_EXCHANGE", "fixed") != "variable" and hasattr(ops, "partition_remote") and cap > 0
     rowptr, col, val, dw, ksum_all, (nnz_global, n_flagged, n_over) = assemble(fixed)
     if n_over > 0:  # some rank owed a peer more than the capacity (every rank sees the same total): variable-length exchange
         rowptr, col, val, dw, ksum_all, (nnz_global, n_flagged, _) = assemble(False)

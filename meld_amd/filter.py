@@ -15,6 +15,8 @@ Host code here only evaluates the M+1 scalar coefficients and sequences kernel l
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import os
 
 import numpy as np
@@ -213,10 +215,10 @@ def chebyshev_apply(G, signal, coeffs, lmax):
     if comm is not None:
         comm.all_gather_rows(t_cur, _local(G, t_cur))
     with _EventSpan("cheby_steps", steps=int(c.shape[0] - 2), N=G.N, p=p, nnz=G.nnz):
-        if comm is None and c.shape[0] > 2 and hasattr(ops, "cheby_run") and os.environ.get("MELD_CHEBY_RUN", "1") != "0" \
+        if comm is None and c.shape[0] > 2 and hasattr(ops, "cheby_run") and opt("MELD_CHEBY_RUN", "1") != "0" \
                 and ops.cheby_run(G, p, t_old, t_cur, r, c, 2.0 / a1, -2.0 * a2 / a1):
             return r  # (one call for all the steps; r is read and written every other step only)
-        if comm is not None and c.shape[0] > 2 and hasattr(ops, "cheby_run_sharded") and os.environ.get("MELD_CHEBY_RUN", "1") != "0" \
+        if comm is not None and c.shape[0] > 2 and hasattr(ops, "cheby_run_sharded") and opt("MELD_CHEBY_RUN", "1") != "0" \
                 and ops.cheby_run_sharded(G, p, t_old, t_cur, r, c, 2.0 / a1, -2.0 * a2 / a1) is not None:
             return r  # (row shard on RCCL: kernel + all-gather of every step enqueued from one C call)
         for k in range(2, c.shape[0]):
@@ -329,7 +331,7 @@ def _lanczos_lmax_device(G, ops, u0, tol, max_iter, check_every):
     host = _LanczosHostSide.of(dev, max_iter)
     main = torch.cuda.current_stream(dev)
     ab_d.record_stream(host.side)
-    in_flight = 2 if os.environ.get("MELD_LANCZOS_SPECULATE", "1") != "0" else 1
+    in_flight = 2 if opt("MELD_LANCZOS_SPECULATE", "1") != "0" else 1
     stop = torch.zeros(1, dtype=torch.int32, device=dev)  # set once the check has passed: what is left of the batch in flight is void
     stop.record_stream(host.side)
 
@@ -495,7 +497,7 @@ def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
     max_iter = min(max_iter, G.N)
     if comm is None and hasattr(ops, "lanczos_steps") and G.n_pad == G.N:
         return _lanczos_lmax_device(G, ops, u, tol, max_iter, check_every)
-    if hasattr(ops, "lanczos_fold") and os.environ.get("MELD_LANCZOS_FOLD", "1") != "0":
+    if hasattr(ops, "lanczos_fold") and opt("MELD_LANCZOS_FOLD", "1") != "0":
         return _lanczos_lmax_folded(G, ops, comm, u, tol, max_iter, check_every)
     if hasattr(ops, "lanczos_spmv"):
         return _lanczos_lmax_phases(G, ops, comm, u, tol, max_iter, check_every)
@@ -630,7 +632,7 @@ def filter(signal, graph, filter, beta, offset=0, order=1, solver="chebyshev", c
                 r_orig[perm] = r
             r = r_orig
         # D2H through a pinned staging buffer kept on the graph (pageable copies run at a few GB/s)
-        out = _POOL.lend(r) if (r.is_cuda and os.environ.get("MELD_PINNED_RESULT", "1") != "0") else None
+        out = _POOL.lend(r) if (r.is_cuda and opt("MELD_PINNED_RESULT", "1") != "0") else None
         if out is not None:
             pass
         elif r.is_cuda:

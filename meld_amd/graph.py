@@ -9,6 +9,8 @@ kernels of ``libmeld_hip.so``; torch only owns the device memory and the stream.
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import math
 import os
 import time
@@ -429,29 +431,29 @@ class HipOps:
         # precision of the f16x3 search on the coordinate K blocks: 1 = fp16 hi parts only (half the MFMAs,
         # error bound 2^-9 max|x|^2), 3 = full hi/lo split (2^-16).  Either way the result is exact: rows
         # the bound cannot certify go through the exact sweep.
-        self.nprod = int(os.environ.get("MELD_KNN_NPROD", "1")) if nprod is None else int(nprod)
+        self.nprod = int(opt("MELD_KNN_NPROD", "1")) if nprod is None else int(nprod)
         # exact tile pruning in the f16x3 search: off by default -- on the 10-d-intrinsic benchmark mixture
         # the bounding spheres of 64-cell tiles (radius 0.72) dwarf the neighbour radius (0.63), 98 % of
         # the (workgroup, tile) pairs stay live and the table costs 3 ms; it pays on low-dimensional or
         # well-separated data
-        self.prune = (os.environ.get("MELD_KNN_PRUNE", "1") != "0") if prune is None else bool(prune)
-        self.radius_cut = os.environ.get("MELD_KNN_RADIUS_CUT", "1") != "0"
+        self.prune = (opt("MELD_KNN_PRUNE", "1") != "0") if prune is None else bool(prune)
+        self.radius_cut = opt("MELD_KNN_RADIUS_CUT", "1") != "0"
         # thresholds of the first pass seeded from every row's own block (meld_knn16_seed_thresholds)
-        self.seed = os.environ.get("MELD_KNN_SEED", "1") != "0"
+        self.seed = opt("MELD_KNN_SEED", "1") != "0"
         # per-query test of the pruning table against those seeds (meld_knn16_bounds, thr_seed)
-        self.seeded_bounds = os.environ.get("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
+        self.seeded_bounds = opt("MELD_KNN_SEEDED_BOUNDS", "1") != "0"
         # pruned search: query blocks dispatched by decreasing work (meld_knn16_block_work)
-        self.block_order = os.environ.get("MELD_KNN_BLOCK_ORDER", "1") != "0"
+        self.block_order = opt("MELD_KNN_BLOCK_ORDER", "1") != "0"
         # the first pass walks precomputed step lists (meld_knn16_step_lists) instead of testing the pruning table step by step
-        self.step_lists = os.environ.get("MELD_KNN_STEP_LISTS", "1") != "0"
+        self.step_lists = opt("MELD_KNN_STEP_LISTS", "1") != "0"
         # the search runs in the cells' principal frame where that concentrates the distances in the leading coordinates (the
         # list-driven first pass tests a block behind its first K block: principal_frame)
-        self.rotate = os.environ.get("MELD_KNN_ROTATE", "1") != "0"
+        self.rotate = opt("MELD_KNN_ROTATE", "1") != "0"
         # ... from this many cells on: the frame costs ~0.9 ms whatever the size (a read-back and a 50 x 50 eigenproblem on the host
         # among it) and pays from ~250k cells (200k: 10.0 vs 9.8 ms per step without it; 350k: 14.6 vs 15.4; 500k: 21.0 vs 22.5)
-        self.rotate_min_cells = int(os.environ.get("MELD_KNN_ROTATE_MIN", "262144"))
+        self.rotate_min_cells = int(opt("MELD_KNN_ROTATE_MIN", "262144"))
         # candidate-search kernel: "f16x3" (split-fp16 MFMA) or "f32" (fp32 MFMA)
-        self.search = search or os.environ.get("MELD_KNN_SEARCH", "f16x3")
+        self.search = search or opt("MELD_KNN_SEARCH", "f16x3")
         if self.search not in ("f16x3", "f32"):
             raise ValueError("unknown search kernel {!r}".format(self.search))
         if not torch.cuda.is_available():
@@ -668,10 +670,10 @@ class HipOps:
             elif self.seed and cand_thr is not None and q_begin % BQ == 0 and not cross:
                 # every row starts at the kernel radius its own block of BQ cells implies instead of at +inf
                 seeds = torch.empty(q_pad, dtype=torch.float32, device=dev)
-                if os.environ.get("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
+                if opt("MELD_KNN_SEED", "1") == "2":  # the fp32 kernel over the own block only
                     check(lib.meld_knn16_seed_thresholds(ptr(X_search), N, d, ptr(mean_search), ptr(scale_info), ptr(nmax), q_begin, q_count, knn, rfac, nprod, ptr(seeds), st), "meld_knn16_seed_thresholds")
                 else:
-                    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, int(os.environ.get("MELD_KNN_SEED_SIDE", "0")), ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
+                    check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, int(opt("MELD_KNN_SEED_SIDE", "0")), ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
             if will_prune:
                 # (after the seeds: with them the table also drops the tiles no query of a wave can reach from
@@ -704,9 +706,9 @@ class HipOps:
                 resident_all = lib.meld_knn16_resident_blocks(d, nprod)
                 few_blocks = resident_all > 0 and n_blocks < 2 * resident_all
                 want_lists = self.step_lists and seeds is not None and cand_thr is not None and nprod == 1 \
-                    and not (few_blocks and os.environ.get("MELD_KNN_LIST_SLICES", "1") == "0")
+                    and not (few_blocks and opt("MELD_KNN_LIST_SLICES", "1") == "0")
                 direct = want_lists and seeded_bounds and not spheres_shared and q_begin == 0 and q_count == N and not cross \
-                    and os.environ.get("MELD_KNN_LIST_DIRECT", "1") != "0" and not os.environ.get("MELD_KNN_SYMMETRIC_BOUNDS_OFF")
+                    and opt("MELD_KNN_LIST_DIRECT", "1") != "0" and not opt("MELD_KNN_SYMMETRIC_BOUNDS_OFF")
                 if direct:
                     # queries = all the cells: the lists come straight from the cells (bounds as two bits per (wave, tile); the fp16
                     # table, its symmetrisation pass and the list builder's pass over it never exist)
@@ -745,8 +747,8 @@ class HipOps:
             main_slices = 1
             if will_prune and cand_thr is not None:
                 resident = lib.meld_knn16_resident_blocks(d, nprod)
-                if os.environ.get("MELD_KNN_MAIN_SLICES"):
-                    main_slices = int(os.environ["MELD_KNN_MAIN_SLICES"])
+                if opt("MELD_KNN_MAIN_SLICES"):
+                    main_slices = int(opt("MELD_KNN_MAIN_SLICES"))
                 elif resident > 0 and n_blocks < 2 * resident:
                     main_slices = int(max(1, min(4, lib.meld_knn16_max_slices(ksel), -(-2 * resident // n_blocks), n_tiles // 64)))  # (more slices cost more in merging than they balance)
             # The partial-distance test of the principal frame as a pass of its own (meld_knn16_partial_filter): every listed (wave,
@@ -755,7 +757,7 @@ class HipOps:
             # 30 % of the blocks of a surviving pair still stop behind K block 0).  MELD_KNN_TWO_PHASE=0: the round-5 form, every
             # listed tile staged in full by the one kernel that tests and searches.
             two_phase = (step_list is not None and X_search is not X and seeds is not None
-                         and os.environ.get("MELD_KNN_TWO_PHASE", "1") != "0" and os.environ.get("MELD_KNN16_EE") is None)
+                         and opt("MELD_KNN_TWO_PHASE", "1") != "0" and opt("MELD_KNN16_EE") is None)
             partial_in_search = int(X_search is not X)
             tiles_b = tiles_done
             if two_phase:
@@ -915,7 +917,7 @@ class HipOps:
         # instead of sweeping them one by one (1M cells in the plane, knn = 15: 292k rows through the sweep at
         # ksel = 64, 0.63 s; none at ksel = 128, 32 ms).  Same graph either way.
         if (n_flag_h > max(1024, q_count // 100) and ksel < 128 and search == "f16x3" and not force_fallback
-                and os.environ.get("MELD_KNN_RETRY", "1") != "0"):
+                and opt("MELD_KNN_RETRY", "1") != "0"):
             # (comm is NOT forwarded on purpose: only the ranks that need the retry take it, so it must not issue collectives
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
@@ -1007,8 +1009,8 @@ class HipOps:
 
         M = m_main + fb_total
         assembled = None
-        if assemble and M > 0 and q_begin == 0 and q_count == NR and not cross and os.environ.get("MELD_ASSEMBLE", "bucket") == "bucket" \
-                and os.environ.get("MELD_ASSEMBLE_FUSED", "1") != "0":
+        if assemble and M > 0 and q_begin == 0 and q_count == NR and not cross and opt("MELD_ASSEMBLE", "bucket") == "bucket" \
+                and opt("MELD_ASSEMBLE_FUSED", "1") != "0":
             # single GPU, every row local: the kept candidates go straight into the row buckets of the symmetrisation
             # (meld_coo_emit_scatter) instead of through 2 M (key, value) pairs -- 512 MB written and read back at 1M cells
             B = int(lib.meld_csr_bucket_slots())
@@ -1043,7 +1045,7 @@ class HipOps:
         nprod_used = nprod if search == "f16x3" else self.nprod
         info = dict(ksel=int(ksel), KP=int(KP), search=search, nprod=nprod_used, n_flagged_rows=n_flag_h,
                     # which of the search options (constructor arguments / MELD_KNN_* ablation switches) were in effect
-                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), principal_frame=bool(X_search is not X), two_phase=bool(used_two_phase), seed_side=int(os.environ.get("MELD_KNN_SEED_SIDE", "0")),
+                    prune=bool(used_prune), radius_cut=bool(cand_thr is not None), seed=bool(used_seed), seeded_bounds=bool(used_seeded_bounds), block_order=bool(used_block_order), step_lists=bool(used_step_lists), principal_frame=bool(X_search is not X), two_phase=bool(used_two_phase), seed_side=int(opt("MELD_KNN_SEED_SIDE", "0")),
                     n_rows_bandwidth_recomputed=n_rebandwidth,
                     n_researched_rows=n_flag_stage1 if search == 'f16x3' and nprod_used == 1 else 0, nnz_directed=M,
                     # (wave, tile) pairs the first search pass computed (all of them without pruning)
@@ -1119,7 +1121,7 @@ class HipOps:
         # the free memory -- very large or tightly sharded runs -- the sort path (32 B per entry) is taken instead
         bucket_bytes = n_rows * B * 12
         fits = bucket_bytes <= torch.cuda.mem_get_info(dev)[0] // 4 if n_rows > 0 else True
-        if n > 0 and n_rows > 0 and fits and os.environ.get("MELD_ASSEMBLE", "bucket") != "sort":
+        if n > 0 and n_rows > 0 and fits and opt("MELD_ASSEMBLE", "bucket") != "sort":
             i32 = dict(dtype=torch.int32, device=dev)
             cursor = torch.empty(n_rows, **i32)
             tcol = torch.empty(n_rows * B, **i32)
@@ -1265,7 +1267,7 @@ class HipOps:
         pt = getattr(G, "pt", None)
         if pt is not None:
             return pt if pt is not False else None
-        mode = getattr(self, "spmm", None) or os.environ.get("MELD_SPMM", "auto")
+        mode = getattr(self, "spmm", None) or opt("MELD_SPMM", "auto")
         G.info["spmm"] = "csr"
         G.pt = False
         if mode == "csr" or G.n_rows == 0 or G.nnz == 0 or not G.val.is_cuda:
@@ -1295,7 +1297,7 @@ class HipOps:
         codes = torch.empty(G.nnz, **i32)  # scratch of the builder
         # in-block pairs are stored once (W symmetric); the builder verifies the symmetry of every block's own
         # square and reports status 5 otherwise (a weight matrix uploaded from elsewhere): built again unfolded
-        fold = os.environ.get("MELD_SPMM_FOLD", "1") != "0"
+        fold = opt("MELD_SPMM_FOLD", "1") != "0"
         for symmetric in ((1, 0) if fold else (0,)):
             with _EventSpan("pt_build", N=G.N, nnz=G.nnz):
                 check(lib.meld_pt_build(ptr(G.rowptr), ptr(G.col), ptr(G.val), G.n_rows, G.n_pad, G.row_begin, symmetric,

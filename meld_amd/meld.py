@@ -9,6 +9,8 @@ GPU: graph construction (``meld_amd.graph.build_knn_graph``) and the Chebyshev f
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 from functools import partial
 
 import os
@@ -501,7 +503,7 @@ class MELD(GraphEstimator):
         try:
             raw = np.asarray(getattr(sample_labels, "values", sample_labels))
             if eligible and (raw.ndim == 1 or (raw.ndim == 2 and raw.shape[1] == 1)) and raw.shape[0] >= self._DEVICE_FACTORIZE_MIN \
-                    and torch.cuda.is_available() and os.environ.get("MELD_LABEL_OVERLAP", "1") != "0":
+                    and torch.cuda.is_available() and opt("MELD_LABEL_OVERLAP", "1") != "0":
                 from . import graph as _graph
 
                 dev = torch.device("cuda", torch.cuda.current_device())

@@ -13,6 +13,8 @@ only memory locality and the cost of the search change.
 """
 from __future__ import annotations
 
+from ._options import is_set, opt
+
 import math
 import os
 
@@ -66,8 +68,8 @@ def locality_permutation(X, c1=None, fanouts=None, seed=0, comm=None):
         return None
     import os
 
-    if os.environ.get("MELD_REORDER"):  # tuning hook: "c1,f1,f2,..."
-        parts = [int(v) for v in os.environ["MELD_REORDER"].split(",")]
+    if opt("MELD_REORDER"):  # tuning hook: "c1,f1,f2,..."
+        parts = [int(v) for v in opt("MELD_REORDER").split(",")]
         c1, fanouts = parts[0], tuple(parts[1:])
     st = torch.cuda.current_stream().cuda_stream
     dev = X.device

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the tests force paths the product no longer takes by default (MELD_KNN_ROTATE_MIN, MELD_KNN16_EE, MELD_ASSEMBLE ...): development
+# switches, read only under MELD_DEV=1 (meld_amd/_options.py); worker processes inherit it
+os.environ.setdefault("MELD_DEV", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

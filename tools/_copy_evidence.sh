@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # gpurun_out/prof_<tag>/* -> profiles/<tag>_* (the names the round's documents cite): bash tools/_copy_evidence.sh r05
 tag=${1:-r05}; src=gpurun_out/prof_$tag
 cp $src/bench_1000000.json profiles/${tag}_bench_1M_line.json; cp $src/bench_500000.json profiles/${tag}_bench_500k_line.json

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # Evidence set of a round, all from ONE build (run on the GPU box; .git does not travel, so the commit is passed in):
 #   gpurun -- 'bash tools/_profile_round.sh r03 <commit> [quick]'
 # bench lines + rocprofv3 kernel traces at 1M (the metric's size) and 500k (C3), fabric traffic (PMC) of the hot kernels,

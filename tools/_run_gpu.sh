@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # What the round-end checks run on the GPU box: gpurun -- 'bash tools/_run_gpu.sh'
 mkdir -p gpurun_out/check
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # stage timers of one bench run under the given environment: bash tools/_stages.sh [VAR=val ...]
 env "$@" python bench.py --steps 8 --warmup 3 --cpu-sample 0 --no-host-input --no-extra --stages 2>&1 | tail -1 | python -c "
 import json,sys

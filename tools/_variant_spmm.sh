@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # recurrence step time at several sizes with variant builds of the library: bash tools/_variant_spmm.sh nont ...
 cp meld_amd/libmeld_hip.so /tmp/libmeld_hip_base.so
 for v in base "$@"; do

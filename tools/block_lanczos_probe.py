@@ -2,6 +2,7 @@
 python tools/block_lanczos_probe.py [N] [b]   (plain torch arithmetic, sparse matmul of the library: an iteration count, not a timing)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from meld_amd.filter import lanczos_lmax

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # Build a variant of the library from one re-compiled source: bash tools/build_variant.sh <name> <source.hip> <extra hipcc flags...>
 # -> meld_amd/libmeld_hip_<name>.so (other objects are taken from meld_amd/build/ as they are)
 set -e

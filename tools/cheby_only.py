@@ -1,6 +1,7 @@
 """Build a graph once and time the Chebyshev recurrence only: python tools/cheby_only.py N [reorder]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from meld_amd import graph as mg

@@ -1,6 +1,7 @@
 """One-off fuzz of the graph builder against the oracle on small awkward inputs.  python tools/fuzz_graph.py [n_cases] [seed]"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from scipy import sparse
 import meld_amd

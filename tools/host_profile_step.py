@@ -1,6 +1,7 @@
 """Where the HOST time of one fit_transform goes (cProfile, 1M cells): python tools/host_profile_step.py [N]"""
 import os, sys, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch, meld_amd
 from bench import synthetic_cells
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

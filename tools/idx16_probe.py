@@ -5,6 +5,7 @@ what it did and what it measured is in profiles/r05_idx16_probe.txt); on the pro
 python tools/idx16_probe.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from meld_amd.graph import HipOps

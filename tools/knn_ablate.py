@@ -3,6 +3,7 @@ timing-only ablations of the kernel with realistic pruning (MELD_KNN16_ABLATION:
 9 = no tile loads).   python tools/knn_ablate.py [N]"""
 import os, sys, math, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd._lib import get_lib, ptr, check
 from meld_amd.reorder import locality_permutation

@@ -4,6 +4,7 @@ residual^2 / gap (gap = theta_1 - theta_2 of the k x k tridiagonal) and the TRUE
 python tools/lmax_rule.py [N ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from scipy.linalg import eigh_tridiagonal
 import meld_amd

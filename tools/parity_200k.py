@@ -2,6 +2,7 @@
 python tools/parity_200k.py [N]      (other shapes / options: DIMS=20 KNN=5 SEED=3 OPTS='{"bandwidth_scale": 0.9}')"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np
 from scipy import sparse
 import meld_amd

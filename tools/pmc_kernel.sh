@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # L2 / fabric counters of every kernel whose name matches a pattern, over one search stage (run on the GPU box):
 #   [CMD="python tools/time_wide.py"] bash tools/pmc_kernel.sh <pattern> [N]
 pat=${1:-refine_kernel}; N=${2:-1000000}; out=/tmp/pmc_kernel; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # PMC passes over the candidate-search kernel (run on the GPU box): tools/pmc_knn.sh <outdir> [N]
 # One rocprofv3 run per counter set (counters only, no tracing domains besides --kernel-trace).
 out=${1:-gpurun_out/pmc_knn}; N=${2:-1000000}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MELD_DEV=1   # (development switches are read only under MELD_DEV=1: meld_amd/_options.py)
 # PMC passes over the recurrence kernel (run on the GPU box): tools/pmc_spmm.sh <outdir> [N] [ablate-mask]
 # One rocprofv3 run per counter set (counters + kernel trace only).  Prints per-dispatch averages per kernel.
 out=${1:-gpurun_out/pmc_spmm}; N=${2:-1000000}; AB=${3:-0}

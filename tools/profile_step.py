@@ -2,6 +2,7 @@
 python tools/profile_step.py [N]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch
 import meld_amd
 from bench import synthetic_cells

@@ -2,6 +2,7 @@
 can hold of a wide iterate decides how often the wide recurrence step re-reads it: python tools/row_locality.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch, meld_amd
 from bench import synthetic_cells
 N = 1_000_000

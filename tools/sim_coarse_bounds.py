@@ -2,6 +2,7 @@
 dead if |c_t - C_g| - rho_t - R_g > max seed radius of the tile's cells.   python tools/sim_coarse_bounds.py [N]"""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd._lib import get_lib, ptr, check
 from meld_amd.reorder import locality_permutation

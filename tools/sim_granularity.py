@@ -5,6 +5,7 @@ ball test against the seeds AND the transposed ball test against the wave's larg
 python tools/sim_granularity.py [N] [n_waves]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from bench import synthetic_cells

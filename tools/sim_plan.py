@@ -7,6 +7,7 @@ previous plan (what a two-pass build could do), each with RMAX = 4080 and larger
 python tools/sim_plan.py graph.pt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch
 
 d = torch.load(sys.argv[1])

@@ -3,6 +3,7 @@ locality order) count the reference tiles a rule keeps, against the tiles that r
 python tools/sim_prune_rules.py [N] [n_waves]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from bench import synthetic_cells

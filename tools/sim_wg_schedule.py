@@ -3,6 +3,7 @@ pruning table and the final thresholds); list scheduling over the resident slots
 python tools/sim_wg_schedule.py   (after tools/knn_ablate.py's setup; 1M cells)"""
 import os, sys, math, heapq
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 os.environ["MELD_KNN16_ABLATION"] = "99"   # (makes knn_ablate stop after its setup + one product run)
 import numpy as np, torch
 src = open(os.path.join(os.path.dirname(__file__), "knn_ablate.py")).read().split("abl = os.environ.get")[0]

@@ -3,6 +3,7 @@ Prints the layout build time, us per Chebyshev step and algorithmic GB/s (SURVEY
 the Lanczos SpMV (p = 1) too, and the maximum difference of the results."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from meld_amd import graph as mg

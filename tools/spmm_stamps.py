@@ -2,6 +2,7 @@
 (meld_pt_debug_stamps): python tools/spmm_stamps.py graph.pt [p]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd.graph import DeviceGraph, HipOps
 from meld_amd._lib import get_lib, ptr

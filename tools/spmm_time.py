@@ -2,6 +2,7 @@
 python tools/spmm_time.py graph.pt [reps]   -> one line per kernel; results checked against the CSR-stream kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd.graph import DeviceGraph, HipOps
 from bench import cheby_bytes_per_step

@@ -1,6 +1,7 @@
 """Step-to-step spread of fit_transform at the benchmark size: python tools/step_jitter.py [steps]  (env toggles of the product)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from bench import synthetic_cells

@@ -1,6 +1,7 @@
 """How many steps until fit_transform reaches its steady time, and what the allocator does meanwhile: python tools/step_warmup.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 import meld_amd
 from bench import synthetic_cells

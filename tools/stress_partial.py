@@ -2,6 +2,7 @@
 same bandwidths.  python tools/stress_partial.py [reps] [d,d,...]     (the regression this guards: tests/test_gpu_partial_search.py)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 os.environ.setdefault("MELD_KNN_ROTATE_MIN", "0")  # (the product takes the frame from 262144 cells on)
 from meld_amd.graph import HipOps

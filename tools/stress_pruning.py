@@ -2,6 +2,7 @@
 the graph of the plain search (no pruning, no seeds) bit for bit.  python tools/stress_pruning.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd.graph import HipOps
 from meld_amd.reorder import locality_permutation

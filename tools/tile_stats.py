@@ -9,6 +9,7 @@ LDS), dense tiles per block, distinct columns per block.  Optionally dumps the s
 65536 rows (columns clipped to it) for offline ordering experiments."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np
 import torch
 import meld_amd

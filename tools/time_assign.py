@@ -1,6 +1,7 @@
 """Time meld_assign_nearest alone (level 0 of the ordering: N x 64 centroids): python tools/time_assign.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from meld_amd._lib import check, get_lib, ptr
 from bench import synthetic_cells

@@ -1,6 +1,7 @@
 """Time the lmax estimate and the layout build on a saved graph: python tools/time_lmax.py graph.pt"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch
 from meld_amd.graph import DeviceGraph, HipOps
 

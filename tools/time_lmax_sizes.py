@@ -2,6 +2,7 @@
 python tools/time_lmax_sizes.py [N ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch, meld_amd
 from bench import synthetic_cells
 for N in [int(a) for a in sys.argv[1:]] or [1_000_000, 500_000]:

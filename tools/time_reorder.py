@@ -1,6 +1,7 @@
 """Where the locality permutation spends its time: python tools/time_reorder.py [N] (env MELD_REORDER)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch
 from meld_amd import reorder as ro
 from bench import synthetic_cells

@@ -1,6 +1,7 @@
 """Where the principal-frame rotation of the search stage spends its time (1M x 50)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch
 from bench import synthetic_cells
 from meld_amd.graph import HipOps, _stream

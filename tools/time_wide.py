@@ -1,6 +1,7 @@
 """The wide (lanes = columns) recurrence step against p / 2 launches of the two-column kernel: python tools/time_wide.py [N] [p]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import torch, meld_amd
 from meld_amd import filter as mf
 from bench import synthetic_cells

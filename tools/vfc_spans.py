@@ -1,6 +1,7 @@
 """Distribution of the SpMM spans inside a filter-bank VertexFrequencyCluster fit at 1M cells: python tools/vfc_spans.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MELD_DEV", "1")  # (development tool: the MELD_* switches it sets or documents are read, see meld_amd/_options.py)
 import numpy as np, torch, meld_amd
 from meld_amd import graph as mg
 from bench import synthetic_cells
