@@ -262,3 +262,30 @@ def test_graph_option_validation_on_the_host():
         assert meld_amd.MELD(distance=name, verbose=0).distance == name
     with pytest.raises(ValueError):
         meld_amd.MELD(distance="precomputed_nonsense")
+
+
+def test_development_switches_need_meld_dev(monkeypatch):
+    """meld_amd/_options.py: the eight public options are read from the environment as they are; every other MELD_* switch keeps its
+    default unless MELD_DEV=1 (a stray variable in a production environment cannot change which kernels run)."""
+    from meld_amd import _options as mo
+
+    monkeypatch.setenv("MELD_KNN_PRUNE", "0")
+    monkeypatch.setenv("MELD_SPMM", "csr")
+    monkeypatch.setenv("MELD_DEV", "0")
+    assert mo.opt("MELD_KNN_PRUNE", "1") == "1" and not mo.is_set("MELD_KNN_PRUNE")
+    assert mo.opt("MELD_SPMM", "auto") == "csr"  # (public)
+    monkeypatch.setenv("MELD_DEV", "1")
+    assert mo.opt("MELD_KNN_PRUNE", "1") == "0" and mo.is_set("MELD_KNN_PRUNE")
+    assert len(mo.PUBLIC) <= 8
+    # no module of the package reads a MELD_* variable behind the options module's back
+    import os
+    import re
+
+    root = os.path.dirname(os.path.abspath(mo.__file__))
+    for f in sorted(os.listdir(root)):
+        if f.endswith(".py") and f != "_options.py":
+            txt = open(os.path.join(root, f)).read()
+            assert not re.search(r"os\.environ(\.get\(|\[)\s*\"MELD_", txt), f
+    for f in sorted(os.listdir(os.path.join(root, "csrc"))):
+        txt = open(os.path.join(root, "csrc", f)).read()
+        assert not re.search(r"(?<![_a-z])getenv\(\"MELD_(?!DEV\")", txt), f
