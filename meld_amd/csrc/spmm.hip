@@ -517,61 +517,12 @@ __global__ __launch_bounds__(256) void cheby_step_wide_kernel(const int64_t* __r
   flush_rows_until(E1 + 1);  // the rows that are left (the last one, and rows without entries)
 }
 
-// The same step on a PANEL of 16 columns of the row-major signal (columns col0 .. col0 + 15 of ld): four rows per wave at a time,
-// lane (g, c) = row group g = lane / 16, column c = lane % 16.  Round 6: the 64-column kernel above reads the iterate 3.6 x (10.8 GB
-// of fabric traffic per product at 1M cells against 3.0 GB algorithmic, L2 hit rate 0.53): 1M rows x 64 columns x 8 B = 512 MB do not fit
-// the 256 MiB Infinity Cache, so the gathers of a row's ~39 neighbours miss it.  A panel of 16 columns is 128 MB of iterate -- one
-// 128-byte line per neighbour, the same bytes per gather -- and stays on die while the matrix (473 MB, read once per panel with `nt`
-// so that it does not evict the panel) streams past: four passes over the matrix, ~1 x over the iterate.
-// A group's 16 lanes load the SAME (value, column) pair of their row (one address per group: the TA serves it as one request), eight
-// pairs and eight gathers in flight per lane; rows of different length in one wave: the loop runs to the longest, the others idle.
-constexpr int WP_COLS = 16;   // columns of a panel
-constexpr int WP_U = 8;       // entries in flight per lane
-constexpr int WP_ROWS = 8;    // rows per group and wave (32 rows per wave, interleaved over the four groups)
-__global__ __launch_bounds__(256) void cheby_step_wide_panel_kernel(const int64_t* __restrict__ rowptr, const int* __restrict__ col,
-                                                                    const double* __restrict__ val, const double* __restrict__ dw,
-                                                                    int64_t n_rows, int ld, int col0, const double* __restrict__ x_full,
-                                                                    int64_t x_row_offset, const double* z, double* y, double alpha,
-                                                                    double beta, double gamma) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  const int nb = gridDim.x;
-  const int per = (nb + 7) >> 3;  // XCD-contiguous workgroups, as above
-  const int64_t rb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (rb >= nb) return;
-  const int64_t row_first = (rb * 4 + wv) * (4 * WP_ROWS);
-  if (row_first >= n_rows) return;  // (uniform)
-  const double* xp = x_full + col0 + c;
-#pragma unroll 1
-  for (int i = 0; i < WP_ROWS; ++i) {
-    const int64_t row = row_first + 4 * i + g;
-    const bool valid = row < n_rows;
-    const int64_t e0 = valid ? rowptr[row] : 0, e1 = valid ? rowptr[row + 1] : 0;
-    int len = (int)(e1 - e0), maxlen = len;
-#pragma unroll
-    for (int off = 32; off >= 16; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));  // (over the four groups)
-    const double xi = valid ? xp[(x_row_offset + row) * ld] : 0.0;
-    const double zi = (valid && gamma != 0.0) ? __builtin_nontemporal_load(z + row * ld + col0 + c) : 0.0;
-    double acc = 0.0;
-    for (int k = 0; k < maxlen; k += WP_U) {
-      int cc[WP_U];
-      double vv[WP_U], xv[WP_U];
-#pragma unroll
-      for (int u = 0; u < WP_U; ++u) {
-        const bool ok = k + u < len;
-        const int64_t e = ok ? e0 + k + u : 0;
-        cc[u] = ok ? __builtin_nontemporal_load(col + e) : 0;
-        vv[u] = ok ? __builtin_nontemporal_load(val + e) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < WP_U; ++u) xv[u] = xp[(int64_t)cc[u] * ld];
-#pragma unroll
-      for (int u = 0; u < WP_U; ++u) acc = fma(vv[u], xv[u], acc);
-    }
-    if (valid) __builtin_nontemporal_store(alpha * (dw[row] * xi - acc) + beta * xi + gamma * zi, y + row * ld + col0 + c);
-  }
-}
-
+// (Round 6, measured and not kept: the same step on PANELS of 16 columns -- four rows per wave, lane = (row group, column), one launch
+// per panel so that the 128 MB of iterate a launch gathers from stay in the 256 MiB Infinity Cache, the matrix streamed `nt` once per
+// panel.  Same results (1.9e-16), 4.89 ms per 64-column product against 1.89 ms for the kernel above.  The gathers move nnz x 8 B x p
+// through the L2s whatever the panel width -- 20 GB per product, of which the L2s absorb half -- and what caps them is the L2 <-> fabric
+// rate (~6.3 TB/s: the rate of a copy, wherever the bytes come from), not HBM: keeping the iterate in the Infinity Cache does not lift
+// it, and four passes add 1.4 GB of matrix.  The lever is the L2 hit rate, i.e. the row order, as round 5's window measurements said.)
 }  // namespace meld
 
 using namespace meld;
@@ -585,21 +536,6 @@ extern "C" int meld_cheby_step_wide(const int64_t* rowptr, const int32_t* col, c
   MELD_CHECK_ARG(rowptr && col && val && dw && x_full && y && n_rows >= 0 && p >= 1 && p <= 64, "meld_cheby_step_wide: bad arguments (1 <= p <= 64)");
   MELD_CHECK_ARG(gamma == 0.0 || z != nullptr, "meld_cheby_step_wide: z is required when gamma != 0");
   if (n_rows == 0) return MELD_OK;
-  {
-    // whole panels of 16 columns: one launch per panel, so that the iterate a launch gathers from (128 MB per panel at 1M cells)
-    // stays in the Infinity Cache (cheby_step_wide_panel_kernel); MELD_WIDE_PANELS=0 (development): the 64-column kernel
-    const char* pe = meld_dev_getenv("MELD_WIDE_PANELS");
-    if (p % WP_COLS == 0 && p >= 2 * WP_COLS && !(pe && atoi(pe) == 0)) {
-      const int64_t nblk_p = ceil_div(n_rows, 4 * 4 * WP_ROWS);
-      const unsigned grid_p = (unsigned)(ceil_div(nblk_p, 8) * 8);
-      for (int c0 = 0; c0 < p; c0 += WP_COLS) {
-        hipLaunchKernelGGL(cheby_step_wide_panel_kernel, dim3(grid_p), dim3(256), 0, S(stream), rowptr, col, val, dw, n_rows, p, c0, x_full,
-                           x_row_offset, z, y, alpha, beta, gamma);
-        MELD_LAUNCH_CHECK("cheby_step_wide_panel_kernel");
-      }
-      return MELD_OK;
-    }
-  }
   const int64_t nblk = ceil_div(n_rows, 4 * WIDE_ROWS);
   const unsigned grid = (unsigned)(ceil_div(nblk, 8) * 8);
   // (profiling hook, never set in production: MELD_WIDE_PADLDS=<bytes> of unused dynamic LDS lowers the workgroups per CU, i.e. the

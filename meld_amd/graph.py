@@ -756,7 +756,11 @@ class HipOps:
             # then stages whole tiles for the quarter of the pairs that survive (it keeps its own test per block of 32 references:
             # 30 % of the blocks of a surviving pair still stop behind K block 0).  MELD_KNN_TWO_PHASE=0: the round-5 form, every
             # listed tile staged in full by the one kernel that tests and searches.
+            # (few query blocks -- a row shard, a mid-sized data set: main_slices > 1 -- keep the one-kernel form: a workgroup of the
+            # filter pass walks its block's whole list, and a launch that fills the chip less than twice over ends when its longest
+            # list does -- a 1/8 shard of 1M cells: 2.4-3.0 ms for the filter alone against 3.0 ms for the sliced search)
             two_phase = (step_list is not None and X_search is not X and seeds is not None
+                         and (main_slices == 1 or opt("MELD_KNN_TWO_PHASE") == "2")
                          and opt("MELD_KNN_TWO_PHASE", "1") != "0" and opt("MELD_KNN16_EE") is None)
             partial_in_search = int(X_search is not X)
             tiles_b = tiles_done
