@@ -3072,11 +3072,11 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   do {                               \
     if (step_list != nullptr) {      \
       K16_DEV_LIST_ABL(KBV)          \
-      if (ee && KBV >= 2 && KBV <= 6) { /* (beyond six K blocks the variant spills; the frame kernels stop at d = 64 anyway) */ \
+      if (ee && KBV >= 2 && KBV <= 7) { /* (seven K blocks: d = 100, the reference's default n_pca; eight and nine are not instantiated) */ \
         if (stats != nullptr)        \
-          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 6) ? KBV : 2), 2, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 7) ? KBV : 2), 2, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
         else                         \
-          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 6) ? KBV : 2), 0, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
+          hipLaunchKernelGGL((knn16_topk_kernel<((KBV >= 2 && KBV <= 7) ? KBV : 2), 0, 1, true, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
       } else if (stats != nullptr)   \
         hipLaunchKernelGGL((knn16_topk_kernel<KBV, 2, 1, true>), grid, dim3(K16_THREADS), pad_lds, S(stream), ka); \
       else                           \

@@ -915,8 +915,8 @@ class HipOps:
         tiles_done_h = int(heads_h[2]) if tiles_done is not None else None
         blocks_on_h = int(heads_h[3]) if tiles_done is not None and X_search is not X else None
         pairs_kept_h = int(heads_h[4]) if tiles_done is not None and used_two_phase else None  # (wave, tile) pairs the filter pass left to the search
-        if pairs_kept_h is not None and lib.meld_knn16_kblocks(d) > 6:
-            blocks_on_h = 2 * pairs_kept_h  # (beyond six K blocks the search behind the filter has no test of its own: both blocks of every pair it is handed)
+        if pairs_kept_h is not None and lib.meld_knn16_kblocks(d) > 7:
+            blocks_on_h = 2 * pairs_kept_h  # (beyond seven K blocks the search behind the filter has no test of its own: both blocks of every pair it is handed)
 
         # Many uncertified rows with a short candidate list (dense low-dimensional data: more than ksel cells
         # inside the radius inflated by the search-error allowance): search once more with the longest list

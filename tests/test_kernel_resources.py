@@ -38,9 +38,16 @@ def test_search_kernels_do_not_spill():
     product = {k: v for k, v in rows.items() if "knn16_topk_kernelILi" in k and "ELi0ELi" in k}  # ABL = 0
     # KB = 1..9 x NPROD in {1, 3}, table-driven (LIST = false) + KB = 1..9 list-driven hi-only first pass (LIST = true) + KB = 2..6
     # the same with the partial test behind the first K block (EE = true)
-    assert len(product) == 32, sorted(product)  # (round 6: KB = 7 of the partial-test kernel is served by the two-pass route)
-    assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 5, sorted(product)
+    # KB = 1..9 x NPROD in {1, 3}, table-driven + KB = 1..9 list-driven + KB = 2..7 with the partial test (round 6: seven K blocks, d = 100)
+    assert len(product) == 33, sorted(product)
+    assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 6, sorted(product)
     for name, r in product.items():
+        if "ILi7ELi0ELi1ELb1ELb1E" in name:
+            # seven K blocks with the partial test: 22 scalar registers spill past the vector lanes kept for them into 36 bytes of
+            # scratch (loop-invariant values, reloaded outside the tile loop); measured 15.6 against 16.8 ms for the kernel without the
+            # test at 1M x 100 -- kept, bounded here
+            assert r["ScratchSize [bytes/lane]:"] <= 64, (name, r)
+            continue
         assert r["ScratchSize [bytes/lane]:"] == 0, (name, r)
     # the benchmark configuration (d = 50: KB = 4, hi-only first pass) keeps three waves per SIMD on the table- and list-driven kernels,
     # four on the two-tile partial-test pass (whose LDS -- two buffers of two tiles + the ranking scratch -- is a quarter of a CU's)
