@@ -184,6 +184,7 @@ def test_whole_path_against_the_oracle_digest(full):
     assert pre + "nnz" in g.files, "no oracle digest for {} cells in {}".format(n, path)
     G = op.graph
     assert G.info["principal_frame"] and G.info["step_lists"] and G.info["blocks_past_partial_test"] is not None
+    assert G.info["two_phase"] and 0 < G.info["pairs_past_filter"] < G.info["wave_tiles_done"]  # (the filter pass + the search behind it)
     assert G.info["blocks_past_partial_test"] < 2 * G.info["wave_tiles_done"]
     W = sparse.csr_matrix(G.W)
     W.sort_indices()

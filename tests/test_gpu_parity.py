@@ -137,24 +137,32 @@ def test_graph_matches_oracle(n, d, knn):
     np.testing.assert_allclose(DG.bandwidth_host, G.info["bandwidth"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("two_pass", [False, True], ids=["one-kernel", "filter+search"])
 @pytest.mark.parametrize("n,d,knn", [(20000, 50, 15), (24000, 14, 10), (24000, 58, 10), (33555, 32, 5), (40000, 100, 15)])
-def test_graph_in_the_principal_frame_matches_oracle(n, d, knn, monkeypatch):
+def test_graph_in_the_principal_frame_matches_oracle(n, d, knn, two_pass, monkeypatch):
     """A2-A5 on the kernel that carries the headline -- the list-driven first pass in the cells' principal frame with the
     partial-distance test behind the first K block (``knn16_topk_kernel<.., LIST, EE>``; the product takes it from 262144 cells
     on, ``MELD_KNN_ROTATE_MIN=0`` asks for it here) -- against the ORACLE itself (brute-force kNN, [UPSTREAM graphtools
     ``build_kernel_to_data``] as restated at oracle/meld_oracle.py, reached from reference meld/meld.py:273), not against this
     library's plain path: W, K (CSR, canonical order), degrees and bandwidths.  Shapes: C2's width; one and four K blocks' worth
     of coordinates behind K block 0 (d = 14, 58); an odd number of K blocks searched in reference slices (33555 x 32, the shape
-    of round 5's staging bug); the reference's default width n_pca = 100."""
+    of round 5's staging bug); the reference's default width n_pca = 100.  Both forms of the pass: the one kernel that tests and
+    searches (what launches with few query blocks take, reference slices included) and the round-6 pair -- the list-filter pass
+    (``meld_knn16_partial_filter``) + the search over the thinned lists -- which the product takes from ~400 000 cells on and
+    ``MELD_KNN_TWO_PHASE=2`` asks for at these sizes (sliced search over thinned lists included)."""
     mo = _oracle()
     import meld_amd
 
     monkeypatch.setenv("MELD_KNN_ROTATE_MIN", "0")
+    monkeypatch.setenv("MELD_KNN_TWO_PHASE", "2" if two_pass else "0")
     X, _ = mo.synthetic_cells(n, n_dims=d, seed=7)
     G = mo.build_graph(X, knn=knn, decay=40, thresh=1e-4, anisotropy=1, algorithm="brute", n_jobs=-1)
     DG = meld_amd.build_knn_graph(torch.from_numpy(X).cuda(), knn=knn, decay=40, thresh=1e-4, anisotropy=1)
     info = DG.info
     assert info["principal_frame"] and info["step_lists"] and info["prune"], info
+    assert bool(info["two_phase"]) == two_pass, info
+    if two_pass:
+        assert 0 < info["pairs_past_filter"] < info["wave_tiles_done"]  # the filter pass dropped pairs, and not all of them
     assert info["blocks_past_partial_test"] is not None
     assert info["blocks_past_partial_test"] < 2 * info["wave_tiles_done"]  # the test dropped something
     _csr_close(DG.W, G.W, rtol=1e-9)

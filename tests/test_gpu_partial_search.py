@@ -66,7 +66,12 @@ def test_graph_does_not_depend_on_the_frame_or_the_partial_test(kind, d, monkeyp
     monkeypatch.setenv("MELD_KNN16_EE", "1")
     c, _ = _graph(ops_b, Xd)
     monkeypatch.delenv("MELD_KNN16_EE")
-    for other in (a, b, c):
+    # (e) the two-pass form (list-filter pass + search over the thinned lists), which launches this small do not take by themselves
+    monkeypatch.setenv("MELD_KNN_TWO_PHASE", "2")
+    e, info_e = _graph(HipOps(), Xd)
+    monkeypatch.delenv("MELD_KNN_TWO_PHASE")
+    assert info_e["two_phase"] and not info["two_phase"] and 0 < info_e["pairs_past_filter"] < info_e["wave_tiles_done"]
+    for other in (a, b, c, e):
         for u, v in zip(base, other):
             assert torch.equal(u, v)
 

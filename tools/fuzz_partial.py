@@ -48,14 +48,17 @@ for c in range(n_cases):
           os.environ["MELD_KNN16_EE"] = "0"; ref, _ = graph(plain, Xd, knn, decay, thresh)
           os.environ["MELD_KNN16_EE"] = "1"; forced, i1 = graph(plain, Xd, knn, decay, thresh)
           del os.environ["MELD_KNN16_EE"]; framed, i2 = graph(HipOps(), Xd, knn, decay, thresh)
-          ok = all(torch.equal(a, b) for a, b in zip(ref, forced)) and all(torch.equal(a, b) for a, b in zip(ref, framed))
+          # (round 6) the two-pass form -- list-filter pass + search over the thinned lists -- forced at these sizes
+          os.environ["MELD_KNN_TWO_PHASE"] = "2"; two, i3 = graph(HipOps(), Xd, knn, decay, thresh); del os.environ["MELD_KNN_TWO_PHASE"]
+          ok = all(torch.equal(a, b) for a, b in zip(ref, forced)) and all(torch.equal(a, b) for a, b in zip(ref, framed)) \
+              and all(torch.equal(a, b) for a, b in zip(ref, two)) and (bool(i3["two_phase"]) == bool(i3["principal_frame"]))
           print("%s %s  nnz %d  past the test: forced %s, framed %s (frame %s)" % ("ok " if ok else "BAD", tag, int(ref[1].numel()),
                 "%.3f" % (i1["blocks_past_partial_test"] / (2.0 * i1["wave_tiles_done"])) if i1.get("blocks_past_partial_test") is not None else "-",
                 "%.3f" % (i2["blocks_past_partial_test"] / (2.0 * i2["wave_tiles_done"])) if i2.get("blocks_past_partial_test") is not None else "-",
-                i2["principal_frame"]), flush=True)
+                i2["principal_frame"]) + ("  filter kept %.3f of the pairs" % (i3["pairs_past_filter"] / max(i3["wave_tiles_done"], 1)) if i3.get("pairs_past_filter") is not None else ""), flush=True)
           bad += 0 if ok else 1
           if not ok:
-              for name, other in (("forced", forced), ("framed", framed)):
+              for name, other in (("forced", forced), ("framed", framed), ("two-pass", two)):
                   for what, a, b in zip(("rowptr", "col", "val", "bw"), ref, other):
                       if not torch.equal(a, b):
                           if a.shape == b.shape:
@@ -68,4 +71,5 @@ for c in range(n_cases):
           print("skip", tag, "(MemoryError: %s)" % str(e)[:60], flush=True)
       finally:
           os.environ.pop("MELD_KNN16_EE", None)
+          os.environ.pop("MELD_KNN_TWO_PHASE", None)
 print("bad:", bad)
