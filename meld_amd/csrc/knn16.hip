@@ -3046,7 +3046,8 @@ static int k16_topk_impl(const void* Q16, const float* Qn, const void* Rt16, con
   // nothing and costs 15 %); MELD_KNN16_EE=0 / 1 overrides the caller, for A-B measurements
   const int dA = k16_dA(d, KB);
   const char* ee_env = meld_dev_getenv("MELD_KNN16_EE");
-  const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
+  const char* ee_max = meld_dev_getenv("MELD_KNN16_EE_MAXKB");  // (development: the widest operand the partial-test kernel is taken for)
+  const bool ee = step_list != nullptr && dA > 0 && KB >= 2 && KB <= (ee_max ? atoi(ee_max) : 7) && (ee_env ? atoi(ee_env) != 0 : partial_test != 0);
   ka.ee_hi = 16 + d - dA;
   ka.count_go = two_counters;  // (a caller of meld_knn16_topk_listed passes ONE counter, whatever MELD_KNN16_EE forces)
   {

@@ -531,10 +531,7 @@ def lanczos_lmax(G, tol=3e-4, max_iter=300, check_every=5, seed=0):
         it += 1
         done = beta <= 1e-14 * max(abs(alpha), 1e-300)
         if it % check_every == 0 or done or it == max_iter:
-            T = np.diag(alphas) + np.diag(betas, 1) + np.diag(betas, -1)
-            ev, evec = np.linalg.eigh(T)
-            theta = float(ev[-1])
-            resid = abs(beta * evec[-1, -1]) / max(abs(theta), 1e-300)
+            theta, resid = _ritz_check(alphas, betas + [beta], tol)  # (the tridiagonal solver: see there for why not a dense eigh)
             if resid <= tol or done:
                 break
         if comm is not None:

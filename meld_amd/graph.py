@@ -407,6 +407,25 @@ class DeviceGraph:
         return 1.0 / (self.ksum * self.ksum) ** self.anisotropy
 
 
+_BLAS_CTL = None
+
+
+def _eigh_one_thread(a):
+    """``np.linalg.eigh(a, UPLO="U")`` (row-major upper triangle) on one BLAS thread (threadpoolctl; plain numpy where it is absent)."""
+    global _BLAS_CTL
+    if a.shape[0] <= 64:  # (below OpenBLAS's threading threshold: 0.1 ms at 50 x 50 as it is)
+        return np.linalg.eigh(a, UPLO="U")
+    try:
+        if _BLAS_CTL is None:
+            from threadpoolctl import ThreadpoolController
+
+            _BLAS_CTL = ThreadpoolController()
+        with _BLAS_CTL.limit(limits=1, user_api="blas"):
+            return np.linalg.eigh(a, UPLO="U")
+    except ImportError:
+        return np.linalg.eigh(a, UPLO="U")
+
+
 def _scan_i32(lib, x, st):
     n = x.shape[0]
     out = torch.empty(n + 1, dtype=torch.int64, device=x.device)
@@ -494,7 +513,10 @@ class HipOps:
             if comm.rank != 0:
                 cov.zero_()
             comm.all_reduce_sum(cov)
-        evals, evecs = np.linalg.eigh(cov.cpu().numpy(), UPLO="U")  # (row-major upper triangle)
+        # (ONE BLAS thread for the d x d eigenproblem: past ~64 x 64 OpenBLAS goes multi-threaded, and on a many-core host its
+        # threads' start-up cost 60-370 ms for a 100 x 100 matrix that one thread decomposes in 1.1 ms -- found as a 62 ms idle gap
+        # of the GPU in the d = 100 step)
+        evals, evecs = _eigh_one_thread(cov.cpu().numpy())
         tot = float(evals.sum())
         if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
             return None
