@@ -1201,7 +1201,9 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
 // emptied entries dropped, cnt_out = the new length.  One workgroup per query block = the search kernel's four waves.
 // (eight tiles per step at four waves per SIMD; 4 tiles x 6 waves, 6 x 5, 2 x 8 measured 5.8 ... 6.9 against 5.4-5.8 ms: the SIMDs are
 // busy issuing -- an LDS-DMA piece costs ~180 cycles of issue, the test ~300 per (wave, tile) -- not waiting; the pieces through
-// registers instead (a 16-byte load at the top of the step, a ds_write behind the tests, __syncthreads): 5.7-5.8 against 5.4-5.5)
+// registers instead (a 16-byte load at the top of the step, a ds_write behind the tests, __syncthreads): 5.7-5.8 against 5.4-5.5;
+// no staging at all -- every wave walking the list on its own, its A fragments by 16-byte loads straight from global memory, four
+// live entries and eight loads in flight, no barrier before the rewrite: 7.4 ms at four waves per SIMD, 7.9-8.1 at six)
 template <int TPS, int WPE>  // tiles per step (and barrier); waves per SIMD the kernel is compiled for
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void knn16_partial_filter_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
                                                                    const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
