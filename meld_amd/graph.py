@@ -697,6 +697,8 @@ class HipOps:
                 else:
                     check(lib.meld_knn16_seed_thresholds_mfma(ptr(Q), ptr(Qn), ptr(Rt), ptr(scale_info), ptr(nmax), N, d, q_begin, q_count, knn, rfac, nprod, int(opt("MELD_KNN_SEED_SIDE", "0")), ptr(seeds), st), "meld_knn16_seed_thresholds_mfma")
                 tm.stop("seed")
+                if opt("MELD_KNN_SEEDS_FROM"):  # (development: what perfect start thresholds would be worth -- the final thresholds of an earlier run)
+                    seeds = torch.minimum(seeds, torch.load(opt("MELD_KNN_SEEDS_FROM")).to(dev))
             if will_prune:
                 # (after the seeds: with them the table also drops the tiles no query of a wave can reach from
                 # its own start threshold, see meld_knn16_bounds)
@@ -816,6 +818,8 @@ class HipOps:
                 # factorisation: a host-blocking copy + a few small launches on a side stream) is started here
                 while _WHILE_SEARCHING:
                     _WHILE_SEARCHING.pop()()
+            if opt("MELD_KNN_SAVE_THR") and cand_thr is not None:
+                torch.save((cand_thr * scale_info[0] ** 2 * 1.0001).cpu(), opt("MELD_KNN_SAVE_THR"))
             used_prune, used_seed = lb2 is not None or step_list is not None, seeds is not None
             used_seeded_bounds = bool(will_prune and seeds is not None and self.seeded_bounds)
             used_block_order = block_order is not None
