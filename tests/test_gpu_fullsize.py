@@ -215,6 +215,36 @@ def test_whole_path_against_the_oracle_digest(full):
         assert np.abs(proj - g[pre + name + "_proj"]).max() <= tol * ref_nrm * np.sqrt(v.shape[0]), name
 
 
+def test_a_row_shard_through_the_two_pass_search_equals_the_rows_of_the_whole_build():
+    """What a rank of a 2-way row-sharded build computes at the 1M size -- the queries [r0, r0 + n) against all cells: table-driven
+    step lists (no symmetry to build them from), the principal frame, the list-filter pass and the search over the thinned lists
+    (1954 query blocks: not sliced) -- must be the corresponding rows of the single-range result, entry for entry and bit for bit."""
+    import bench
+    from meld_amd.graph import HipOps
+    from meld_amd.reorder import locality_permutation
+
+    N = 1_000_000
+    X, _ = bench.synthetic_cells(N, n_dims=D_FULL, seed=0)
+    Xd = torch.from_numpy(X).cuda()
+    Xd = Xd.index_select(0, locality_permutation(Xd)).contiguous()
+    del X
+    ops = HipOps()
+    keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, N, 15, 40.0, 1e-4, 64)
+    assert info["two_phase"] and info["principal_frame"]
+    M = keys.shape[0] // 2
+    r0, n = 499_968, 500_032  # (a multiple of the 256 queries of a workgroup, as the sharded driver cuts)
+    k, v, b, inf = ops.directed_kernel_coo(Xd, r0, n, 15, 40.0, 1e-4, 64)
+    assert inf["two_phase"] and inf["principal_frame"] and inf["step_lists"], inf
+    assert 0 < inf["pairs_past_filter"] < inf["wave_tiles_done"]
+    m = k.shape[0] // 2
+    rows = keys[:M] >> 32
+    sel = (rows >= r0) & (rows < r0 + n)
+    ka, va = keys[:M][sel], vals[:M][sel]
+    oa, ob = torch.argsort(ka), torch.argsort(k[:m])
+    assert torch.equal(ka[oa], k[:m][ob]) and torch.equal(va[oa], v[:m][ob])
+    assert torch.equal(b, bw[r0 : r0 + n])
+
+
 def test_filterbank_vertex_frequency_cluster_at_one_million_cells():
     """BASELINE configs[4] on one GPU: the filter-bank VertexFrequencyCluster at the 1M-cell size (the reference's dense
     algorithm cannot run beyond ~2e4 cells).  Properties that do not depend on the size: finite non-negative spectrogram
