@@ -114,7 +114,7 @@ def measured_full_size(n_cells):
     """The one MEASURED CPU number at the benchmark size: the whole oracle (brute-force kNN on all host cores) run by the round's
     evidence script (tools/parity_200k.py under tools/_profile_round.sh, 160 s at 1M cells -- too long for a default bench run),
     recorded with its commit in profiles/r04_cpu_full_size.json."""
-    for name in ("r05_cpu_full_size.json", "r04_cpu_full_size.json"):
+    for name in ("r06_cpu_full_size.json", "r05_cpu_full_size.json", "r04_cpu_full_size.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
@@ -462,7 +462,10 @@ def main():
                     "cycles of issue, the test ~300 per pair (4 MFMAs = 128 pipe cycles + the minima over 64 accumulator registers); "
                     "without its staging the pass takes 5.2 ms, without its arithmetic 2.7, with neither 1.0 (DESIGN.md 4.1.8)",
         }
-        out["roofline"]["search_ms_filter_plus_search"] = 1e3 * (t_f + float(np.mean(ev["knn_topk"])) * 1e-3)
+        t_both = t_f + float(np.mean(ev["knn_topk"])) * 1e-3
+        out["roofline"]["search_ms_filter_plus_search"] = 1e3 * t_both
+        # the two launches of the search stage together: flops issued by both over the time of both (a utilisation, like `frac`)
+        out["roofline"]["frac_filter_plus_search"] = (ex_f + out["roofline"]["achieved"] * 1e12 * float(np.mean(ev["knn_topk"])) * 1e-3) / t_both / 1e12 / PEAK_MFMA_F16_TFLOPS
     if "cheby_steps" in ev:
         out["roofline_cheby"] = cheby_roofline(G, ev, args.order, p, N, d)
     if world == 1 and not args.no_extra and N == 1_000_000 and d == 50:
