@@ -329,7 +329,19 @@ def main():
         host_elapsed = time.perf_counter() - th
         gc.enable()
         del X_host
+    per_rank = None
     if dist is not None:
+        # what every rank saw (outside the timed region): its own wall time over the steps, the HIP-event spans of its stages, its
+        # share of the graph -- so that the first run on a multi-GPU node says where a rank's time goes
+        mine = {"rank": rank, "elapsed_s": elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+                "events_ms": {k: float(np.mean(v)) for k, v in ev.items()},
+                "rows_local": int(op.graph.info.get("rows_local", 0)), "nnz_local": int(op.graph.nnz),
+                "exchange": op.graph.info.get("exchange"), "exchange_capacity": op.graph.info.get("exchange_capacity"),
+                "two_phase": bool(op.graph.info.get("two_phase")), "principal_frame": bool(op.graph.info.get("principal_frame")),
+                "rccl_c_loops": bool(getattr(getattr(op.graph, "comm", None), "rccl", lambda: None)() is not None)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -371,6 +383,13 @@ def main():
             "lanczos_iterations": int(G.lmax_info.get("iterations", 0)),
         },
     }
+    if per_rank is not None:
+        # per Chebyshev step every rank all-gathers the iterate (8 p bytes per cell), per Lanczos iteration the iterate (8 bytes per
+        # cell) and 3 x 64 doubles; the symmetrisation is one fixed-capacity all-to-all
+        out["per_rank"] = per_rank
+        out["collective_bytes_per_step"] = {
+            "chebyshev_all_gather": int((args.order - 1) * 8 * p * N), "lanczos_all_gather": int(G.lmax_info.get("iterations", 0)) * 8 * N,
+            "symmetrise_all_to_all_capacity": int(world * 16 * int(G.info.get("exchange_capacity") or 0)), "kernel_row_sums_all_gather": 8 * N}
     if "knn_topk" in ev:
         t_knn = float(np.mean(ev["knn_topk"])) * 1e-3
         rows = G.info.get("rows_local", N)

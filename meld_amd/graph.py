@@ -13,6 +13,7 @@ from ._options import is_set, opt
 
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -795,6 +796,10 @@ class HipOps:
                     if block_order is not None:  # (longest blocks first, by what is left of them)
                         block_order = torch.argsort(step_cnt, descending=True, stable=True).to(torch.int32)
                 tiles_b = tiles_done[1:]  # (the search counts the pairs it computes, and its blocks, behind the filter's)
+                if opt("MELD_KNN_LIST_STATS"):  # (development: how long the thinned lists are -- the longest one bounds the search from below)
+                    sc = step_cnt.to(torch.float64)
+                    print("[lists behind the filter] blocks %d  entries: mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
+                        sc.numel(), sc.mean(), sc.median(), torch.quantile(sc, 0.9), torch.quantile(sc, 0.99), sc.max()), file=sys.stderr)
                 tm.stop("knn_filter")
             with _EventSpan("knn_topk", N=N, d=d, q=q_count):
                 if main_slices > 1:
