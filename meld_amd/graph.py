@@ -489,7 +489,40 @@ class HipOps:
         check(self.lib.meld_col_stats_f64(ptr(X), N, d, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(tmp), tb, _stream()), "meld_col_stats_f64")
         return out[0], out[1], out[2]
 
-    def principal_frame(self, X, mean, lead, comm=None):
+    def frame_axes_async(self, X, col_stats):
+        """Start the frame of the search on ``X`` BEFORE the cells are brought into locality order: the covariance of evenly spaced
+        rows does not depend on the order of the cells, so its scatter matrix and the read-back go out first, and the d x d
+        eigenproblem is solved on the host while the GPU works through the ordering (the GPU used to idle ~0.35 ms at 1M cells
+        while the host waited for the read-back, decomposed the matrix and sent the axes back).  Returns a function that finishes
+        the job -- ``finish(lead)`` -> the axes as rows ``At`` (device, [d, meld_frame_max_dims()]) or None (frame declined) -- or
+        None where the frame will not be asked for (options, size, width) or the column sums are not at hand."""
+        lib = self.lib
+        N, d = int(X.shape[0]), int(X.shape[1])
+        if (col_stats is None or opt("MELD_FRAME_ASYNC", "1") == "0" or not self.rotate or not self.prune or not self.step_lists or not self.seed or self.nprod != 1 or self.search != "f16x3"
+                or N < max(16384, self.rotate_min_cells) or d > int(lib.meld_frame_max_dims()) or int(lib.meld_knn16_split_dims(d)) <= 0):
+            return None
+        st = _stream()
+        mean = col_stats[0] / N
+        cov = torch.zeros(d, d, dtype=torch.float64, device=X.device)
+        check(lib.meld_cov_sample_f64(ptr(X), N, d, ptr(mean), max(1, N // 32768), ptr(cov), st), "meld_cov_sample_f64")
+        host = torch.empty(d, d, dtype=torch.float64, pin_memory=True)
+        host.copy_(cov, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def finish(lead):
+            done.synchronize()
+            evals, evecs = _eigh_one_thread(host.numpy())
+            tot = float(evals.sum())
+            if not np.isfinite(tot) or tot <= 0.0 or float(evals[-lead:].sum()) < 0.5 * tot:
+                return False
+            At = np.zeros((d, int(lib.meld_frame_max_dims())))
+            At[:, :d] = evecs[:, ::-1].T
+            return torch.from_numpy(At).to(X.device, non_blocking=True)
+
+        return finish
+
+    def principal_frame(self, X, mean, lead, comm=None, axes=None):
         """The cells in their principal frame, ``(X - mean) V`` with the eigenvectors of the covariance (of at most 32768 evenly
         spaced rows, ``meld_cov_sample_f64``) in descending order of variance (``meld_rotate_rows_f64``) -- or None when the
         ``lead`` leading coordinates would carry less than half of the variance (the search's partial test would seldom drop a
@@ -498,6 +531,14 @@ class HipOps:
         ``X`` itself.  The d x d eigenproblem is solved on the host (one read-back of d x d numbers)."""
         lib, st = self.lib, _stream()
         N, d = int(X.shape[0]), int(X.shape[1])
+        if axes is not None and (comm is None or getattr(comm, "world", 1) == 1):
+            # (the axes were started before the ordering: frame_axes_async)
+            At = axes(lead)
+            if At is False:
+                return None
+            out = torch.empty_like(X)
+            check(lib.meld_rotate_rows_f64(ptr(X), N, d, ptr(mean), ptr(At), ptr(out), st), "meld_rotate_rows_f64")
+            return out
         wide = d > int(lib.meld_frame_max_dims())  # (beyond the frame kernels' row width: the same two products through the library)
         stride = max(1, N // 32768)
         if wide:
@@ -535,7 +576,7 @@ class HipOps:
 
     # ---- A2 + A3: directed alpha-decay kernel rows of [q_begin, q_begin + q_count) as COO -------
     def directed_kernel_coo(self, X, q_begin, q_count, knn, decay, thresh, ksel, tm=None, force_fallback=False, n_refs=None, assemble=False, comm=None,
-                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None, symm=(0, 0.0), count_rows_ge=None):
+                            bw_scale=1.0, bw_fixed=None, col_stats=None, knn_max=None, symm=(0, 0.0), count_rows_ge=None, frame_axes=None):
         """Returns (keys[2M] int64, vals[2M] fp64, info): slot e < M holds (i, j, K_ij / 2) with
         key = i << 32 | j for the local row i; slot M + e holds the transposed (j, i, K_ij / 2).
 
@@ -642,7 +683,7 @@ class HipOps:
             lead = int(lib.meld_knn16_split_dims(d))
             if (self.rotate and lead > 0 and nprod == 1 and not cross and self.prune and self.step_lists and self.seed
                     and N >= max(16384, self.rotate_min_cells) and q_begin % BQ == 0 and bw_fixed is None):
-                X_s = self.principal_frame(X, mean, lead, comm)
+                X_s = self.principal_frame(X, mean, lead, comm, axes=frame_axes)
                 if X_s is not None:
                     sums_s, col_min, col_max = self.col_stats(X_s)
                     X_search, mean_search = X_s, sums_s / N
@@ -959,7 +1000,7 @@ class HipOps:
             # -- the shared-spheres all-gather of the first try is skipped, every rank computes all spheres itself)
             out = self.directed_kernel_coo(X, q_begin, q_count, knn, decay, thresh, 128, tm=tm, force_fallback=False, n_refs=n_refs,
                                            assemble=assemble, bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm,
-                                           count_rows_ge=count_rows_ge)
+                                           count_rows_ge=count_rows_ge, frame_axes=frame_axes)
             out[3]["ksel_retry_from"] = int(ksel)
             out[3]["n_flagged_rows_first_try"] = int(n_flag_h)
             return out
@@ -1628,6 +1669,9 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
             raise ValueError("bandwidth must be finite and non-negative")
         bw_fixed = b.contiguous().clone()
 
+    # (the frame of the search does not depend on the order of the cells: its scatter matrix and read-back go out in front of
+    # the ordering, the host decomposes it while the GPU orders: frame_axes_async)
+    frame_axes = ops.frame_axes_async(X, col_stats) if (bw_fixed is None and hasattr(ops, "frame_axes_async")) else None
     perm = None
     if reorder:
         from .reorder import locality_permutation
@@ -1651,7 +1695,8 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
     info = None
     if knn_max is not None and decay is not None and math.isfinite(decay) and 36 * k1 < min(knn_max + 1, N):
         trial = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                        bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=None, symm=symm, count_rows_ge=6 * k1)
+                                        bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=None, symm=symm, count_rows_ge=6 * k1,
+                                        frame_axes=frame_axes)
         if trial[3]["rows_with_at_least"] <= N // 10 or 36 * k1 >= N / 2:
             keys, vals, bw, info = trial
             info["knn_max_uncapped_as_upstream"] = True
@@ -1659,7 +1704,8 @@ def build_knn_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, ksel=None, pr
         del trial
     if info is None:
         keys, vals, bw, info = ops.directed_kernel_coo(X, 0, N, knn, decay, thresh, ksel, tm=tm, force_fallback=force_fallback, assemble=True,
-                                                       bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm)
+                                                       bw_scale=bw_scale, bw_fixed=bw_fixed, col_stats=col_stats, knn_max=knn_max, symm=symm,
+                                                       frame_axes=frame_axes)
     if bw_scale != 1.0:  # (the stages record the unscaled bandwidth; the graph reports the one the kernel used)
         bw = (bw * bw_scale).clamp_(min=float(np.finfo(float).eps))
     if info.get("nnz_directed", 0) == 0:
