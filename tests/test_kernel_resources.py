@@ -36,8 +36,6 @@ def _resource_usage(src):
 def test_search_kernels_do_not_spill():
     rows = _resource_usage(os.path.join(ROOT, "meld_amd", "csrc", "knn16.hip"))
     product = {k: v for k, v in rows.items() if "knn16_topk_kernelILi" in k and "ELi0ELi" in k}  # ABL = 0
-    # KB = 1..9 x NPROD in {1, 3}, table-driven (LIST = false) + KB = 1..9 list-driven hi-only first pass (LIST = true) + KB = 2..6
-    # the same with the partial test behind the first K block (EE = true)
     # KB = 1..9 x NPROD in {1, 3}, table-driven + KB = 1..9 list-driven + KB = 2..7 with the partial test (round 6: seven K blocks, d = 100)
     assert len(product) == 33, sorted(product)
     assert sum("ELb1ELb0E" in k for k in product) == 9 and sum("ELb1ELb1E" in k for k in product) == 6, sorted(product)
