@@ -1203,7 +1203,8 @@ __attribute__((amdgpu_waves_per_eu(k16_waves(KB, ABL, NPROD) + ((EE && K16_EE_PA
 // busy issuing -- an LDS-DMA piece costs ~180 cycles of issue, the test ~300 per (wave, tile) -- not waiting; the pieces through
 // registers instead (a 16-byte load at the top of the step, a ds_write behind the tests, __syncthreads): 5.7-5.8 against 5.4-5.5;
 // no staging at all -- every wave walking the list on its own, its A fragments by 16-byte loads straight from global memory, four
-// live entries and eight loads in flight, no barrier before the rewrite: 7.4 ms at four waves per SIMD, 7.9-8.1 at six)
+// live entries and eight loads in flight, no barrier before the rewrite: 7.4 ms at four waves per SIMD, 7.9-8.1 at six; one copy
+// request behind every other tile's test instead of the four of a wave back to back at the top of the step: 5.6 against 5.6)
 template <int TPS, int WPE>  // tiles per step (and barrier); waves per SIMD the kernel is compiled for
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void knn16_partial_filter_kernel(const _Float16* __restrict__ Q16, const float* __restrict__ Qn,
                                                                    const _Float16* __restrict__ Rt16, const float* __restrict__ scale_info,
