@@ -335,11 +335,19 @@ def fit_transform_sharded(op, X, sample_labels, ops=None, comm=None):
     if not isinstance(X, torch.Tensor):
         X = torch.from_numpy(np.ascontiguousarray(np.asarray(getattr(X, "values", X)), dtype=np.float64))
     X = X.to(device=ops.device, dtype=torch.float64).contiguous()
-    if op.thresh == 0:  # (n_landmark: accepted, the filter never uses the landmark operator)
-        raise NotImplementedError("the sharded driver supports sparse graphs only (thresh > 0)")
-    unsupported = sorted(k for k in op.kwargs if k not in ("ksel", "sample_idx"))
-    if unsupported:
-        raise NotImplementedError("graph options {} are not implemented by the row-sharded builder".format(unsupported))
+    # Graphs the row-sharded BUILDER does not build itself -- graphtools' bandwidth / bandwidth_scale / knn_max / kernel_symm / theta,
+    # the dense "exact" graph of thresh = 0, precomputed matrices, the manhattan / chebyshev metrics, knn > 126 -- are built whole on
+    # every rank by the single-GPU builder (``op.fit``: the same front end, the same refusals), and the FILTER is sharded: every rank
+    # keeps its rows (``shard_of_graph``), as for ``sample_idx`` below.  (n_landmark: accepted, the filter never uses the operator.)
+    replicated = [k for k in op.kwargs if k not in ("ksel", "sample_idx")]
+    dense_kind = (op.thresh == 0 and op.decay is not None) or str(op.distance).lower().startswith("precomputed") \
+        or str(op.distance).lower() in ("manhattan", "cityblock", "l1", "chebyshev") or min(int(op.knn), int(X.shape[0]) - 2) > 126
+    if (replicated or dense_kind) and op.kwargs.get("sample_idx") is None:
+        if not X.is_cuda:
+            raise NotImplementedError("graph options {} on the row-sharded driver need the single-GPU builder on every rank (a GPU)".format(sorted(replicated)))
+        op.fit(X)
+        op.graph = shard_of_graph(op.graph, ops, comm)
+        return op.transform(sample_labels)
     decay = float("inf") if op.decay is None else op.decay  # None: graphtools' unweighted kNN graph = a 0 / 1 kernel
     # the same front end as the single-GPU path (MELD._build_graph): reject NaN / infinity, and build the
     # graph on the PCA scores when n_pca < min(X.shape) (graphtools' Data._reduce_data; the reference's

@@ -53,7 +53,12 @@ def main(out_path, n, d, knn, mode=""):
     kw = {}
     if mode == "mnn":  # sample_idx: the MNN graph, built whole on every rank, rows sharded for the recurrences
         kw["sample_idx"] = np.random.default_rng(3).choice(["s0", "s1"], size=n)
-    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0, decay=None if mode == "unweighted" else 40, **kw)
+    if mode.startswith("opt:"):  # graph keywords the sharded builder does not shard: replicated build, sharded filter
+        import json
+
+        kw.update(json.loads(mode[4:]))
+    thresh = kw.pop("thresh", 1e-4)
+    op = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0, decay=None if mode == "unweighted" else 40, thresh=thresh, **kw)
     dens = mdist.fit_transform_sharded(op, torch.from_numpy(X).cuda(), labels, comm=StagedComm())
     G = op.graph
     extra = {}
@@ -64,7 +69,7 @@ def main(out_path, n, d, knn, mode=""):
                                               chebyshev_order=48, random_state=3, n_clusters=3)
         vfc.fit(G)
         extra = dict(spec=vfc._fb_spectrogram.cpu().numpy(), ritz=vfc._fb["ritz"].cpu().numpy(), norm2=vfc._fb["window_norm2"].cpu().numpy())
-    if mode in ("mnn", "unweighted", "vfc"):
+    if mode in ("mnn", "unweighted", "vfc") or mode.startswith("opt:"):
         np.savez(out_path + ".rank{}".format(dist.get_rank()), dens=dens.values, lmax=G.lmax, row_begin=G.row_begin, n_rows=G.n_rows,
                  nnz_global=G.info["nnz_global"], **extra)
         dist.destroy_process_group()

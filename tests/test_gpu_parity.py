@@ -785,6 +785,44 @@ def test_two_ranks_on_one_gpu_vfc_and_graph_options(tmp_path, mode):
             assert np.abs(r["spec"] - spec).max() < 1e-6
 
 
+@pytest.mark.parametrize("opts,n", [({"bandwidth_scale": 0.8, "knn_max": 14}, 20011), ({"kernel_symm": "mnn", "theta": 0.3}, 20011),
+                                    ({"bandwidth": 0.9}, 20011), ({"thresh": 0}, 1500)])
+def test_two_ranks_on_one_gpu_with_graph_keywords(tmp_path, opts, n):
+    """graphtools' graph keywords on the row-sharded driver (reference meld/meld.py:106,117-118 forwards them): the builder does not
+    shard these graphs itself -- every rank builds the graph whole with the single-GPU builder and keeps its rows, the filter is
+    sharded.  Two ranks with the real HIP kernels (collectives staged through host memory): every rank returns what one GPU
+    computes alone."""
+    import json
+    import socket
+    import subprocess
+
+    import meld_amd
+
+    mo = _oracle()
+    d, knn, world = 16, 9, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn), "opt:" + json.dumps(opts)]
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
+    X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
+    kw = dict(opts)
+    thresh = kw.pop("thresh", 1e-4)
+    single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0, thresh=thresh, **kw)
+    ref = single.fit_transform(X, labels)
+    assert [int(r["n_rows"]) for r in ranks] != [n, n]  # (the filter ran on row shards)
+    assert sum(int(r["n_rows"]) for r in ranks) == n
+    for r in ranks:
+        assert abs(float(r["lmax"]) - single.graph.lmax) <= 1e-9 * single.graph.lmax
+        assert np.abs(r["dens"] - ref.values).max() <= 1e-9 * np.abs(ref.values).max()
+
+
 def test_locality_reordering_does_not_change_results():
     """The permutation is a memory-layout decision only: identical graph and densities (to
     rounding: summation order inside a row changes) with and without it."""
