@@ -71,7 +71,10 @@ def _alpha_decay_dense(D, knn, decay, thresh):
     return K, bw
 
 
-def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
+def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0), bandwidth=None, bandwidth_scale=1.0):
+    """``bandwidth`` ([UPSTREAM ``TraditionalGraph.build_kernel``]: a number, one value per cell, or a CALLABLE that is handed the
+    N x N matrix of pairwise distances (a host array, as upstream hands it a numpy array) and returns either) replaces the distance
+    to the knn-th neighbour; ``bandwidth_scale`` multiplies whichever is used."""
     N = int(X.shape[0])
     if N > DENSE_MAX_N:
         raise ValueError("thresh=0 builds a dense {0}x{0} graph; the limit is N <= {1}".format(N, DENSE_MAX_N))
@@ -80,7 +83,21 @@ def build_dense_graph(X, knn=5, decay=40, anisotropy=1, symm=(0, 0.0)):
     X = X.to(torch.float64)
     D = torch.cdist(X, X, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
     D.fill_diagonal_(0.0)
-    K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
+    if bandwidth is None and float(bandwidth_scale) == 1.0:
+        K, bw = _alpha_decay_dense(D, knn, decay, 0.0)
+    else:
+        if bandwidth is None:
+            bw = torch.kthvalue(D, knn + 1, dim=1).values
+        else:
+            b = bandwidth(D.cpu().numpy()) if callable(bandwidth) else bandwidth
+            bw = torch.as_tensor(np.asarray(b, dtype=np.float64)).to(D.device)
+            if bw.dim() == 0:
+                bw = bw.expand(N)
+            if tuple(bw.shape) != (N,):
+                raise ValueError("bandwidth must be a number or have one entry per cell ({}), got shape {}".format(N, tuple(bw.shape)))
+        bw = bw * float(bandwidth_scale)
+        K = torch.exp(-torch.pow(D / bw[:, None], decay))
+        K = torch.where(torch.isnan(K), torch.ones_like(K), K)
     return _graph_from_dense_kernel(K, anisotropy, bw, dict(knn=int(knn)), symm=symm)
 
 

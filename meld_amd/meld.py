@@ -200,10 +200,14 @@ class MELD(GraphEstimator):
         # (the metric enters through the data: cosine = the euclidean graph of the unit rows with the decay doubled)
         X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
         bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale", "knn_max") if opts.get(k) is not None}
-        if bw_opts and (opts.get("sample_idx") is not None or (self.thresh == 0 and self.decay is not None) or self.decay is None
+        dense_exact = self.thresh == 0 and self.decay is not None
+        if bw_opts and (opts.get("sample_idx") is not None or (dense_exact and "knn_max" in bw_opts) or self.decay is None
                         or str(self.distance).lower() not in ("euclidean", "l2")):
-            raise NotImplementedError("bandwidth / bandwidth_scale / knn_max are implemented for the sparse euclidean alpha-decay kNN graph only "
-                                      "(not with sample_idx, thresh=0, decay=None or another distance)")
+            raise NotImplementedError("bandwidth / bandwidth_scale / knn_max are implemented for the euclidean alpha-decay graphs only -- the sparse kNN "
+                                      "graph, and (without knn_max) the dense graph of thresh=0 -- not with sample_idx, decay=None or another distance")
+        if callable(bw_opts.get("bandwidth")) and not dense_exact:
+            # [UPSTREAM graphtools kNNGraph.__init__]: "Callable bandwidth is only supported by graphtools.graphs.TraditionalGraph."
+            raise NotImplementedError("Callable bandwidth is only supported by the dense graph of thresh=0 (graphtools.graphs.TraditionalGraph)")
         if opts.get("sample_idx") is not None:
             # graphtools builds its MNN graph when sample_idx is forwarded (reference test/test_meld.py:34)
             if self.thresh == 0 and self.decay is not None:  # "exact" subgraphs: the dense route
@@ -225,7 +229,8 @@ class MELD(GraphEstimator):
         if self.thresh == 0 and self.decay is not None:
             from .dense import build_dense_graph
 
-            G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy, symm=symm)
+            G = build_dense_graph(X, knn=self.knn, decay=decay_m, anisotropy=self.anisotropy, symm=symm,
+                                  bandwidth=bw_opts.get("bandwidth"), bandwidth_scale=bw_opts.get("bandwidth_scale", 1.0))
             G.bandwidth_to_metric = bw_to_metric
             return G
         if min(int(self.knn), int(X.shape[0]) - 2) > 126 and not bw_opts:

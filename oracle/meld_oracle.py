@@ -181,21 +181,28 @@ def knn_kernel(
     return K
 
 
-def dense_kernel(X, knn=5, decay=40, thresh=0.0):
+def dense_kernel(X, knn=5, decay=40, thresh=0.0, bandwidth=None, bandwidth_scale=1.0):
     """Dense "exact" kernel used when thresh == 0.
 
     [UPSTREAM graphtools ``api.Graph`` picks ``TraditionalGraph`` when ``decay is not None and
     thresh == 0``; ``TraditionalGraph.build_kernel``]: pdist/squareform, bandwidth =
     max of the (knn+1) smallest entries per row (self included), ``K = exp(-(pdx/bw)^decay)``,
     NaN -> 1, ``K[K < thresh] = 0``.  Exercised by reference ``test/test_meld.py:59-69``.
+    ``bandwidth`` / ``bandwidth_scale`` ([UPSTREAM ``TraditionalGraph.build_kernel``: ``bandwidth = self.bandwidth(pdx)`` for a
+    callable -- the one graph class that takes one --, a number or one value per cell otherwise; then
+    ``bandwidth = bandwidth * self.bandwidth_scale``], forwarded by reference ``meld/meld.py:106,117-118``).
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
     N = X.shape[0]
     if knn > N - 2:
         knn = N - 2
     pdx = squareform(pdist(X, metric="euclidean"))
-    knn_dist = np.partition(pdx, knn + 1, axis=1)[:, : knn + 1]
-    bandwidth = np.max(knn_dist, axis=1)
+    if bandwidth is None:
+        knn_dist = np.partition(pdx, knn + 1, axis=1)[:, : knn + 1]
+        bandwidth = np.max(knn_dist, axis=1)
+    elif callable(bandwidth):
+        bandwidth = bandwidth(pdx)
+    bandwidth = np.asarray(bandwidth, dtype=np.float64) * bandwidth_scale
     pdx = (pdx.T / bandwidth).T
     K = np.exp(-1 * np.power(pdx, decay))
     K = np.where(np.isnan(K), 1, K)
@@ -590,7 +597,7 @@ def build_graph(X, knn=5, decay=40, thresh=1e-4, anisotropy=1, n_jobs=1, algorit
         L, dw = laplacian(W)
         return OracleGraph(Kd, K, W, L, dw)
     if thresh == 0 and decay is not None:  # ([UPSTREAM graphtools api.Graph]: decay=None picks the kNN graph before thresh is looked at)
-        Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0)
+        Kd = dense_kernel(X, knn=knn, decay=decay, thresh=0.0, bandwidth=bandwidth, bandwidth_scale=bandwidth_scale)
         K = apply_anisotropy(symmetrize(Kd, kernel_symm, theta), anisotropy)
         W = weights_from_kernel(K)
         L, dw = laplacian(W)

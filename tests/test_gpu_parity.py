@@ -208,6 +208,36 @@ def test_bandwidth_options_match_the_oracle(n, d, knn, opt):
         assert _rel(out.values, dens) < 1e-5
 
 
+@pytest.mark.parametrize("opt", ["number", "per_cell", "scale", "callable"])
+def test_dense_graph_bandwidth_options_match_the_oracle(opt):
+    """``thresh=0`` (graphtools' TraditionalGraph, the graph of the reference's known-answer test) with graphtools' ``bandwidth`` --
+    a number, one value per cell, or a CALLABLE of the pairwise-distance matrix (the one graph class that takes one) -- and
+    ``bandwidth_scale``: W, degrees and densities against the oracle's restatement of ``TraditionalGraph.build_kernel``; a callable
+    on the sparse builder is refused as upstream refuses it."""
+    mo = _oracle()
+    import meld_amd
+
+    X, labels = mo.synthetic_cells(900, n_dims=8, seed=9)
+    rng = np.random.default_rng(2)
+    kw = {"number": dict(bandwidth=0.7), "per_cell": dict(bandwidth=rng.uniform(0.5, 1.0, size=900)), "scale": dict(bandwidth_scale=0.7),
+          "callable": dict(bandwidth=lambda pdx: np.sort(pdx, axis=1)[:, 4], bandwidth_scale=1.2)}[opt]
+    G = mo.build_graph(X, knn=7, decay=10, thresh=0, anisotropy=1, **kw)
+    op = meld_amd.MELD(knn=7, decay=10, thresh=0, chebyshev_order=20, verbose=0, **kw).fit(X)
+    np.testing.assert_allclose(np.asarray(op.graph.W.todense()), np.asarray(G.W.todense() if hasattr(G.W, "todense") else G.W), rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(op.graph.dw, G.dw, rtol=1e-10)
+    ind = mo.sample_indicators(labels)[1]
+    lmax = mo.estimate_lmax(G.L, G.dw)
+    op.graph.lmax = lmax
+    dens = op.transform(labels)
+    ref = mo.meld_filter(ind, G, chebyshev_order=20, lmax=lmax)
+    assert _rel(dens.values, ref) < 1e-5
+    if opt == "callable":
+        with pytest.raises(NotImplementedError):
+            meld_amd.MELD(knn=7, verbose=0, bandwidth=lambda pdx: pdx[:, 1]).fit(X)
+    with pytest.raises(NotImplementedError):
+        meld_amd.MELD(knn=7, thresh=0, verbose=0, knn_max=9).fit(X)
+
+
 @pytest.mark.parametrize("kind", ["distance", "affinity", "auto_distance", "auto_affinity"])
 def test_precomputed_matrices_match_the_oracle(kind):
     """``MELD(distance="precomputed_distance" | "precomputed_affinity" | "precomputed").fit_transform(M, labels)``: graphtools'
@@ -329,9 +359,12 @@ def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 
     X = np.random.default_rng(0).normal(size=(400, 5))
-    for extra in (dict(thresh=0), dict(decay=None), dict(sample_idx=np.arange(400) % 2), dict(distance="cosine")):
+    for extra in (dict(decay=None), dict(sample_idx=np.arange(400) % 2), dict(distance="cosine")):
         with pytest.raises(NotImplementedError):
             meld_amd.MELD(bandwidth_scale=0.5, verbose=0, **extra).fit(X)
+    meld_amd.MELD(bandwidth_scale=0.5, thresh=0, verbose=0).fit(X)  # (round 6: the dense graph takes them, test_dense_graph_bandwidth_options_match_the_oracle)
+    with pytest.raises(NotImplementedError):
+        meld_amd.MELD(knn_max=9, thresh=0, verbose=0).fit(X)
     with pytest.raises(ValueError):
         meld_amd.MELD(bandwidth_scale=-1.0, verbose=0).fit(X)
     with pytest.raises(ValueError):
