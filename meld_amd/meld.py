@@ -201,10 +201,14 @@ class MELD(GraphEstimator):
         X, decay_m, bw_to_metric = metric_front_end(X, self.distance, self.decay)
         bw_opts = {k: opts[k] for k in ("bandwidth", "bandwidth_scale", "knn_max") if opts.get(k) is not None}
         dense_exact = self.thresh == 0 and self.decay is not None
-        if bw_opts and (opts.get("sample_idx") is not None or (dense_exact and "knn_max" in bw_opts) or self.decay is None
+        if self.decay is None and opts.get("sample_idx") is None:
+            # [UPSTREAM graphtools kNNGraph.build_kernel_to_data]: without alpha decay the kernel is the connectivity of the knn + 1
+            # nearest cells and the function returns before it looks at bandwidth, bandwidth_scale or knn_max: accepted, no effect
+            bw_opts = {}
+        if bw_opts and (opts.get("sample_idx") is not None or (dense_exact and "knn_max" in bw_opts)
                         or str(self.distance).lower() not in ("euclidean", "l2")):
             raise NotImplementedError("bandwidth / bandwidth_scale / knn_max are implemented for the euclidean alpha-decay graphs only -- the sparse kNN "
-                                      "graph, and (without knn_max) the dense graph of thresh=0 -- not with sample_idx, decay=None or another distance")
+                                      "graph, and (without knn_max) the dense graph of thresh=0 -- not with sample_idx or another distance")
         if callable(bw_opts.get("bandwidth")) and not dense_exact:
             # [UPSTREAM graphtools kNNGraph.__init__]: "Callable bandwidth is only supported by graphtools.graphs.TraditionalGraph."
             raise NotImplementedError("Callable bandwidth is only supported by the dense graph of thresh=0 (graphtools.graphs.TraditionalGraph)")

@@ -359,9 +359,13 @@ def test_bandwidth_options_are_refused_where_they_are_not_built():
     import meld_amd
 
     X = np.random.default_rng(0).normal(size=(400, 5))
-    for extra in (dict(decay=None), dict(sample_idx=np.arange(400) % 2), dict(distance="cosine")):
+    for extra in (dict(sample_idx=np.arange(400) % 2), dict(distance="cosine")):
         with pytest.raises(NotImplementedError):
             meld_amd.MELD(bandwidth_scale=0.5, verbose=0, **extra).fit(X)
+    # decay=None: upstream's unweighted kNN graph never looks at the bandwidth options -- accepted, no effect
+    Wa = meld_amd.MELD(decay=None, bandwidth_scale=0.5, knn_max=9, verbose=0).fit(X).graph.W
+    Wb = meld_amd.MELD(decay=None, verbose=0).fit(X).graph.W
+    assert Wa.nnz == Wb.nnz and abs(Wa - Wb).max() == 0
     meld_amd.MELD(bandwidth_scale=0.5, thresh=0, verbose=0).fit(X)  # (round 6: the dense graph takes them, test_dense_graph_bandwidth_options_match_the_oracle)
     with pytest.raises(NotImplementedError):
         meld_amd.MELD(knn_max=9, thresh=0, verbose=0).fit(X)
