@@ -25,9 +25,47 @@ namespace meld {
 
 constexpr int RB_FALL = 8;  // flagged rows per workgroup in the exact sweep
 #ifndef RF_U
+#define RF_UC 7  // rounds of 64 bytes per quad in flight in refine_kernel<true> (d = 50: the whole row)
 #define RF_U 5  // 16-byte loads of a candidate row in flight per lane in refine_kernel (measured at d = 50: 5 -> 3.3 ms,
                // 8 -> 4.1 ms, 12 -> 5.7 ms: more registers per lane cost more occupancy than they add in flight)
 #endif
+
+// Summation order of the exact squared distances (refine_kernel, radius_exact_kernel and pair_distances_kernel must agree bit
+// for bit: the sweep CONFIRMS bandwidths the other two produce).  Coordinate pairs (2 kk, 2 kk + 1), kk = 0 .. d / 2 - 1:
+//   * even d <= RF_DMAX ("four chains"): pair kk belongs to slot kk & 3; a slot adds its pairs in rising order, the even
+//     coordinate into one FMA chain and the odd one into another; u_j = even_j + odd_j; d2 = (u_0 + u_1) + (u_2 + u_3).
+//     This is the order in which four neighbouring lanes that read 64 contiguous bytes of a candidate row per instruction
+//     accumulate it (refine_kernel<true>), written out in scalar form by dist2_four_chains below.
+//   * any other d: one even and one odd chain over all coordinates, then their sum (the order of rounds 1-5).
+constexpr int RF_DMAX = 256;
+__host__ __device__ __forceinline__ bool rf_four_chains(int d) { return (d & 1) == 0 && d <= RF_DMAX; }
+
+__device__ __forceinline__ double dist2_four_chains(const double* __restrict__ xa, const double* __restrict__ xb, int d) {
+  const double2* a2 = reinterpret_cast<const double2*>(xa);
+  const double2* b2 = reinterpret_cast<const double2*>(xb);
+  const int nk = d >> 1;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  int kk = 0;
+  for (; kk + 4 <= nk; kk += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double2 a = a2[kk + j], b = b2[kk + j];
+      const double t0 = a.x - b.x, t1 = a.y - b.y;
+      s[j] = fma(t0, t0, s[j]);
+      s1[j] = fma(t1, t1, s1[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (kk + j < nk) {
+      const double2 a = a2[kk + j], b = b2[kk + j];
+      const double t0 = a.x - b.x, t1 = a.y - b.y;
+      s[j] = fma(t0, t0, s[j]);
+      s1[j] = fma(t1, t1, s1[j]);
+    }
+  }
+  return ((s[0] + s1[0]) + (s[1] + s1[1])) + ((s[2] + s1[2]) + (s[3] + s1[3]));
+}
 
 __device__ __forceinline__ double decay_kernel(double dist, double bw, double decay) {
   // decay = +inf: graphtools' decay=None, the unweighted kNN graph -- 1 for the knn + 1 nearest (self
@@ -38,7 +76,14 @@ __device__ __forceinline__ double decay_kernel(double dist, double bw, double de
   return v;
 }
 
-// one wave per query row; lane c owns candidates c and c + 64
+// one wave per query row; lane c owns candidates c and c + 64.
+// COOP (even d <= RF_DMAX; round 6): the candidate rows are read by FOUR lanes each -- 64 contiguous bytes per quad and
+// instruction, 16 candidates per pass -- instead of by their own lane.  With a lane per candidate every load instruction
+// touched as many cache lines as there were candidates (47 of a row's 59 listed ones are gathered at 1M x 50), and the kernel ran
+// at the rate of the vector L1, not of anything behind it: 1.5e9 tag accesses (TCP_TOTAL_CACHE_ACCESSES) in 7.4 M cycles on 256
+// CUs, TCP busy (TCP_GATE_EN1) 96 % of the time, L2 hit rate 85 %, 2.5-5 GB from the fabric for 18.7 GB gathered
+// (profiles/r06_refine_pmc.txt).  The query row sits in LDS; the four lanes' partial sums meet by two DPP exchanges.
+template <bool COOP>
 __global__ __launch_bounds__(256) void refine_kernel(
     const double* __restrict__ X, int d, int64_t q_begin, int64_t q_count, const int* __restrict__ cand_idx,
     const float* __restrict__ cand_d2, const int* __restrict__ cand_cnt, const float* __restrict__ cand_thr, int ksel,
@@ -54,14 +99,27 @@ __global__ __launch_bounds__(256) void refine_kernel(
   // candidate indices are copied into the first-stage index array so that later stages see one list
   const int64_t orow = rows ? (int64_t)rows[q] : q;
   const int64_t gi = q_begin + orow;
-  const int n = min(cand_cnt[q], ksel);
   const double* xi = X + gi * d;
   const size_t ro = (size_t)q * cap;
+  // (COOP: everything the row needs from its candidate list is requested at once, whatever its length turns out to be -- the
+  // chain count -> entry knn -> entries cost three round trips to L2 per row, a third of the kernel's time without its gather)
+  int idx_raw[2] = {0, 0};
+  float d2_raw[2] = {0.0f, 0.0f}, d2_knn = 0.0f;
+  if constexpr (COOP) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cc = min(lane + 64 * e, cap - 1);
+      idx_raw[e] = cand_idx[ro + cc];
+      d2_raw[e] = cand_d2[ro + cc];
+    }
+    d2_knn = cand_d2[ro + min(knn, cap - 1)];
+  }
+  const int n = min(cand_cnt[q], ksel);
 
   // search-error allowance: constant part + the part that scales with this row's own norm
   // (|q.r - q~.r~| <= c_lin |x_q| max|x_r|, the per-row form of the Cauchy-Schwarz bound)
   double E = err_coef * (double)norm2_max[0];
-  if (norm2 != nullptr) E += err_coef_lin * sqrt((double)norm2[gi] * (double)norm2_max[0]);
+  if (norm2 != nullptr && err_coef_lin > 0.0) E += err_coef_lin * sqrt((double)norm2[gi] * (double)norm2_max[0]);
   // Candidates that cannot lie inside the radius are not gathered: the list is sorted by approximate
   // d2, the exact (knn+1)-th distance^2 is <= approx[knn] + E, so radius^2 <= rf^2 (approx[knn] + E), and
   // a candidate with approx > rf^2 (approx[knn] + E) + E has exact d2 > radius^2 (>= bandwidth^2): it
@@ -74,11 +132,60 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const double rfix = fmax(bw_fixed[gi] * bw_scale, DBL_EPSILON) * radius_factor;
     skip_above = rfix * rfix * (1.0 + 1e-12) + E;
   } else if (n > knn) {
-    skip_above = skip_factor * skip_factor * ((double)cand_d2[ro + knn] + E) + E;
+    skip_above = skip_factor * skip_factor * ((double)(COOP ? d2_knn : cand_d2[ro + knn]) + E) + E;
   }
 
   double dist[2];
   int idx[2];
+  if constexpr (COOP) {
+    __shared__ __attribute__((aligned(16))) double xis[4][RF_DMAX];
+    __shared__ double dls[4][128];
+    const int w = threadIdx.x >> 6;
+    for (int k = lane; k < d; k += 64) xis[w][k] = xi[k];
+    bool gth[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = lane + 64 * e;
+      idx[e] = c < n ? idx_raw[e] : 0x7fffffff;
+      gth[e] = c < n && (double)d2_raw[e] <= skip_above;
+    }
+    // (the list is sorted by approximate d2: the gathered candidates are a prefix of it)
+    const int n_g = __popcll(__ballot(gth[0])) + __popcll(__ballot(gth[1]));
+    const int grp = lane >> 2, j = lane & 3, nk = d >> 1;
+    const double2* X2 = reinterpret_cast<const double2*>(X);
+    const double2* xi2 = reinterpret_cast<const double2*>(&xis[w][0]);
+    for (int c0 = 0; c0 < n_g; c0 += 16) {
+      const int c = c0 + grp;
+      const int i_lo = __shfl(idx[0], c & 63, 64), i_hi = __shfl(idx[1], c & 63, 64);
+      const bool ok = c < n_g;
+      const double2* xj2 = X2 + (int64_t)(ok ? (c < 64 ? i_lo : i_hi) : 0) * nk;
+      double s = 0.0, s1 = 0.0;
+      for (int k0 = 0; k0 < nk; k0 += 4 * RF_UC) {
+        double2 b[RF_UC];
+#pragma unroll
+        for (int u = 0; u < RF_UC; ++u) {
+          const int k = k0 + 4 * u + j;
+          if (ok && k < nk) b[u] = xj2[k];
+        }
+#pragma unroll
+        for (int u = 0; u < RF_UC; ++u) {
+          const int k = k0 + 4 * u + j;
+          if (ok && k < nk) {
+            const double2 a = xi2[k];
+            const double t0 = a.x - b[u].x, t1 = a.y - b[u].y;
+            s = fma(t0, t0, s);
+            s1 = fma(t1, t1, s1);
+          }
+        }
+      }
+      double u_ = s + s1;
+      u_ += __shfl_xor(u_, 1, 64);
+      u_ += __shfl_xor(u_, 2, 64);
+      if (ok && j == 0) dls[w][c] = sqrt(u_);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) dist[e] = gth[e] ? dls[w][lane + 64 * e] : INFINITY;
+  } else {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int c = lane + 64 * e;
@@ -133,6 +240,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
       dist[e] = INFINITY;
     }
   }
+  }
 
   // rank of each candidate by (dist, idx); the entry with rank == knn is the bandwidth.  The list is sorted by
   // approximate d2, so the candidates that were gathered are a prefix of it: the rest sit at +inf behind every finite
@@ -142,13 +250,32 @@ __global__ __launch_bounds__(256) void refine_kernel(
   const int n_fin = g1 ? 64 + (64 - __clzll((long long)g1)) : (g0 ? 64 - __clzll((long long)g0) : 0);
   int rk[2] = {0, 0};
   const int ne = (n_fin > 64) ? 2 : 1;
-  for (int e2 = 0; e2 < ne; ++e2) {
+  // Lists of at most 64 entries (every list, with ksel = 64) whose exact distances are all different -- nearly all of them -- are
+  // ranked by `<` alone, four instructions per source entry: with a tie the ranks of the tied entries coincide and the sum of the
+  // ranks falls short of n (n - 1) / 2, and only then is the list ranked again by (distance, index).
+  bool ranked = false;
+  if (ne == 1 && n <= 64) {
+    int r0 = 0;
+    for (int l2 = 0; l2 < n_fin; ++l2) {
+      // (l2 is uniform: the source entry travels through scalar registers -- v_readlane, not the LDS crossbar)
+      const double de = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dist[0]), l2), __builtin_amdgcn_readlane(__double2loint(dist[0]), l2));
+      r0 += (de < dist[0]) ? 1 : 0;
+    }
+    int sum = dist[0] < INFINITY ? r0 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (sum == n_fin * (n_fin - 1) / 2) {
+      rk[0] = r0;
+      ranked = true;
+    }
+  }
+  for (int e2 = 0; e2 < (ranked ? 0 : ne); ++e2) {
     const int lim = min(64, n_fin - 64 * e2);
     for (int l2 = 0; l2 < lim; ++l2) {
-      const double de = __shfl(dist[e2], l2, 64);
-      const int ie = __shfl(idx[e2], l2, 64);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) rk[e] += (de < dist[e] || (de == dist[e] && ie < idx[e])) ? 1 : 0;
+      const double de = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dist[e2]), l2), __builtin_amdgcn_readlane(__double2loint(dist[e2]), l2));
+      const int ie = __builtin_amdgcn_readlane(idx[e2], l2);
+      rk[0] += (de < dist[0] || (de == dist[0] && ie < idx[0])) ? 1 : 0;
+      if (n > 64) rk[1] += (de < dist[1] || (de == dist[1] && ie < idx[1])) ? 1 : 0;  // (lanes' second entries exist for lists beyond 64 only)
     }
   }
   double bw = 0.0;
@@ -220,7 +347,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
     int* __restrict__ fb_cnt, const int64_t* __restrict__ fb_off, int* __restrict__ fb_cursor,
     int* __restrict__ fb_col, double* __restrict__ fb_val, int* __restrict__ err_flag, int64_t ref_chunk,
     double radius_factor, double bw_scale) {
-  extern __shared__ double xq[];  // [RB_FALL][d]
+  extern __shared__ __attribute__((aligned(16))) double xq[];  // [RB_FALL][d]
   __shared__ int s_cnt[RB_FALL];
   __shared__ int s_lt[RB_FALL];
   // grid: x = group of RB_FALL flagged rows, y = chunk of the references (a handful of flagged rows must
@@ -258,8 +385,14 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
 
   for (int64_t ref = ref_lo + threadIdx.x; ref < ref_hi; ref += blockDim.x) {
     const double* xr = X + ref * d;
-    // same summation order as refine_kernel: even / odd coordinate chains, then their sum
+    // same summation order as refine_kernel (see the head of the file)
     double s[RB_FALL], s1[RB_FALL];
+    if (rf_four_chains(d)) {
+#pragma unroll
+      for (int f = 0; f < RB_FALL; ++f) s[f] = dist2_four_chains(xq + f * d, xr, d);
+#pragma unroll
+      for (int f = 0; f < RB_FALL; ++f) s1[f] = 0.0;
+    } else {
 #pragma unroll
     for (int f = 0; f < RB_FALL; ++f) s[f] = s1[f] = 0.0;
     for (int k = 0; k < d; ++k) {
@@ -277,6 +410,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
           s1[f] = fma(t, t, s1[f]);
         }
       }
+    }
     }
 #pragma unroll
     for (int f = 0; f < RB_FALL; ++f) s[f] += s1[f];
@@ -342,6 +476,10 @@ __global__ __launch_bounds__(256) void pair_distances_kernel(const double* __res
   if (e >= n * kk) return;
   const double* xq = X + rows[e / kk] * d;
   const double* xr = X + cand[e] * d;
+  if (rf_four_chains(d)) {
+    out[e] = sqrt(dist2_four_chains(xq, xr, d));
+    return;
+  }
   double s = 0.0, s1 = 0.0;
   for (int k = 0; k < d; ++k) {
     const double t = xq[k] - xr[k];
@@ -375,10 +513,16 @@ extern "C" int meld_knn_refine(const double* X, int64_t N, int d, int64_t q_begi
   MELD_CHECK_ARG(bw_scale > 0 && bw_scale < INFINITY, "meld_knn_refine: bandwidth_scale must be positive and finite");
   MELD_CHECK_ARG(max_rank == 0 || max_rank > knn, "meld_knn_refine: max_rank=%d must exceed knn=%d (or be 0)", max_rank, knn);
   const double radius_factor = pow(-log(thresh), 1.0 / decay);
-  hipLaunchKernelGGL(refine_kernel, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin,
-                     q_count, cand_idx, cand_d2, cand_cnt, cand_thr, ksel, cap, knn, decay, thresh, radius_factor, norm2_max,
-                     err_coef, norm2, err_coef_lin, bw_scale, bw_fixed, max_rank, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap,
-                     cand_idx_out);
+#define RF_LAUNCH(COOPV)                                                                                                          \
+  hipLaunchKernelGGL(refine_kernel<COOPV>, dim3((unsigned)ceil_div(q_count, 4)), dim3(256), 0, S(stream), X, d, q_begin, q_count,  \
+                     cand_idx, cand_d2, cand_cnt, cand_thr, ksel, cap, knn, decay, thresh, radius_factor, norm2_max, err_coef,     \
+                     norm2, err_coef_lin, bw_scale, bw_fixed, max_rank, bw, cand_val, keep_cnt, flag_rows, n_flag, rows, out_cap, \
+                     cand_idx_out)
+  if (rf_four_chains(d))
+    RF_LAUNCH(true);
+  else
+    RF_LAUNCH(false);
+#undef RF_LAUNCH
   MELD_LAUNCH_CHECK("refine_kernel");
   return MELD_OK;
 }

@@ -913,6 +913,15 @@ class HipOps:
         nmax_used = nmax
         if force_fallback:  # test hook: an infinite error bound flags every row
             nmax_used = torch.full((1,), float("inf"), dtype=torch.float32, device=dev)
+        if opt("MELD_REFINE_STATS") and bw_fixed is None:  # (development: how many candidate rows the refinement gathers per row)
+            c2 = cand_d2.view(-1, cap)[:q_count].to(torch.float64)
+            cn = cand_cnt[:q_count].clamp(max=ksel)
+            E_ = float(err_coef) * nmax.to(torch.float64) + float(err_lin) * torch.sqrt(norm2[q_begin : q_begin + q_count].to(torch.float64) * nmax.to(torch.float64))
+            rf_ = max((1.0 if math.isinf(decay) else float((-math.log(thresh)) ** (1.0 / decay))) * float(bw_scale), 1.0)
+            skip_ = rf_ * rf_ * (c2[:, min(knn, cap - 1)] + E_) + E_
+            g_ = ((c2 <= skip_[:, None]) & (torch.arange(cap, device=dev)[None, :] < cn[:, None])).sum(1).to(torch.float64)
+            print("[refine] rows %d  listed: mean %.1f  gathered: mean %.1f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
+                q_count, cn.to(torch.float64).mean(), g_.mean(), g_.median(), torch.quantile(g_, 0.9), torch.quantile(g_, 0.99), g_.max()), file=sys.stderr)
         check(
             lib.meld_knn_refine(
                 ptr(X), N, d, q_begin, q_count, ptr(cand_idx), ptr(cand_d2), ptr(cand_cnt), ptr(cand_thr), ksel, cap, knn, float(decay),
@@ -1581,7 +1590,7 @@ def _exact_bandwidth(X, rows, knn, n_refs=None):
         Xq = X[r]
         d2 = (Xq * Xq).sum(1)[:, None] + n2[None, :] - 2.0 * (Xq @ Xr.T)
         cand = torch.topk(d2, kk, dim=1, largest=False).indices.contiguous()
-        # the candidates' distances in the SWEEP's arithmetic (meld_knn_pair_distances: even / odd FMA chains): the sweep counts
+        # the candidates' distances in the SWEEP's arithmetic (meld_knn_pair_distances: the summation order of csrc/refine.hip): the sweep counts
         # the references strictly closer than the bandwidth with its own summation order, and confirms a bandwidth ranked from
         # these by construction.  (A library norm, two ulps down, was flagged again at d = 52: "could not settle".)
         dist = torch.empty(cand.shape, dtype=torch.float64, device=X.device)

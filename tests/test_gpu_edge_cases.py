@@ -111,6 +111,40 @@ def test_recomputed_bandwidths_are_ranked_in_the_sweeps_own_arithmetic(seed):
     assert DG.info["n_rows_bandwidth_recomputed"] > 100
 
 
+@pytest.mark.parametrize("d", [50, 52, 14, 7, 2, 100, 256, 300])
+def test_the_three_exact_distance_kernels_share_one_summation_order(d):
+    """refine_kernel (four lanes per candidate row for even d <= 256: slot kk & 3 takes coordinate pair kk; a lane per candidate
+    otherwise), the exact sweep and meld_knn_pair_distances must produce the SAME double for the same pair of cells
+    (csrc/refine.hip, head of the file): the bandwidth the refinement reports for a row is, bit for bit, the pair distance of the
+    row and its knn-th neighbour, and a build whose every row goes through the sweep (force_fallback) reports the same bandwidths
+    and kernel values as the build that refines candidate lists."""
+    from meld_amd._lib import check, get_lib, ptr
+    from meld_amd.graph import HipOps, _stream
+
+    rng = np.random.default_rng(d)
+    N, knn = 2500, 7
+    X = rng.normal(size=(N, d)) * rng.uniform(0.2, 2.0, size=d) + rng.normal(size=d)
+    Xd = torch.from_numpy(X).cuda()
+    ops = HipOps()
+    keys, vals, bw, info = ops.directed_kernel_coo(Xd, 0, N, knn, 40, 1e-4, 64)
+    keys2, vals2, bw2, info2 = ops.directed_kernel_coo(Xd, 0, N, knn, 40, 1e-4, 64, force_fallback=True)
+    assert info2["n_flagged_rows"] == N and (d > 64 or info["n_flagged_rows"] < N // 10)  # (in many isotropic dimensions the radius holds more cells than a candidate list)
+    assert torch.equal(bw, bw2)
+    a, b = ops.assemble_rows(keys, vals, 0, N, N), ops.assemble_rows(keys2, vals2, 0, N, N)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    D = torch.cdist(Xd, Xd)
+    kth = torch.argsort(D, dim=1)[:, knn].contiguous()  # (self is entry 0: entry knn is the (knn + 1)-th nearest, self counted)
+    rows = torch.arange(N, dtype=torch.int64, device="cuda")
+    out = torch.empty(N, dtype=torch.float64, device="cuda")
+    check(get_lib().meld_knn_pair_distances(ptr(Xd), d, ptr(rows), ptr(kth), N, 1, ptr(out), _stream()), "meld_knn_pair_distances")
+    torch.cuda.synchronize()
+    same = out == bw
+    # (cdist's own rounding may order two nearly equidistant cells the other way round: a handful of rows at most)
+    assert int((~same).sum()) <= 3, int((~same).sum())
+    assert float(((out - bw).abs() / bw).max()) < 1e-9
+
+
 @pytest.mark.parametrize("knn", [1, 2, 30, 60])
 def test_knn_range(knn):
     rng = np.random.default_rng(knn)
