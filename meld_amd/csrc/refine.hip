@@ -383,18 +383,44 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
 #pragma unroll
   for (int f = 0; f < RB_FALL; ++f) cnt[f] = lt[f] = 0;
 
-  for (int64_t ref = ref_lo + threadIdx.x; ref < ref_hi; ref += blockDim.x) {
+  // Four chains (even d <= RF_DMAX): FOUR threads per reference, thread j = slot j of the order at the head of the file -- it takes
+  // the coordinate pairs j, j + 4, ... (a quad reads 64 contiguous bytes of the reference per instruction, as refine_kernel<true>
+  // does), the quad joins its partial sums by two exchanges and its first thread goes on with the distance.  Other d: a thread
+  // per reference, one even and one odd chain.
+  const bool four = rf_four_chains(d);
+  const int tpr = four ? 4 : 1;  // threads per reference
+  const int jq = four ? (threadIdx.x & 3) : 0;
+  const int nk = d >> 1;
+  const double2* xq2 = reinterpret_cast<const double2*>(xq);
+  for (int64_t base = ref_lo; base < ref_hi; base += blockDim.x / tpr) {
+    const int64_t ref_raw = base + (four ? (threadIdx.x >> 2) : threadIdx.x);
+    const bool live = ref_raw < ref_hi;
+    const int64_t ref = live ? ref_raw : ref_hi - 1;
     const double* xr = X + ref * d;
-    // same summation order as refine_kernel (see the head of the file)
     double s[RB_FALL], s1[RB_FALL];
-    if (rf_four_chains(d)) {
-#pragma unroll
-      for (int f = 0; f < RB_FALL; ++f) s[f] = dist2_four_chains(xq + f * d, xr, d);
-#pragma unroll
-      for (int f = 0; f < RB_FALL; ++f) s1[f] = 0.0;
-    } else {
 #pragma unroll
     for (int f = 0; f < RB_FALL; ++f) s[f] = s1[f] = 0.0;
+    if (four) {
+      const double2* xr2 = reinterpret_cast<const double2*>(xr);
+      for (int kk = jq; kk < nk; kk += 4) {
+        const double2 b = xr2[kk];
+#pragma unroll
+        for (int f = 0; f < RB_FALL; ++f) {
+          const double2 a = xq2[f * nk + kk];
+          const double t0 = a.x - b.x, t1 = a.y - b.y;
+          s[f] = fma(t0, t0, s[f]);
+          s1[f] = fma(t1, t1, s1[f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < RB_FALL; ++f) {
+        double u = s[f] + s1[f];
+        u += __shfl_xor(u, 1, 64);
+        u += __shfl_xor(u, 2, 64);
+        s[f] = u;
+        s1[f] = 0.0;
+      }
+    } else {
     for (int k = 0; k < d; ++k) {
       const double xv = xr[k];
       if ((k & 1) == 0) {
@@ -412,6 +438,7 @@ __global__ __launch_bounds__(256) void radius_exact_kernel(
       }
     }
     }
+    if (!live || jq != 0) continue;
 #pragma unroll
     for (int f = 0; f < RB_FALL; ++f) s[f] += s1[f];
 #pragma unroll
