@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void cov_sample_kernel(const double* __restric
 // (Measured on the way, 1M x 50: V in LDS read at wave-uniform addresses, 14 LDS reads per 13 FMAs: 1.1 ms; the same with the tile
 // loads issued one by one behind a run-time trip count: 1.1 ms more; v_mfma_f64_16x16x4_f64 with V as B fragments: 0.93 ms, 0.75 of
 // them the MFMAs -- the fp64 matrix instruction runs far below its nominal rate here; 0.19 ms is what the memory side takes; this
-// version 0.69 ms: ~24 cycles per wave-wide fp64 FMA.)
+// version 0.69 ms: ~24 cycles per wave-wide fp64 FMA.  Round 6, the roles exchanged -- lane = column with its axis in registers,
+// the ROWS through scalar registers (s_load_dwordx16 of the row, its doubles as the scalar operand of 8 K8 FMAs, no LDS, no barrier,
+// the mean folded in as x . a - mean . a): correct, 0.7 ms again at d = 50 and 4.2 ms at d = 100 against 1.8 for the library GEMM --
+// 400 MB through the scalar data caches arrive at ~0.6 TB/s; the same with a row across the lanes and v_readlane (two per double) in
+// front of every FMA: 0.5 ms at d = 50, 2.9 at d = 100.  Not kept: 0.2 ms for a second kernel and a guard against cancellation.)
 typedef double f64x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) f64x8* const_f64x8_ptr;
 constexpr int FR_LD = FR_DMAX + 1;
