@@ -27,12 +27,9 @@ def _free_port():
 
 def _run(world, tmp_path, n, d, knn, n_labels, n_pca=0, extra_env=None):
     out = str(tmp_path / "res")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n), str(d), str(knn), str(n_labels), str(n_pca)]
-    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    from tests.conftest import run_ranks
+
+    run_ranks("dist_worker.py", [out, n, d, knn, n_labels, n_pca], world, timeout=600, env=extra_env)
     return [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
 
 
@@ -142,11 +139,9 @@ def test_sharded_filterbank_vfc(tmp_path):
     res = {}
     for world in (1, 2, 3):
         out = str(tmp_path / "vfc{}".format(world))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-               os.path.join(ROOT, "tests", "dist_worker_vfc.py"), out, "900", "6", "7"]
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        from tests.conftest import run_ranks
+
+        run_ranks("dist_worker_vfc.py", [out, 900, 6, 7], world)
         res[world] = [np.load(out + ".rank{}.npz".format(k)) for k in range(world)]
     ref = res[1][0]
     assert ref["spec"].shape == (900, 24 + 6) and np.isfinite(ref["spec"]).all() and ref["spec"].min() >= 0.0
@@ -165,11 +160,9 @@ def test_sharded_filterbank_vfc_wide_probe_block(tmp_path):
     res = {}
     for world in (1, 2):
         out = str(tmp_path / "vfcw{}".format(world))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-               os.path.join(ROOT, "tests", "dist_worker_vfc.py"), out, "900", "6", "7"]
-        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="2", MELD_TEST_PROBES="40"), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        from tests.conftest import run_ranks
+
+        run_ranks("dist_worker_vfc.py", [out, 900, 6, 7], world, env=dict(MELD_TEST_PROBES="40"))
         res[world] = [np.load(out + ".rank{}.npz".format(k)) for k in range(world)]
     ref = res[1][0]
     assert ref["spec"].shape == (900, 40 + 6) and np.isfinite(ref["spec"]).all()

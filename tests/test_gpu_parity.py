@@ -752,16 +752,10 @@ def test_two_ranks_on_one_gpu(tmp_path, world):
 
     mo = _oracle()
     n, d, knn = 20011, 16, 9
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from tests.conftest import run_ranks
+
     out = str(tmp_path / "res")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn)]
-    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    run_ranks("dist_worker_gpu.py", [out, n, d, knn], world)
     ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     single = meld_amd.MELD(knn=knn, beta=40, chebyshev_order=25, verbose=0)
@@ -791,16 +785,10 @@ def test_two_ranks_on_one_gpu_vfc_and_graph_options(tmp_path, mode):
 
     mo = _oracle()
     n, d, knn, world = 20011, 16, 9, 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from tests.conftest import run_ranks
+
     out = str(tmp_path / "res")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn), mode]
-    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    run_ranks("dist_worker_gpu.py", [out, n, d, knn, mode], world)
     ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     kw = dict(sample_idx=np.random.default_rng(3).choice(["s0", "s1"], size=n)) if mode == "mnn" else {}
@@ -837,16 +825,10 @@ def test_two_ranks_on_one_gpu_with_graph_keywords(tmp_path, opts, n):
 
     mo = _oracle()
     d, knn, world = 16, 9, 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from tests.conftest import run_ranks
+
     out = str(tmp_path / "res")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "dist_worker_gpu.py"), out, str(n), str(d), str(knn), "opt:" + json.dumps(opts)]
-    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    run_ranks("dist_worker_gpu.py", [out, n, d, knn, "opt:" + json.dumps(opts)], world)
     ranks = [np.load(out + ".rank{}.npz".format(r)) for r in range(world)]
     X, labels = mo.synthetic_cells(n, n_dims=d, seed=7)
     kw = dict(opts)
