@@ -322,7 +322,9 @@ int meld_knn_radius_exact(const double* X, int64_t N, int d, int64_t q_begin, co
                           meld_stream_t stream);
 /* out[i][c] = |X[rows[i]] - X[cand[i][c]]| (rows, cand: global row numbers; cand [n][kk]) in the summation order of meld_knn_refine
  * and meld_knn_radius_exact: a bandwidth ranked from these is one the sweep confirms (it counts the references strictly closer
- * in this arithmetic; a library norm differs by a few ulps at d ~ 50). */
+ * in this arithmetic; a library norm differs by a few ulps at d ~ 50).  The order (csrc/refine.hip): even d <= 256 -- coordinate pair
+ * kk in slot kk & 3, an even and an odd FMA chain per slot, d2 = (u0 + u1) + (u2 + u3); any other d -- one even and one odd chain.
+ * X must be 16-byte aligned when d is even (rows are read as pairs of doubles). */
 int meld_knn_pair_distances(const double* X, int d, const int64_t* rows, const int64_t* cand, int64_t n, int kk, double* out,
                             meld_stream_t stream);
 
