@@ -365,6 +365,8 @@ __global__ __launch_bounds__(256) void assign_nearest_mfma_kernel(const double* 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next chunk overwrites the rows)
       // row m = 8 (r / 4) + 4 h + r % 4 of the block is point m of the chunk; its minimum over the columns
+      // (a butterfly that halves what a lane carries at every step -- 16 exchanges instead of 16 x 5, lane l ending with row
+      // (l >> 1) & 15 -- keeps the 16 keys live across the exchanges: the ordering took 2.1 instead of 1.8 ms at 1M cells; not kept)
       unsigned mine = 0xffffffffu;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
